@@ -1,0 +1,185 @@
+/*
+ * tools/gen_amplicons.c — deterministic synthetic amplicon sets.
+ *
+ * This repo's own generator (nothing here comes from the reference).  Shapes:
+ *   - n/50 random centroids of length L (uniform ACGT), heavy-tailed
+ *     abundances  floor(20 * U^(-1/0.8)) + 2   (Pareto alpha = 0.8)
+ *   - the rest: pick a random existing (non-light) amplicon, apply `e` random
+ *     edits (60 % substitution, 20 % deletion, 20 % insertion; e = 1 for d=1
+ *     sets, uniform 1..max_edits otherwise), abundance =
+ *     max(1, floor(parent * U(0,0.3))), duplicates rejected
+ *   - with light_frac > 0 that fraction of the amplicons are abundance-1
+ *     "light" sequences at 2..3 edits from a non-light one and are never used
+ *     as parents (exercises --fastidious)
+ *   - output order shuffled; headers ">s<i>_<abundance>"
+ *
+ * Build:  gcc -O2 -o gen_amplicons tools/gen_amplicons.c          (CLI)
+ *         gcc -O2 -shared -fPIC -DGEN_NO_MAIN ...                   (library)
+ * CLI:    gen_amplicons <n> <L> <seed> <max_edits> <light_frac> <out.fasta>
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+typedef struct { uint64_t s; } rng_t;
+
+static uint64_t rng_next(rng_t * r) {            /* splitmix64 */
+  uint64_t z = (r->s += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static double rng_unit(rng_t * r) { return (double)(rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+static uint64_t rng_below(rng_t * r, uint64_t n) { return (uint64_t)(rng_unit(r) * (double)n); }
+
+typedef struct {
+  uint64_t off;     /* offset into the nucleotide pool */
+  uint16_t len;
+  uint8_t  light;
+  uint64_t abundance;
+} amp_t;
+
+static uint64_t seq_hash(const uint8_t * s, uint32_t len) {   /* FNV-1a over bases */
+  uint64_t h = 0xcbf29ce484222325ULL ^ len;
+  for (uint32_t i = 0; i < len; ++i) { h ^= s[i]; h *= 0x100000001b3ULL; }
+  return h ? h : 1;
+}
+
+typedef struct { uint64_t * key; uint32_t * val; uint64_t mask; } set_t;
+
+/* returns 1 if inserted, 0 if an identical sequence is already present */
+static int set_insert(set_t * t, const uint8_t * pool, const amp_t * amps,
+                      const uint8_t * s, uint32_t len, uint32_t id) {
+  const uint64_t h = seq_hash(s, len);
+  uint64_t i = h & t->mask;
+  while (t->key[i]) {
+    if (t->key[i] == h) {
+      const amp_t * a = &amps[t->val[i]];
+      if (a->len == len && memcmp(pool + a->off, s, len) == 0) return 0;
+    }
+    i = (i + 1) & t->mask;
+  }
+  t->key[i] = h; t->val[i] = id;
+  return 1;
+}
+
+static uint32_t apply_edit(rng_t * r, uint8_t * s, uint32_t len) {
+  const double u = rng_unit(r);
+  if (u < 0.6 || len < 8) {                        /* substitution */
+    const uint32_t p = (uint32_t)rng_below(r, len);
+    s[p] = (uint8_t)((s[p] + 1 + rng_below(r, 3)) & 3);
+    return len;
+  }
+  if (u < 0.8) {                                   /* deletion */
+    const uint32_t p = (uint32_t)rng_below(r, len);
+    memmove(s + p, s + p + 1, len - p - 1);
+    return len - 1;
+  }
+  {                                                /* insertion */
+    const uint32_t p = (uint32_t)rng_below(r, len + 1);
+    memmove(s + p + 1, s + p, len - p);
+    s[p] = (uint8_t)rng_below(r, 4);
+    return len + 1;
+  }
+}
+
+/* Generates the set and writes FASTA.  Returns 0 on success. */
+int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edits,
+                        double light_frac, const char * path) {
+  if (n == 0 || L < 8 || L > 60000 || max_edits == 0) return 1;
+  rng_t rng = { seed * 0x2545F4914F6CDD1DULL + 0x1234567ULL };
+  const uint32_t maxlen = L + 3 * max_edits + 8;
+  amp_t * amps = (amp_t *)calloc(n, sizeof(amp_t));
+  uint8_t * pool = (uint8_t *)malloc((size_t)n * maxlen);
+  uint32_t * heavy_ids = (uint32_t *)malloc(n * sizeof(uint32_t));
+  uint8_t * tmp = (uint8_t *)malloc(maxlen + 16);
+  set_t set; uint64_t cap = 4; while (cap < 2 * n + 16) cap <<= 1;
+  set.mask = cap - 1;
+  set.key = (uint64_t *)calloc(cap, sizeof(uint64_t));
+  set.val = (uint32_t *)calloc(cap, sizeof(uint32_t));
+  if (!amps || !pool || !heavy_ids || !tmp || !set.key || !set.val) return 2;
+
+  uint64_t centroids = n / 50; if (centroids < 1) centroids = 1;
+  uint64_t n_light = (uint64_t)(light_frac * (double)n);
+  if (n_light + centroids > n) n_light = n - centroids;
+  const uint64_t n_heavy = n - n_light;
+  uint64_t count = 0, heavy_count = 0;
+  size_t pool_used = 0;
+
+  while (count < n) {
+    uint32_t len;
+    uint64_t abundance;
+    uint8_t light = 0;
+    if (count < centroids) {
+      len = L;
+      for (uint32_t i = 0; i < len; ++i) tmp[i] = (uint8_t)(rng_next(&rng) >> 62);
+      double u = rng_unit(&rng); if (u < 1e-12) u = 1e-12;
+      double a = 20.0 * pow(u, -1.0 / 0.8) + 2.0;
+      if (a > 1e12) a = 1e12;
+      abundance = (uint64_t)a;
+    } else {
+      const amp_t * parent = &amps[heavy_ids[rng_below(&rng, heavy_count)]];
+      len = parent->len;
+      memcpy(tmp, pool + parent->off, len);
+      uint32_t edits;
+      if (count >= n_heavy) {                    /* light: 2..3 edits, abundance 1 */
+        light = 1;
+        edits = 2 + (uint32_t)rng_below(&rng, 2);
+        abundance = 1;
+      } else {
+        edits = 1 + (max_edits > 1 ? (uint32_t)rng_below(&rng, max_edits) : 0);
+        abundance = (uint64_t)((double)parent->abundance * (rng_unit(&rng) * 0.3));
+        if (abundance < 1) abundance = 1;
+      }
+      for (uint32_t e = 0; e < edits; ++e) len = apply_edit(&rng, tmp, len);
+    }
+    if (!set_insert(&set, pool, amps, tmp, len, (uint32_t)count)) continue;   /* duplicate */
+    amp_t * a = &amps[count];
+    a->off = pool_used; a->len = (uint16_t)len; a->light = light; a->abundance = abundance;
+    memcpy(pool + pool_used, tmp, len);
+    pool_used += len;
+    if (!light) heavy_ids[heavy_count++] = (uint32_t)count;
+    ++count;
+  }
+
+  /* shuffled output order */
+  uint32_t * order = (uint32_t *)malloc(n * sizeof(uint32_t));
+  if (!order) return 2;
+  for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+  for (uint64_t i = n - 1; i > 0; --i) {
+    const uint64_t j = rng_below(&rng, i + 1);
+    const uint32_t t = order[i]; order[i] = order[j]; order[j] = t;
+  }
+
+  FILE * fp = fopen(path, "w");
+  if (!fp) return 4;
+  static const char sym[4] = { 'A', 'C', 'G', 'T' };
+  char * line = (char *)malloc(maxlen + 64);
+  setvbuf(fp, NULL, _IOFBF, 1 << 22);
+  for (uint64_t k = 0; k < n; ++k) {
+    const amp_t * a = &amps[order[k]];
+    int w = sprintf(line, ">s%u_%llu\n", order[k], (unsigned long long)a->abundance);
+    for (uint32_t i = 0; i < a->len; ++i) line[w + (int)i] = sym[pool[a->off + i]];
+    line[w + a->len] = '\n';
+    fwrite(line, 1, (size_t)w + a->len + 1, fp);
+  }
+  fclose(fp);
+  free(line); free(order); free(set.key); free(set.val); free(tmp); free(heavy_ids); free(pool); free(amps);
+  return 0;
+}
+
+#ifndef GEN_NO_MAIN
+int main(int argc, char ** argv) {
+  if (argc != 7) {
+    fprintf(stderr, "usage: %s <n> <L> <seed> <max_edits> <light_frac> <out.fasta>\n", argv[0]);
+    return 2;
+  }
+  const int rc = gen_amplicons_fasta(strtoull(argv[1], NULL, 10), (uint32_t)atoi(argv[2]),
+                                     strtoull(argv[3], NULL, 10), (uint32_t)atoi(argv[4]),
+                                     atof(argv[5]), argv[6]);
+  if (rc) fprintf(stderr, "gen_amplicons: failed (%d)\n", rc);
+  return rc;
+}
+#endif
