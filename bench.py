@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the d=1 neighbour-finding path (seam B1) on N MI355X.
+
+One "step" = one full pass of the hot path over the synthetic amplicon set, through the
+C ABI, with the packed database already resident in HBM and the CSR left in HBM:
+    swa_d1_index_build   (sequence hashes, amplicon hash table, Bloom filter, duplicate check)
+    swa_d1_network_device (microvariant hashes -> Bloom -> table probe -> verify -> CSR)
+and, for N > 1, the RCCL all-gather of the per-rank CSR slices (hit counts, then padded hit
+lists) over xGMI.
+
+Workload at N = 1: BASELINE.json configs[1] — 1M synthetic amplicons x 150 bp, d = 1.
+For N > 1 the job is weak-scaled: the database holds N x 1M amplicons, replicated on every
+GPU (table + Bloom built per GPU), and rank r answers the queries of its contiguous 1M slice.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline"     — algorithmic bytes of the dominant kernel (k_d1_network) / its measured
+                   average duration (HIP events on the launch stream) vs the 8 TB/s HBM peak
+  "cpu_baseline" — the unmodified reference (oracle/_ref/swarm, kind "reference") or the C
+                   oracle (kind "port") timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(seqlen: np.ndarray, hits: int) -> float:
+    """per amplicon 8*ceil(L/32) (sequence) + 16 (hash, abundance)
+    + V(L)*8 (one 8-byte membership word per variant, V(L) = 6.75 L + 4.25) + 4 per hit."""
+    L = seqlen.astype(np.float64)
+    words = np.ceil(L / 32.0)
+    return float((8.0 * words + 16.0 + (6.75 * L + 4.25) * 8.0).sum() + 4.0 * hits)
+
+
+def gen_tool() -> Path:
+    out = ROOT / "tools" / "gen_amplicons"
+    src = ROOT / "tools" / "gen_amplicons.c"
+    if not out.exists() or out.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["gcc", "-O2", "-o", str(out), str(src), "-lm"], check=True)
+    return out
+
+
+def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
+    """Reference swarm (or, failing that, the C oracle) on this box's host cores, bounded sample."""
+    cores = os.cpu_count() or 1
+    ref = ROOT / "oracle" / "_ref" / "swarm"
+    sample_n = n if cores >= 8 else max(100_000, n // 4)
+    with tempfile.TemporaryDirectory() as tmp:
+        sample = fasta
+        if sample_n != n:
+            sample = Path(tmp) / "sample.fa"
+            subprocess.run([str(gen_tool()), str(sample_n), str(length), str(seed), "1", "0", str(sample)], check=True)
+        if ref.exists():
+            threads = min(cores, 256)
+            t0 = time.perf_counter()
+            subprocess.run([str(ref), "-d", "1", "-t", str(threads), "-o", "/dev/null", "-l", "/dev/null", str(sample)],
+                           check=True)
+            dt = time.perf_counter() - t0
+            return {"value": sample_n / dt, "unit": "amplicons/s", "cores": threads, "kind": "reference",
+                    "sample": f"reference swarm 3.1.6 -d 1 -t {threads}, whole run (FASTA read + network + clustering "
+                              f"+ output) on {sample_n} x {length} bp synthetic amplicons, {dt:.2f} s wall"}
+        # port: the single-threaded C oracle's network construction (test infrastructure, timed only)
+        sys.path.insert(0, str(ROOT / "tests"))
+        import support as S
+        from swarm_amd import HostDb
+        hdb = HostDb(sample)
+        db = S.Db(headers=[], seqs=hdb.seqs, seq_off=hdb.seq_off, seqlen=hdb.seqlen, abundance=hdb.abundance,
+                  longest=hdb.longest)
+        t0 = time.perf_counter()
+        S.oracle_d1_network(db)
+        dt = time.perf_counter() - t0
+        return {"value": sample_n / dt, "unit": "amplicons/s", "cores": 1, "kind": "port",
+                "sample": f"oracle/ C restatement, index build + network only, {sample_n} x {length} bp, {dt:.2f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--per-gpu", type=int, default=1_000_000, help="amplicons queried per GPU")
+    ap.add_argument("--length", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from swarm_amd import Context, HostDb
+
+    n_total = args.per_gpu * world
+    fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n_total}x{args.length}_s{args.seed}.fa"
+    if local_rank == 0 and not fasta.exists():
+        tmp = fasta.with_suffix(f".tmp{os.getpid()}")
+        subprocess.run([str(gen_tool()), str(n_total), str(args.length), str(args.seed), "1", "0", str(tmp)], check=True)
+        os.replace(tmp, fasta)
+    if world > 1:
+        dist.barrier()
+    hdb = HostDb(fasta)
+    assert hdb.n == n_total
+
+    # database resident in HBM before the timed region (torch owns the memory; the library adopts it)
+    def to_dev(a: np.ndarray, as_dtype) -> "torch.Tensor":
+        return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
+
+    seqs_pad = np.concatenate([hdb.seqs, np.zeros(2, dtype=np.uint64)])
+    t_seqs = to_dev(seqs_pad, np.int64)
+    t_off = to_dev(hdb.seq_off, np.int64)
+    t_len = to_dev(hdb.seqlen, np.int32)
+    t_ab = to_dev(hdb.abundance, np.int64)
+    stream = torch.cuda.current_stream(dev)
+    ctx = Context(local_rank, stream.cuda_stream)
+    ctx.attach_db(t_seqs, t_off, t_len, t_ab, hdb.longest)
+    ctx.timing_enable(True)
+
+    first = rank * args.per_gpu
+    count = args.per_gpu
+    cap = 8 * count
+    d_offsets = torch.zeros(count + 1, dtype=torch.int64, device=dev)
+    d_nb = torch.zeros(cap, dtype=torch.int32, device=dev)
+    if world > 1:
+        g_counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        g_offsets = torch.zeros(world * (count + 1), dtype=torch.int64, device=dev)
+        g_nb = torch.zeros(world * cap, dtype=torch.int32, device=dev)
+
+    kernel_ms = []
+    hits_seen = [0]
+
+    def step(record: bool) -> None:
+        dup = ctx.d1_index_build()
+        assert not dup
+        total = ctx.d1_network_device(d_offsets, d_nb, cap, False, first, count)
+        hits_seen[0] = total
+        if world > 1:
+            # exchange step named by the north star: all-gather hit counts, then the hit lists
+            # padded to the largest slice, so every rank holds the whole CSR
+            mine = torch.tensor([total], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(g_counts, mine)
+            longest = int(g_counts.max().item())
+            dist.all_gather_into_tensor(g_offsets, d_offsets)
+            dist.all_gather_into_tensor(g_nb[: world * longest].view(world, longest), d_nb[:longest].contiguous())
+        if record:
+            kernel_ms.append(ctx.timing_read()[3])
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    timings = ctx.timing_read()
+    if rank == 0:
+        ms_per_step = 1000.0 * elapsed / args.steps
+        value = n_total * args.steps / elapsed
+        k_ms = float(np.mean(kernel_ms))
+        abytes = algorithmic_bytes(hdb.seqlen[first:first + count], hits_seen[0])
+        achieved = abytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / "profiles" / "d1_network_pmc.json"
+        if pmc.exists():
+            try:
+                rec = json.loads(pmc.read_text())
+                if rec.get("workload") == f"{args.per_gpu}x{args.length}_s{args.seed}":
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "amplicons/sec clustered (d=1)",
+            "value": value,
+            "unit": "amplicons/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n_total} synthetic amplicons x {args.length} bp, d=1 (BASELINE configs[1] per GPU)",
+                "per_gpu_queries": count,
+                "db_amplicons": n_total,
+                "step": "swa_d1_index_build + swa_d1_network_device (B1 seam), db and CSR resident in HBM"
+                        + ("; RCCL all-gather of CSR slices" if world > 1 else ""),
+                "neighbour_links": int(hits_seen[0]),
+                "phase_ms": {"seqhash": timings[0], "table_bloom_build": timings[1], "dup_check": timings[2],
+                             "network_kernel": k_ms, "csr": timings[4]},
+            },
+            "roofline": {"bound": "hbm", "kernel": "k_d1_network", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": abytes, "avg_kernel_ms": k_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fasta, n_total, args.length, args.seed)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

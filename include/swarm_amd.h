@@ -1,0 +1,154 @@
+/*
+ * swarm_amd.h — C ABI of the MI355X-native amplicon neighbour-finding library
+ * (libswarm_amd.so, built from swarm_amd/csrc/ with hipcc --offload-arch=gfx950).
+ *
+ * The reference (torognes/swarm 3.1.6) has no plugin/FFI interface; its hot path is
+ * reached through four internal C++ call seams.  This header is the
+ * thin C ABI a maintainer would bind at exactly those seams: plain pointers and
+ * sizes, caller-allocated result buffers (as in the reference, where algo_d1_run /
+ * algo_run own every vector: src/algod1.cc:1104-1125, src/algo.cc:352-361), int
+ * status instead of fatal()+exit(1) (src/utils/fatal.cc:27-31).
+ *
+ *   seam  reference interface replaced                               entry point
+ *   ----  ---------------------------------------------------------  --------------------------
+ *   L2    global seqindex[] read through db_get*() (src/db.h:35-53)  swa_db_upload / swa_db_attach
+ *   B1    hash_insert loop + network_thread/check_variants           swa_d1_index_build
+ *         (src/algod1.cc:188-208, 606-670, 1122-1171)                swa_d1_network[_device]
+ *   B2    mark_light_thread / check_heavy_thread                     swa_d1_fastidious
+ *         (src/algod1.cc:453-552, 1411-1467)
+ *   B3    db_qgrams_init + qgram_diff_fast (src/db.cc:819-842,       swa_qgram_build
+ *         src/qgram.h:31-35)                                         swa_qgram_diff
+ *   B4    search_begin + search_do (src/scan.h:30-37, 259)           swa_search_begin / swa_search_do
+ *
+ * Amplicon numbering everywhere = the reference's db order after db_read():
+ * abundance descending, then header ascending (src/db.cc:388-413).  Sequences are
+ * 2-bit packed exactly as the reference packs them (A0 C1 G2 T/U3, 32 nt per
+ * little-endian u64, LSB first, zero padded: src/db.cc:541-628,
+ * src/utils/nt_codec.cc:35-75) but 8-byte aligned, one amplicon after the other.
+ *
+ * All functions are synchronous with respect to the caller unless the name ends in
+ * _device (those only enqueue on the context's HIP stream and leave results in HBM).
+ * One swa_ctx is bound to one GPU and one HIP stream; use one context per GPU (one
+ * process per GPU, or one host thread per GPU).  The library never falls back to the
+ * CPU: without a usable gfx950 device every call fails with SWA_E_DEVICE.
+ */
+#ifndef SWARM_AMD_H
+#define SWARM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWA_ABI_VERSION 1
+
+enum {
+  SWA_OK = 0,
+  SWA_E_DEVICE = 1,      /* no GPU / HIP runtime error (see swa_last_error) */
+  SWA_E_ARG = 2,         /* invalid argument or call order */
+  SWA_E_NOMEM = 3,       /* hipMalloc / host allocation failed */
+  SWA_E_CAPACITY = 4,    /* caller's result buffer too small; *total tells the need */
+  SWA_E_DUPLICATES = 5   /* identical sequences present (reference: fatal, src/algod1.cc:1141-1150) */
+};
+
+#define SWA_NO_AMPLICON 0xFFFFFFFFu   /* the reference's no_swarm (src/algod1.cc:80) */
+
+typedef struct swa_ctx swa_ctx;
+
+/* The packed amplicon database, n amplicons in db order.  Host or device pointers
+   depending on the call that takes it. */
+typedef struct swa_db_view {
+  uint32_t n;                  /* amplicons */
+  uint32_t longest;            /* longest sequence (nt) */
+  const uint64_t * seqs;       /* packed words, amplicon i at words [seq_off[i], seq_off[i+1]) */
+  const uint64_t * seq_off;    /* n+1 word offsets; seq_off[i+1]-seq_off[i] >= ceil(seqlen[i]/32) */
+  const uint32_t * seqlen;     /* n lengths, nt (>= 1) */
+  const uint64_t * abundance;  /* n abundances (>= 1) */
+} swa_db_view;
+
+/* ---- context ------------------------------------------------------------------ */
+int  swa_abi_version(void);
+/* device: HIP ordinal.  stream: a hipStream_t to run on (NULL -> the context creates
+   its own non-blocking stream). */
+int  swa_ctx_create(int device, void * stream, swa_ctx ** out);
+void swa_ctx_destroy(swa_ctx * ctx);
+/* message of the last failing call on this context ("" if none) */
+const char * swa_last_error(const swa_ctx * ctx);
+/* blocks until everything enqueued on the context's stream has finished */
+int  swa_ctx_synchronize(swa_ctx * ctx);
+
+/* Per-kernel timing with HIP events on the context's stream (off by default).
+   swa_timing_read: ms[0] seqhash, [1] table+Bloom build, [2] duplicate check,
+   [3] d1 network kernel, [4] CSR assembly, [5] fastidious light pass, [6] fastidious
+   heavy pass, [7] reserved — durations of the most recent launches. */
+int  swa_timing_enable(swa_ctx * ctx, int on);
+int  swa_timing_read(swa_ctx * ctx, float * ms8);
+
+/* ---- L2: database residency ---------------------------------------------------- */
+/* copy a host-resident database into HBM (replicated on this context's GPU) */
+int swa_db_upload(swa_ctx * ctx, const swa_db_view * host_db);
+/* adopt a database whose arrays are ALREADY device memory on this GPU (not copied,
+   not freed; must outlive the context's use of it) */
+int swa_db_attach(swa_ctx * ctx, const swa_db_view * device_db);
+
+/* ---- B1: d = 1 network --------------------------------------------------------- */
+/* Zobrist table (bit-identical to the reference's, src/zobrist.cc:49-80), seqhash[]
+   (src/db.cc:761), amplicon hash table and Bloom filter (src/hashtable.cc,
+   src/bloompat.cc) for ALL amplicons, built on the GPU.  *has_duplicates != 0 (and
+   SWA_E_DUPLICATES returned) when two amplicons have identical sequences. */
+int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates);
+
+/* Neighbour lists of amplicons [first, first+count) as CSR: offsets[count+1],
+   neighbours[offsets[count]]; row k = { j != first+k : seq_j is a microvariant of
+   seq_(first+k) and (no_cluster_breaking or abundance[first+k] >= abundance[j]) },
+   each neighbour once, ascending.  cap = capacity of `neighbours` in entries;
+   *total = entries needed.  SWA_E_CAPACITY if total > cap (offsets still valid). */
+int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
+                   uint64_t * offsets, uint32_t * neighbours, uint64_t cap, uint64_t * total);
+/* same, results left in HBM: d_offsets / d_neighbours are device pointers; only
+   enqueues + one 8-byte readback of *total */
+int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
+                          uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap, uint64_t * total);
+
+/* Introspection used by the parity tests (bit-exact against the oracle): copies to host.
+   what: 0 seqhash u64[n] · 1 Bloom bitmap u64[table_size/8] · 2 Zobrist table
+   u64[4*(longest+2)] · 3 probe statistics u64[8] of the last network call
+   {variants, bloom_pass, hash_match, verified, hits, 0,0,0} */
+int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out_bytes);
+uint64_t swa_d1_table_size(const swa_ctx * ctx);
+
+/* ---- B2: fastidious second pass ------------------------------------------------- */
+/* is_light[n]: != 0 when the amplicon's swarm has mass < boundary.  light_nt: total
+   nt of amplicons in light swarms; bloom_bits: --bloom-bits (src/algod1.cc:1337-1357).
+   graft_cand[n] <- min heavy amplicon id two microvariant steps away, or
+   SWA_NO_AMPLICON.  counters[0..4] = {light variants, heavy variants, graft
+   candidates, Bloom m (bits), Bloom k} = the reference's logged numbers
+   (src/algod1.cc:1394-1396, 1436-1438, 1469-1470). */
+int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
+                      uint32_t * graft_cand, uint64_t * counters);
+
+/* ---- B3: q-gram prefilter -------------------------------------------------------- */
+/* 1024-bit 5-mer parity signature per amplicon (src/qgram.cc:68-96), kept in HBM */
+int swa_qgram_build(swa_ctx * ctx);
+/* difflist[i] = ceil(popcount(sig[seed] xor sig[amplist[i]]) / 10)  (src/qgram.cc:247-252) */
+int swa_qgram_diff(swa_ctx * ctx, uint64_t seed, uint64_t listlen, const uint64_t * amplist,
+                   uint64_t * difflist);
+/* copy the signature matrix to host: out = u8[n][128] */
+int swa_qgram_debug_read(swa_ctx * ctx, uint8_t * out, size_t out_bytes);
+
+/* ---- B4: alignment scan ----------------------------------------------------------- */
+/* penalties after the reference's gcd reduction (src/swarm.cc:466-483): defaults
+   mismatch 18, gapopen 24, gapextend 13.  resolution d = -d value. */
+int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, uint64_t d);
+/* diffs[i] == the reference's search8/search16 + backtrack value whenever that value
+   is <= d; otherwise some value > d (the caller only tests diff <= d, src/algo.cc:460,
+   554).  scores / alignlengths may be NULL (never read by the reference's caller). */
+int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listlength, const uint64_t * targets,
+                  uint64_t * scores, uint64_t * diffs, uint64_t * alignlengths);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWARM_AMD_H */

@@ -1,0 +1,301 @@
+"""ctypes binding of libswarm_amd.so (include/swarm_amd.h) — the thin Python face of the
+C ABI used by the tests, bench.py and __graft_entry__.py.
+
+There is deliberately NO fallback here: if the HIP library is missing or no gfx950
+device is usable, everything raises.  Nothing in this package imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libswarm_amd.so"
+
+SWA_OK, SWA_E_DEVICE, SWA_E_ARG, SWA_E_NOMEM, SWA_E_CAPACITY, SWA_E_DUPLICATES = range(6)
+NO_AMPLICON = 0xFFFFFFFF
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class SwaError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libswarm_amd error {code}: {msg}")
+        self.code = code
+
+
+class DbView(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("longest", C.c_uint32), ("seqs", C.c_void_p), ("seq_off", C.c_void_p),
+                ("seqlen", C.c_void_p), ("abundance", C.c_void_p)]
+
+
+EXPORTS = [
+    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize",
+    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_network", "swa_d1_network_device",
+    "swa_d1_debug_read", "swa_d1_table_size", "swa_d1_fastidious", "swa_qgram_build", "swa_qgram_diff",
+    "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
+    "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
+    "swa_hostdb_header",
+]
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile every HIP translation unit for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", str(PKG / "csrc"), "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", str(PKG / "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libswarm_amd.so and declare the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+    lib = C.CDLL(str(LIB_PATH))
+    lib.swa_abi_version.restype = C.c_int
+    lib.swa_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.swa_ctx_destroy.argtypes = [C.c_void_p]
+    lib.swa_ctx_destroy.restype = None
+    lib.swa_last_error.argtypes = [C.c_void_p]
+    lib.swa_last_error.restype = C.c_char_p
+    lib.swa_ctx_synchronize.argtypes = [C.c_void_p]
+    lib.swa_db_upload.argtypes = [C.c_void_p, C.POINTER(DbView)]
+    lib.swa_db_attach.argtypes = [C.c_void_p, C.POINTER(DbView)]
+    lib.swa_d1_index_build.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.swa_d1_network.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                   C.c_uint64, u64p]
+    lib.swa_d1_network_device.argtypes = lib.swa_d1_network.argtypes
+    lib.swa_d1_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    lib.swa_d1_table_size.argtypes = [C.c_void_p]
+    lib.swa_d1_table_size.restype = C.c_uint64
+    lib.swa_d1_fastidious.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.swa_qgram_build.argtypes = [C.c_void_p]
+    lib.swa_qgram_diff.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.swa_qgram_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.swa_search_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.swa_search_do.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+    lib.swa_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.swa_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.swa_hostdb_read_fasta.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+    lib.swa_hostdb_free.argtypes = [C.c_void_p]
+    lib.swa_hostdb_free.restype = None
+    lib.swa_hostdb_error.argtypes = [C.c_void_p]
+    lib.swa_hostdb_error.restype = C.c_char_p
+    lib.swa_hostdb_view.argtypes = [C.c_void_p, C.POINTER(DbView)]
+    lib.swa_hostdb_view.restype = None
+    lib.swa_hostdb_nucleotides.argtypes = [C.c_void_p]
+    lib.swa_hostdb_nucleotides.restype = C.c_uint64
+    lib.swa_hostdb_header.argtypes = [C.c_void_p, C.c_uint32, u32p]
+    lib.swa_hostdb_header.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(a) -> int:
+    """Address of a numpy array (host) or of anything with data_ptr() (a torch tensor: device)."""
+    if a is None:
+        return 0
+    if hasattr(a, "data_ptr"):
+        return int(a.data_ptr())
+    return int(a.ctypes.data)
+
+
+class HostDb:
+    """Packed amplicon database on the host, read from FASTA by the library's own reader
+    (mirror of the reference's db_read, src/db.cc:432-803).  Arrays are numpy views into the
+    handle's memory (db order)."""
+
+    def __init__(self, path, usearch_abundance: bool = False, append_abundance: int = 0,
+                 check_duplicate_sequences: bool = False):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.swa_hostdb_read_fasta(str(path).encode(), int(usearch_abundance), int(append_abundance),
+                                            int(check_duplicate_sequences), C.byref(h))
+        self.h = h
+        if rc != SWA_OK:
+            msg = self.lib.swa_hostdb_error(h).decode() if h else "allocation failed"
+            self.close()
+            raise SwaError(rc, msg)
+        v = DbView()
+        self.lib.swa_hostdb_view(h, C.byref(v))
+        self.n = int(v.n)
+        self.longest = int(v.longest)
+        self.nucleotides = int(self.lib.swa_hostdb_nucleotides(h))
+
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count)
+
+        self.seq_off = view(v.seq_off, self.n + 1, np.uint64)
+        self.seqlen = view(v.seqlen, self.n, np.uint32)
+        self.abundance = view(v.abundance, self.n, np.uint64)
+        self.seqs = view(v.seqs, int(self.seq_off[self.n]) if self.n else 0, np.uint64)
+
+    def header(self, i: int) -> bytes:
+        return self.lib.swa_hostdb_header(self.h, i, None)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.swa_hostdb_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream.  Mirrors the reference's implicit global state for the path
+    (seqindex, hash table, Bloom filters) as an explicit handle."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.swa_ctx_create(device, C.c_void_p(stream or 0), C.byref(h))
+        if rc != SWA_OK:
+            raise SwaError(rc, "swa_ctx_create failed: no usable gfx950 device (there is no CPU fallback)")
+        self.h = h
+        self.n = 0
+        self._keep = None
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.swa_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, allow=()) -> int:
+        if rc != SWA_OK and rc not in allow:
+            raise SwaError(rc, self.lib.swa_last_error(self.h).decode())
+        return rc
+
+    def synchronize(self) -> None:
+        self._check(self.lib.swa_ctx_synchronize(self.h))
+
+    def timing_enable(self, on: bool = True) -> None:
+        self._check(self.lib.swa_timing_enable(self.h, int(on)))
+
+    def timing_read(self) -> list:
+        ms = (C.c_float * 8)()
+        self._check(self.lib.swa_timing_read(self.h, ms))
+        return [float(x) for x in ms]
+
+    def upload_hostdb(self, hdb: "HostDb") -> None:
+        self.upload_db(hdb.seqs, hdb.seq_off, hdb.seqlen, hdb.abundance, hdb.longest)
+
+    # ---- L2
+    def upload_db(self, seqs, seq_off, seqlen, abundance, longest: int) -> None:
+        """Host numpy arrays (db order) -> HBM."""
+        n = int(seqlen.shape[0])
+        v = DbView(n, int(longest), _ptr(seqs), _ptr(seq_off), _ptr(seqlen), _ptr(abundance))
+        self._check(self.lib.swa_db_upload(self.h, C.byref(v)))
+        self.n = n
+
+    def attach_db(self, seqs, seq_off, seqlen, abundance, longest: int) -> None:
+        """Arrays already in HBM (torch tensors on this GPU); not copied."""
+        n = int(seqlen.shape[0])
+        v = DbView(n, int(longest), _ptr(seqs), _ptr(seq_off), _ptr(seqlen), _ptr(abundance))
+        self._check(self.lib.swa_db_attach(self.h, C.byref(v)))
+        self._keep = (seqs, seq_off, seqlen, abundance)
+        self.n = n
+
+    # ---- B1
+    def d1_index_build(self) -> bool:
+        """Returns True when duplicate sequences were found (the reference aborts in that case)."""
+        dup = C.c_int(0)
+        self._check(self.lib.swa_d1_index_build(self.h, C.byref(dup)), allow=(SWA_E_DUPLICATES,))
+        return bool(dup.value)
+
+    def d1_network(self, no_cluster_breaking: bool = False, first: int = 0, count: int | None = None):
+        """CSR over [first, first+count): (offsets u64[count+1], neighbours u32[total]), rows ascending."""
+        if count is None:
+            count = self.n - first
+        offsets = np.zeros(count + 1, dtype=np.uint64)
+        cap = max(1024, 4 * count)
+        total = C.c_uint64(0)
+        while True:
+            nb = np.zeros(cap, dtype=np.uint32)
+            rc = self._check(self.lib.swa_d1_network(self.h, int(no_cluster_breaking), first, count,
+                                                     _ptr(offsets), _ptr(nb), cap, C.byref(total)),
+                             allow=(SWA_E_CAPACITY,))
+            if rc == SWA_OK:
+                return offsets, nb[:total.value]
+            cap = int(total.value)
+
+    def d1_network_device(self, d_offsets, d_neighbours, cap: int, no_cluster_breaking: bool = False,
+                          first: int = 0, count: int | None = None) -> int:
+        """Device-resident CSR (torch tensors); returns the number of neighbours written."""
+        if count is None:
+            count = self.n - first
+        total = C.c_uint64(0)
+        self._check(self.lib.swa_d1_network_device(self.h, int(no_cluster_breaking), first, count,
+                                                   _ptr(d_offsets), _ptr(d_neighbours), cap, C.byref(total)))
+        return int(total.value)
+
+    def d1_table_size(self) -> int:
+        return int(self.lib.swa_d1_table_size(self.h))
+
+    def d1_debug(self, what: int, count: int) -> np.ndarray:
+        out = np.zeros(count, dtype=np.uint64)
+        self._check(self.lib.swa_d1_debug_read(self.h, what, _ptr(out), out.nbytes))
+        return out
+
+    # ---- B2
+    def d1_fastidious(self, is_light: np.ndarray, light_nt: int, bloom_bits: int = 16):
+        is_light = np.ascontiguousarray(is_light, dtype=np.uint8)
+        graft = np.zeros(self.n, dtype=np.uint32)
+        counters = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.swa_d1_fastidious(self.h, _ptr(is_light), int(light_nt), int(bloom_bits),
+                                               _ptr(graft), _ptr(counters)))
+        return graft, counters
+
+    # ---- B3
+    def qgram_build(self) -> None:
+        self._check(self.lib.swa_qgram_build(self.h))
+
+    def qgram_diff(self, seed: int, amplist: np.ndarray) -> np.ndarray:
+        amplist = np.ascontiguousarray(amplist, dtype=np.uint64)
+        out = np.zeros(amplist.shape[0], dtype=np.uint64)
+        self._check(self.lib.swa_qgram_diff(self.h, int(seed), amplist.shape[0], _ptr(amplist), _ptr(out)))
+        return out
+
+    def qgram_signatures(self) -> np.ndarray:
+        out = np.zeros((self.n, 128), dtype=np.uint8)
+        self._check(self.lib.swa_qgram_debug_read(self.h, _ptr(out), out.nbytes))
+        return out
+
+    # ---- B4
+    def search_begin(self, mismatch: int = 18, gapopen: int = 24, gapextend: int = 13, d: int = 3) -> None:
+        self._check(self.lib.swa_search_begin(self.h, mismatch, gapopen, gapextend, d))
+
+    def search_do(self, query: int, targets: np.ndarray):
+        targets = np.ascontiguousarray(targets, dtype=np.uint64)
+        m = targets.shape[0]
+        scores = np.zeros(m, dtype=np.uint64)
+        diffs = np.zeros(m, dtype=np.uint64)
+        alens = np.zeros(m, dtype=np.uint64)
+        self._check(self.lib.swa_search_do(self.h, int(query), m, _ptr(targets), _ptr(scores), _ptr(diffs),
+                                           _ptr(alens)))
+        return scores, diffs, alens

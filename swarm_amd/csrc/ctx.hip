@@ -1,0 +1,164 @@
+// ctx.hip — context, error reporting, database residency (seam L2 of include/swarm_amd.h).
+#include "swa_internal.h"
+
+int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e) {
+  if (ctx != nullptr) {
+    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  return code;
+}
+
+int swa_fail_msg(swa_ctx * ctx, int code, const std::string & msg) {
+  if (ctx != nullptr) { ctx->err = msg; }
+  return code;
+}
+
+int swa_reserve(swa_ctx * ctx, swa_dbuf & buf, size_t bytes) {
+  if (bytes <= buf.bytes && buf.ptr != nullptr) { return SWA_OK; }
+  if (buf.ptr != nullptr) {
+    (void)hipFree(buf.ptr);
+    buf.ptr = nullptr;
+    buf.bytes = 0;
+  }
+  if (bytes == 0) { bytes = 16; }
+  const hipError_t e = hipMalloc(&buf.ptr, bytes);
+  if (e != hipSuccess) {
+    buf.ptr = nullptr;
+    return swa_fail(ctx, SWA_E_NOMEM, "hipMalloc", e);
+  }
+  buf.bytes = bytes;
+  return SWA_OK;
+}
+
+void swa_release(swa_dbuf & buf) {
+  if (buf.ptr != nullptr) { (void)hipFree(buf.ptr); }
+  buf.ptr = nullptr;
+  buf.bytes = 0;
+}
+
+extern "C" int swa_abi_version(void) { return SWA_ABI_VERSION; }
+
+extern "C" int swa_ctx_create(int device, void * stream, swa_ctx ** out) {
+  if (out == nullptr) { return SWA_E_ARG; }
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    return SWA_E_DEVICE;   // no CPU fallback, ever
+  }
+  if (hipSetDevice(device) != hipSuccess) { return SWA_E_DEVICE; }
+  hipDeviceProp_t prop{};
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { return SWA_E_DEVICE; }
+  auto * ctx = new swa_ctx();
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream != nullptr) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return SWA_E_DEVICE;
+    }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return SWA_OK;
+}
+
+extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
+  if (ctx == nullptr) { return; }
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (swa_dbuf * b : {&ctx->d_seqs, &ctx->d_seq_off, &ctx->d_seqlen, &ctx->d_abund, &ctx->d_zobrist,
+                       &ctx->d_seqhash, &ctx->d_table, &ctx->d_bloom, &ctx->d_patterns, &ctx->d_flags,
+                       &ctx->d_stats, &ctx->d_edges, &ctx->d_counts, &ctx->d_cursor, &ctx->d_scan_tmp,
+                       &ctx->d_offsets_tmp, &ctx->d_nb_tmp, &ctx->d_qgrams, &ctx->d_list_a, &ctx->d_list_b,
+                       &ctx->d_list_c, &ctx->d_list_d, &ctx->d_light, &ctx->d_graft, &ctx->d_bloomflex,
+                       &ctx->d_fpatterns, &ctx->d_queue, &ctx->d_fcounters}) {
+    swa_release(*b);
+  }
+  if (ctx->ev_ready) { for (auto & e : ctx->ev) { (void)hipEventDestroy(e); } }
+  if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); }
+  delete ctx;
+}
+
+extern "C" const char * swa_last_error(const swa_ctx * ctx) {
+  return ctx != nullptr ? ctx->err.c_str() : "null context";
+}
+
+extern "C" int swa_timing_enable(swa_ctx * ctx, int on) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  if (on != 0 && !ctx->ev_ready) {
+    for (auto & e : ctx->ev) { SWA_HIP(ctx, hipEventCreate(&e)); }
+    ctx->ev_ready = true;
+  }
+  ctx->timing = on != 0;
+  return SWA_OK;
+}
+
+extern "C" int swa_timing_read(swa_ctx * ctx, float * ms8) {
+  if (ctx == nullptr || ms8 == nullptr) { return SWA_E_ARG; }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < 8; ++s) {
+    ms8[s] = 0.0f;
+    if (ctx->ev_ready && ctx->ev_used[s]) { (void)hipEventElapsedTime(&ms8[s], ctx->ev[2 * s], ctx->ev[2 * s + 1]); }
+  }
+  return SWA_OK;
+}
+
+extern "C" int swa_ctx_synchronize(swa_ctx * ctx) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}
+
+static int check_view(swa_ctx * ctx, const swa_db_view * v) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (v == nullptr || v->seqs == nullptr || v->seq_off == nullptr || v->seqlen == nullptr ||
+      v->abundance == nullptr) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_db: null array in db view");
+  }
+  if (v->n == 0 || v->longest == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_db: empty database"); }
+  return SWA_OK;
+}
+
+static void invalidate(swa_ctx * ctx) {
+  ctx->d1_ready = false;
+  ctx->qgram_ready = false;
+}
+
+extern "C" int swa_db_upload(swa_ctx * ctx, const swa_db_view * h) {
+  SWA_TRY(check_view(ctx, h));
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t words = h->seq_off[h->n];
+  // one zero word of slack after the last sequence: kernels may read seq[nw] as padding
+  SWA_TRY(swa_reserve(ctx, ctx->d_seqs, (words + 2) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_seq_off, (uint64_t(h->n) + 1) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_seqlen, uint64_t(h->n) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_abund, uint64_t(h->n) * sizeof(uint64_t)));
+  SWA_HIP(ctx, hipMemsetAsync(static_cast<uint64_t *>(ctx->d_seqs.ptr) + words, 0, 2 * sizeof(uint64_t), ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_seqs.ptr, h->seqs, words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_seq_off.ptr, h->seq_off, (uint64_t(h->n) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_seqlen.ptr, h->seqlen, uint64_t(h->n) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_abund.ptr, h->abundance, uint64_t(h->n) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->db.n = h->n;
+  ctx->db.longest = h->longest;
+  ctx->db.seqs = static_cast<const uint64_t *>(ctx->d_seqs.ptr);
+  ctx->db.seq_off = static_cast<const uint64_t *>(ctx->d_seq_off.ptr);
+  ctx->db.seqlen = static_cast<const uint32_t *>(ctx->d_seqlen.ptr);
+  ctx->db.abundance = static_cast<const uint64_t *>(ctx->d_abund.ptr);
+  ctx->db_owned = true;
+  invalidate(ctx);
+  return SWA_OK;
+}
+
+extern "C" int swa_db_attach(swa_ctx * ctx, const swa_db_view * d) {
+  SWA_TRY(check_view(ctx, d));
+  ctx->db = *d;
+  ctx->db_owned = false;
+  invalidate(ctx);
+  return SWA_OK;
+}

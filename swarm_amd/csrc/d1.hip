@@ -1,0 +1,729 @@
+// d1.hip — seam B1: the d = 1 amplicon network on gfx950.
+//
+// Replaces (behaviourally) the reference's per-thread loop
+//   network_thread -> check_variants -> generate_variants + find_variant_matches
+// (src/algod1.cc:558-670, src/variants.cc:184-249) and the serial table build
+// (src/algod1.cc:188-208, 1122-1150).  Nothing here is a translation of that code:
+//
+//   * one 64-lane wavefront owns one query amplicon; lane l owns the K = ceil((L+1)/64)
+//     consecutive sequence positions [l*K, (l+1)*K).  The reference's serially
+//     incremental deletion / insertion hashes become three wave-wide XOR scans
+//     (exclusive prefix of Z[p][s_p], suffixes of Z[p-1][s_p] and Z[p+1][s_p]);
+//   * the 2-bit packed query, the Zobrist table and the 1024 Bloom patterns live in LDS;
+//   * every lane issues its Bloom-word loads 8 at a time (one position's substitutions,
+//     deletion and insertions) so a wave keeps up to 512 independent 8-byte HBM/L2
+//     reads in flight;
+//   * Bloom survivors (~2 % of the variants) are compacted with __ballot/__popcll into a
+//     per-wave LDS queue and drained 64 at a time, so the divergent part (table probe,
+//     abundance rule, exact verification) runs with full lanes;
+//   * the hash table is one 16-byte slot per entry (hash, amplicon id): one transaction
+//     per probe step instead of the reference's three arrays;
+//   * hits leave the wave as (source, target) edges through one atomicAdd per drain;
+//     a scan + scatter + per-row sort turns the edge list into the canonical CSR.
+//
+// All arithmetic is 64-bit integer XOR/shift/compare; results are bit-exact.
+#include "swa_internal.h"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int kWaves = 4;                 // waves per workgroup
+constexpr int kThreads = kWaves * 64;
+constexpr int kQueueCap = 128;            // per-wave candidate queue (>= 64 + 63)
+constexpr uint32_t kEmpty = SWA_NO_AMPLICON;
+constexpr size_t kMaxZobristLds = 96 * 1024;
+
+struct NetArgs {
+  const uint64_t * seqs;
+  const uint64_t * seq_off;
+  const uint32_t * seqlen;
+  const uint64_t * abundance;
+  const uint64_t * zobrist;     // 4 * zlen
+  uint32_t zlen;
+  uint32_t maxwords;            // ceil(longest / 32)
+  const swa_slot * table;
+  uint64_t tmask;
+  const uint64_t * bloom;
+  uint64_t bmask;
+  const uint64_t * patterns;    // 1024
+  int no_cluster_breaking;
+  uint32_t first;
+  uint32_t count;
+  uint64_t * edges;             // (src << 32) | dst
+  uint64_t edge_cap;
+  unsigned long long * edge_counter;
+  uint32_t * counts;            // per query amplicon (index k = amp - first)
+  unsigned long long * stats;   // [0] variants [1] bloom pass [2] hash match [3] verified
+};
+
+// ---- sequence hashes (db.cc:761 zobrist_hash) --------------------------------------
+template <bool ZLDS>
+__global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ seqs,
+                                                 const uint64_t * __restrict__ seq_off,
+                                                 const uint32_t * __restrict__ seqlen,
+                                                 const uint64_t * __restrict__ zobrist, uint32_t zlen,
+                                                 uint32_t n, uint64_t * __restrict__ seqhash) {
+  extern __shared__ uint64_t lds[];
+  const uint64_t * zob = zobrist;
+  if (ZLDS) {
+    for (uint32_t i = threadIdx.x; i < 4u * zlen; i += blockDim.x) { lds[i] = zobrist[i]; }
+    __syncthreads();
+    zob = lds;
+  }
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+    const uint64_t * s = seqs + seq_off[a];
+    const uint32_t len = seqlen[a];
+    uint64_t h = 0;
+    uint64_t word = 0;
+    for (uint32_t p = 0; p < len; ++p) {
+      if ((p & 31u) == 0u) { word = s[p >> 5]; }
+      h ^= zob[4u * p + (uint32_t)(word & 3u)];
+      word >>= 2;
+    }
+    seqhash[a] = h;
+  }
+}
+
+// ---- table + Bloom build (algod1.cc:188-208; insertion order is free) ---------------
+__global__ __launch_bounds__(256) void k_table_clear(swa_slot * table, uint64_t slots, uint64_t * bloom,
+                                                     uint64_t bloom_words) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride) {
+    swa_slot s;
+    s.hash = 0; s.amp = kEmpty; s.pad = 0;
+    table[i] = s;
+  }
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < bloom_words; i += stride) {
+    bloom[i] = ~0ull;          // inverted polarity, bloompat.cc:93-97
+  }
+}
+
+// inserts amplicons for which (is_member == nullptr || is_member[a] != 0)
+__global__ __launch_bounds__(256) void k_table_insert(const uint64_t * __restrict__ seqhash, uint32_t n,
+                                                      const uint8_t * __restrict__ is_member,
+                                                      swa_slot * table, uint64_t tmask,
+                                                      unsigned long long * bloom, uint64_t bmask,
+                                                      const uint64_t * __restrict__ patterns) {
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+    if (is_member != nullptr && is_member[a] == 0) { continue; }
+    const uint64_t h = seqhash[a];
+    uint64_t idx = (h >> 32) & tmask;                          // hashtable.cc:47-53
+    for (;;) {
+      const uint32_t old = atomicCAS(&table[idx].amp, kEmpty, a);
+      if (old == kEmpty) { break; }
+      idx = (idx + 1) & tmask;
+    }
+    table[idx].hash = h;
+    atomicAnd(&bloom[(h >> 10) & bmask], ~(unsigned long long)patterns[h & 1023u]);   // bloompat.cc:62-65
+  }
+}
+
+// identical sequences => flag (algod1.cc:174-208 detects this while inserting)
+__global__ __launch_bounds__(256) void k_dup_check(const uint64_t * __restrict__ seqs,
+                                                   const uint64_t * __restrict__ seq_off,
+                                                   const uint32_t * __restrict__ seqlen,
+                                                   const uint64_t * __restrict__ seqhash, uint32_t n,
+                                                   const swa_slot * __restrict__ table, uint64_t tmask,
+                                                   uint32_t * flag) {
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+    const uint64_t h = seqhash[a];
+    const uint32_t len = seqlen[a];
+    uint64_t idx = (h >> 32) & tmask;
+    for (;;) {
+      const swa_slot s = table[idx];
+      if (s.amp == kEmpty) { break; }
+      if (s.hash == h && s.amp != a && seqlen[s.amp] == len) {
+        const uint64_t * x = seqs + seq_off[a];
+        const uint64_t * y = seqs + seq_off[s.amp];
+        bool same = true;
+        for (uint32_t w = 0; w < ((len + 31u) >> 5); ++w) { same = same && (x[w] == y[w]); }
+        if (same) { atomicOr(flag, 1u); }
+      }
+      idx = (idx + 1) & tmask;
+    }
+  }
+}
+
+// ---- the network kernel --------------------------------------------------------------
+
+// one probe of the candidate (hash h, edit code) drawn from the queue: walk the cluster,
+// apply the abundance rule, verify exactly (algod1.cc:558-603, variants.cc:118-165)
+__device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64_t * sw, uint32_t slen,
+                                                 uint32_t snw, uint32_t seed, uint64_t seed_abundance,
+                                                 uint64_t h, uint32_t code, uint32_t & out_amp,
+                                                 uint32_t & n_match) {
+  const uint32_t type = code & 3u;
+  const uint32_t base = (code >> 2) & 3u;
+  const uint32_t pos = code >> 4;
+  const uint32_t vlen = (type == 0u) ? slen : (type == 1u ? slen - 1u : slen + 1u);
+  const uint32_t vnw = (vlen + 31u) >> 5;
+  uint64_t idx = (h >> 32) & a.tmask;
+  for (;;) {
+    const swa_slot s = a.table[idx];
+    if (s.amp == kEmpty) { return false; }
+    if (s.hash == h) {
+      ++n_match;
+      const uint32_t amp = s.amp;
+      if (amp != seed && (a.no_cluster_breaking != 0 || seed_abundance >= a.abundance[amp]) &&
+          a.seqlen[amp] == vlen) {
+        const uint64_t * y = a.seqs + a.seq_off[amp];
+        bool same = true;
+        for (uint32_t w = 0; w < vnw; ++w) {
+          same = same && (swa_variant_word(sw, snw, type, pos, base, w) == y[w]);
+        }
+        if (same) {
+          out_amp = amp;
+          return true;
+        }
+      }
+    }
+    idx = (idx + 1) & a.tmask;
+  }
+}
+
+template <bool ZLDS, bool STATS>
+__global__ __launch_bounds__(kThreads) void k_d1_network(const NetArgs a) {
+  extern __shared__ uint64_t lds[];
+  // LDS carve-up (all 8-byte aligned)
+  uint64_t * zob_lds = lds;
+  uint64_t * pat = lds + (ZLDS ? 4u * a.zlen : 0u);
+  uint64_t * wave_base = pat + 1024;
+  const uint32_t seed_words = a.maxwords + 2u;               // + zero padding words
+  const uint32_t per_wave = seed_words + kQueueCap + kQueueCap / 2;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t * sw = wave_base + (size_t)wave * per_wave;       // staged query words
+  uint64_t * qh = sw + seed_words;                           // queue: hashes
+  uint32_t * qc = reinterpret_cast<uint32_t *>(qh + kQueueCap);   // queue: edit codes
+
+  if (ZLDS) {
+    for (uint32_t i = threadIdx.x; i < 4u * a.zlen; i += kThreads) { zob_lds[i] = a.zobrist[i]; }
+  }
+  for (uint32_t i = threadIdx.x; i < 1024u; i += kThreads) { pat[i] = a.patterns[i]; }
+  __syncthreads();
+  const uint64_t * zob = ZLDS ? zob_lds : a.zobrist;
+
+  unsigned long long st_var = 0, st_pass = 0, st_match = 0, st_ver = 0;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+
+  const uint32_t nwaves = gridDim.x * kWaves;
+  for (uint32_t k = blockIdx.x * kWaves + wave; k < a.count; k += nwaves) {
+    const uint32_t seed = a.first + k;
+    const uint32_t len = a.seqlen[seed];
+    const uint32_t nw = (len + 31u) >> 5;
+    const uint64_t * gs = a.seqs + a.seq_off[seed];
+    const uint64_t seed_ab = a.abundance[seed];
+    for (uint32_t w = lane; w < nw + 2u; w += 64u) { sw[w] = (w < nw) ? gs[w] : 0ull; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- pass 1: per-lane XOR of the three Zobrist streams over the owned positions
+    const uint32_t K = (len + 64u) >> 6;                     // ceil((len + 1) / 64)
+    const uint32_t p0 = (uint32_t)lane * K;
+    uint64_t xa = 0, xd = 0, xi = 0;
+    for (uint32_t j = 0; j < K; ++j) {
+      const uint32_t p = p0 + j;
+      if (p < len) {
+        const uint32_t c = swa_nt(sw, p);
+        xa ^= zob[4u * p + c];
+        if (p >= 1u) { xd ^= zob[4u * (p - 1u) + c]; }
+        xi ^= zob[4u * (p + 1u) + c];
+      }
+    }
+    // wave scans: exclusive prefix of xa; inclusive suffix of xd, xi
+    uint64_t pa = xa, sd = xd, si = xi;
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1) {
+      const uint64_t ta = swa_shfl_up_u64(pa, d);
+      const uint64_t td = swa_shfl_down_u64(sd, d);
+      const uint64_t ti = swa_shfl_down_u64(si, d);
+      if (lane >= (int)d) { pa ^= ta; }
+      if (lane + (int)d < 64) { sd ^= td; si ^= ti; }
+    }
+    const uint64_t H = swa_shfl_u64(pa, 63);                 // == seqhash[seed]
+    pa ^= xa;                                                // exclusive
+
+    uint32_t qn = 0;          // queue fill (wave uniform)
+    uint32_t row = 0;         // hits of this amplicon (wave uniform)
+
+    auto drain = [&](uint32_t cnt) {
+      bool hit = false;
+      uint32_t amp = 0;
+      uint32_t nmatch = 0;
+      if ((uint32_t)lane < cnt) {
+        hit = probe_and_verify(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch);
+      }
+      const uint64_t hm = __ballot(hit);
+      if (STATS) {
+        for (int o = 32; o > 0; o >>= 1) { nmatch += __shfl_down(nmatch, o, 64); }
+        st_match += __shfl(nmatch, 0, 64);
+      }
+      if (hm != 0ull) {
+        const uint32_t nh = (uint32_t)__popcll(hm);
+        unsigned long long base = 0;
+        if (lane == 0) { base = atomicAdd(a.edge_counter, (unsigned long long)nh); }
+        base = swa_shfl_u64(base, 0);
+        if (hit) {
+          const unsigned long long at = base + (unsigned long long)__popcll(hm & lane_lt);
+          if (at < a.edge_cap) { a.edges[at] = ((uint64_t)seed << 32) | amp; }
+        }
+        row += nh;
+        if (STATS) { st_ver += nh; }
+      }
+    };
+
+    auto enqueue = [&](bool pass, uint64_t h, uint32_t code) {
+      const uint64_t m = __ballot(pass);
+      if (m == 0ull) { return; }
+      if (pass) {
+        const uint32_t at = qn + (uint32_t)__popcll(m & lane_lt);
+        qh[at] = h;
+        qc[at] = code;
+      }
+      qn += (uint32_t)__popcll(m);
+      if (STATS) { st_pass += (unsigned long long)__popcll(m); }
+      if (qn >= 64u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        drain(64u);
+        const uint32_t rest = qn - 64u;
+        uint64_t th = 0;
+        uint32_t tc = 0;
+        if ((uint32_t)lane < rest) { th = qh[64 + lane]; tc = qc[64 + lane]; }
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < rest) { qh[lane] = th; qc[lane] = tc; }
+        qn = rest;
+      }
+    };
+
+    // ---- pass 2: the variants of the owned positions, 8 Bloom loads in flight per lane
+    uint64_t sd_run = sd, si_run = si;
+    uint32_t prevc = (p0 >= 1u && p0 - 1u < len) ? swa_nt(sw, p0 - 1u) : 4u;
+    for (uint32_t j = 0; j < K; ++j) {
+      const uint32_t p = p0 + j;
+      const bool in_seq = p < len;
+      const bool in_ins = p <= len;
+      const uint32_t c = in_seq ? swa_nt(sw, p) : 4u;
+      uint64_t z[4];
+#pragma unroll
+      for (uint32_t b = 0; b < 4u; ++b) { z[b] = in_ins ? zob[4u * p + b] : 0ull; }
+      // z[c] without dynamic register indexing
+      const uint64_t zc = (c == 0u) ? z[0] : (c == 1u) ? z[1] : (c == 2u) ? z[2] : z[3];
+      const uint64_t za = in_seq ? zc : 0ull;
+      const uint64_t zd = (in_seq && p >= 1u) ? zob[4u * (p - 1u) + c] : 0ull;
+      const uint64_t zi = in_seq ? zob[4u * (p + 1u) + c] : 0ull;
+
+      uint64_t hs[8];
+      bool ok[8];
+      uint32_t code[8];
+      // insertions before position p (variants.cc:226-246): all 4 bases at p == 0,
+      // otherwise every base but the left neighbour
+#pragma unroll
+      for (uint32_t b = 0; b < 4u; ++b) {
+        hs[b] = pa ^ z[b] ^ si_run;
+        ok[b] = in_ins && (p == 0u || b != prevc);
+        code[b] = 2u | (b << 2) | (p << 4);
+      }
+      // substitutions at p (variants.cc:192-206): the three other bases
+#pragma unroll
+      for (uint32_t t = 0; t < 3u; ++t) {
+        const uint32_t b = (t < c) ? t : t + 1u;               // the t-th base that is not c
+        hs[4 + t] = H ^ za ^ ((t < c) ? z[t] : z[t + 1u]);
+        ok[4 + t] = in_seq;
+        code[4 + t] = 0u | (b << 2) | (p << 4);
+      }
+      // deletion of p (variants.cc:210-222): once per homopolymer run
+      hs[7] = pa ^ sd_run ^ zd;
+      ok[7] = in_seq && (p == 0u || c != prevc);
+      code[7] = 1u | (p << 4);
+
+      uint64_t word[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        word[s] = ok[s] ? a.bloom[(hs[s] >> 10) & a.bmask] : ~0ull;
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bool pass = ok[s] && ((word[s] & pat[hs[s] & 1023u]) == 0ull);   // bloompat.cc:68-71
+        if (STATS) { st_var += (unsigned long long)__popcll(__ballot(ok[s])); }
+        enqueue(pass, hs[s], code[s]);
+      }
+      // advance the running prefix / suffixes past position p
+      pa ^= za;
+      sd_run ^= zd;
+      si_run ^= zi;
+      prevc = c;
+    }
+    if (qn > 0u) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      drain(qn);
+    }
+    if (lane == 0) { a.counts[k] = row; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (STATS && lane == 0) {
+    atomicAdd(&a.stats[0], st_var);
+    atomicAdd(&a.stats[1], st_pass);
+    atomicAdd(&a.stats[2], st_match);
+    atomicAdd(&a.stats[3], st_ver);
+  }
+}
+
+// ---- CSR assembly: counts -> offsets (exclusive scan), edges -> rows, sort rows ------
+constexpr int kScanItems = 8;
+constexpr int kScanBlock = 256;
+constexpr int kScanTile = kScanItems * kScanBlock;
+
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t * smem, uint64_t & total) {
+  // v: per-thread value; returns exclusive prefix within the block (256 threads)
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint64_t incl = v;
+#pragma unroll
+  for (unsigned d = 1; d < 64; d <<= 1) {
+    const uint64_t t = swa_shfl_up_u64(incl, d);
+    if (lane >= (int)d) { incl += t; }
+  }
+  if (lane == 63) { smem[wave] = incl; }
+  __syncthreads();
+  uint64_t wave_off = 0;
+  uint64_t tot = 0;
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    if (w < wave) { wave_off += smem[w]; }
+    tot += smem[w];
+  }
+  __syncthreads();
+  total = tot;
+  return wave_off + incl - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const uint32_t * __restrict__ counts, uint32_t n,
+                                                           uint64_t * __restrict__ tile_sums) {
+  __shared__ uint64_t smem[4];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint64_t v = 0;
+  for (int i = 0; i < kScanItems; ++i) { if (base + i < n) { v += counts[base + i]; } }
+  uint64_t total;
+  (void)block_exclusive_scan(v, smem, total);
+  if (threadIdx.x == 0) { tile_sums[blockIdx.x] = total; }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums(uint64_t * tile_sums, uint32_t tiles) {
+  __shared__ uint64_t smem[4];
+  uint64_t carry = 0;
+  for (uint32_t base = 0; base < tiles; base += kScanBlock) {
+    const uint32_t i = base + threadIdx.x;
+    const uint64_t v = (i < tiles) ? tile_sums[i] : 0;
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan(v, smem, total);
+    if (i < tiles) { tile_sums[i] = carry + ex; }
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t * __restrict__ counts, uint32_t n,
+                                                           const uint64_t * __restrict__ tile_sums,
+                                                           uint64_t * __restrict__ offsets) {
+  __shared__ uint64_t smem[4];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t c[kScanItems];
+  uint64_t v = 0;
+  for (int i = 0; i < kScanItems; ++i) {
+    c[i] = (base + i < n) ? counts[base + i] : 0u;
+    v += c[i];
+  }
+  uint64_t total;
+  uint64_t run = tile_sums[blockIdx.x] + block_exclusive_scan(v, smem, total);
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) { offsets[base + i] = run; }
+    run += c[i];
+    if (base + i + 1 == n) { offsets[n] = run; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_edges(const uint64_t * __restrict__ edges, uint64_t n_edges,
+                                                       uint32_t first, const uint64_t * __restrict__ offsets,
+                                                       uint32_t * cursor, uint32_t * __restrict__ neighbours,
+                                                       uint64_t cap) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += stride) {
+    const uint64_t edge = edges[e];
+    const uint32_t k = (uint32_t)(edge >> 32) - first;
+    const uint64_t at = offsets[k] + atomicAdd(&cursor[k], 1u);
+    if (at < cap) { neighbours[at] = (uint32_t)edge; }
+  }
+}
+
+// rows are tiny (about two neighbours per amplicon): one thread insertion-sorts a row;
+// long rows (> 64) are sorted by a whole wave with an odd-even transposition sort
+__global__ __launch_bounds__(256) void k_sort_rows(const uint64_t * __restrict__ offsets, uint32_t count,
+                                                   uint32_t * neighbours, uint64_t cap) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+    const uint64_t b = offsets[k];
+    const uint64_t e = offsets[k + 1];
+    if (e > cap || e - b < 2 || e - b > 64) { continue; }
+    for (uint64_t i = b + 1; i < e; ++i) {
+      const uint32_t v = neighbours[i];
+      uint64_t j = i;
+      while (j > b && neighbours[j - 1] > v) { neighbours[j] = neighbours[j - 1]; --j; }
+      neighbours[j] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_sort_long_rows(const uint64_t * __restrict__ offsets, uint32_t count,
+                                                       uint32_t * neighbours, uint64_t cap) {
+  // one wave per row, grid-stride over rows; only rows longer than 64 do work
+  const int lane = threadIdx.x;
+  for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+    const uint64_t b = offsets[k];
+    const uint64_t e = offsets[k + 1];
+    const uint64_t len = e - b;
+    if (e > cap || len <= 64) { continue; }
+    for (uint64_t phase = 0; phase < len; ++phase) {
+      for (uint64_t i = (phase & 1u) + 2ull * lane; i + 1 < len; i += 128) {
+        const uint32_t x = neighbours[b + i];
+        const uint32_t y = neighbours[b + i + 1];
+        if (x > y) { neighbours[b + i] = y; neighbours[b + i + 1] = x; }
+      }
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+int grid_for(const swa_ctx * ctx, uint64_t items, int per_block, int max_per_cu) {
+  uint64_t blocks = (items + per_block - 1) / per_block;
+  const uint64_t cap = (uint64_t)ctx->num_cus * max_per_cu;
+  if (blocks > cap) { blocks = cap; }
+  if (blocks < 1) { blocks = 1; }
+  return (int)blocks;
+}
+
+}  // namespace
+
+// shared with fastidious.hip
+int swa_d1_rebuild_table(swa_ctx * ctx, const uint8_t * d_is_member) {
+  const uint32_t n = ctx->db.n;
+  hipLaunchKernelGGL(k_table_clear, dim3(grid_for(ctx, ctx->table_size, 256, 8)), dim3(256), 0, ctx->stream,
+                     static_cast<swa_slot *>(ctx->d_table.ptr), ctx->table_size,
+                     static_cast<uint64_t *>(ctx->d_bloom.ptr), ctx->bloom_words);
+  hipLaunchKernelGGL(k_table_insert, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream,
+                     static_cast<const uint64_t *>(ctx->d_seqhash.ptr), n, d_is_member,
+                     static_cast<swa_slot *>(ctx->d_table.ptr), ctx->table_size - 1,
+                     static_cast<unsigned long long *>(ctx->d_bloom.ptr), ctx->bloom_words - 1,
+                     static_cast<const uint64_t *>(ctx->d_patterns.ptr));
+  SWA_HIP(ctx, hipGetLastError());
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build: no database"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  ctx->d1_ready = false;
+  ctx->zobrist_len = ctx->db.longest + 2;                  // db.cc:652-653 (sequence part)
+  ctx->table_size = swa_hashtable_size(n);
+  const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
+  ctx->bloom_words = bloom_bytes >> 3;
+
+  std::vector<uint64_t> zob;
+  std::vector<uint64_t> pat;
+  swa_zobrist_table(ctx->zobrist_len, zob);
+  swa_bloom_patterns(1024, 8, pat);
+  SWA_TRY(swa_reserve(ctx, ctx->d_zobrist, zob.size() * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_patterns, pat.size() * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_seqhash, uint64_t(n) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_table, ctx->table_size * sizeof(swa_slot)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_bloom, ctx->bloom_words * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_zobrist.ptr, zob.data(), zob.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_patterns.ptr, pat.data(), pat.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));        // zob / pat are host temporaries
+
+  const size_t zbytes = zob.size() * sizeof(uint64_t);
+  const int hgrid = grid_for(ctx, n, 256, 8);
+  swa_t0(ctx, 0);
+  if (zbytes <= kMaxZobristLds) {
+    hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                       ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr));
+  } else {
+    hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                       ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr));
+  }
+  SWA_HIP(ctx, hipGetLastError());
+  swa_t1(ctx, 0);
+  swa_t0(ctx, 1);
+  SWA_TRY(swa_d1_rebuild_table(ctx, nullptr));
+  swa_t1(ctx, 1);
+  swa_t0(ctx, 2);
+  hipLaunchKernelGGL(k_dup_check, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_seqhash.ptr), n,
+                     static_cast<const swa_slot *>(ctx->d_table.ptr), ctx->table_size - 1,
+                     static_cast<uint32_t *>(ctx->d_flags.ptr));
+  SWA_HIP(ctx, hipGetLastError());
+  swa_t1(ctx, 2);
+  uint32_t flag = 0;
+  SWA_HIP(ctx, hipMemcpyAsync(&flag, ctx->d_flags.ptr, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->d1_ready = true;
+  if (has_duplicates != nullptr) { *has_duplicates = flag != 0 ? 1 : 0; }
+  if (flag != 0) {
+    return swa_fail_msg(ctx, SWA_E_DUPLICATES, "some fasta entries have identical sequences");
+  }
+  return SWA_OK;
+}
+
+extern "C" uint64_t swa_d1_table_size(const swa_ctx * ctx) { return ctx != nullptr ? ctx->table_size : 0; }
+
+static size_t network_lds_bytes(const swa_ctx * ctx, bool zlds) {
+  const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
+  const size_t per_wave = (size_t)(maxwords + 2u) + kQueueCap + kQueueCap / 2;
+  return sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull + kWaves * per_wave);
+}
+
+// launches the network kernel for [first, first+count); leaves the edge list, the
+// per-amplicon counts and the edge counter on the device
+static int launch_network(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count, bool stats) {
+  NetArgs a{};
+  a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen; a.abundance = ctx->db.abundance;
+  a.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
+  a.zlen = ctx->zobrist_len;
+  a.maxwords = (ctx->db.longest + 31u) >> 5;
+  a.table = static_cast<const swa_slot *>(ctx->d_table.ptr);
+  a.tmask = ctx->table_size - 1;
+  a.bloom = static_cast<const uint64_t *>(ctx->d_bloom.ptr);
+  a.bmask = ctx->bloom_words - 1;
+  a.patterns = static_cast<const uint64_t *>(ctx->d_patterns.ptr);
+  a.no_cluster_breaking = ncb;
+  a.first = first; a.count = count;
+  a.edges = static_cast<uint64_t *>(ctx->d_edges.ptr);
+  a.edge_cap = ctx->d_edges.bytes / sizeof(uint64_t);
+  a.stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
+  a.edge_counter = a.stats + 8;
+  a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
+  const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
+  const size_t lds = network_lds_bytes(ctx, zlds);
+  const int grid = grid_for(ctx, count, kWaves, 8);
+  swa_t0(ctx, 3);
+  if (zlds && stats) {
+    hipLaunchKernelGGL((k_d1_network<true, true>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+  } else if (zlds) {
+    hipLaunchKernelGGL((k_d1_network<true, false>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+  } else if (stats) {
+    hipLaunchKernelGGL((k_d1_network<false, true>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL((k_d1_network<false, false>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+  }
+  swa_t1(ctx, 3);
+  SWA_HIP(ctx, hipGetLastError());
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
+                                     uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap, uint64_t * total) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: call swa_d1_index_build first"); }
+  if (count == 0 || (uint64_t)first + count > ctx->db.n || d_offsets == nullptr || total == nullptr ||
+      (d_neighbours == nullptr && cap != 0)) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: bad range or null buffer");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const char * env_stats = getenv("SWA_D1_STATS");
+  const bool stats = env_stats != nullptr && env_stats[0] == '1';
+  SWA_TRY(swa_reserve(ctx, ctx->d_counts, uint64_t(count) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_cursor, uint64_t(count) * sizeof(uint32_t)));
+  const uint32_t tiles = (count + kScanTile - 1) / kScanTile;
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
+  if (ctx->d_edges.bytes == 0) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_edges, (uint64_t(count) * 4 + 1024) * sizeof(uint64_t)));
+  }
+  uint64_t n_edges = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    SWA_TRY(launch_network(ctx, no_cluster_breaking, first, count, stats));
+    SWA_HIP(ctx, hipMemcpyAsync(&n_edges, static_cast<uint64_t *>(ctx->d_stats.ptr) + 8, sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_edges * sizeof(uint64_t) <= ctx->d_edges.bytes) { break; }
+    // edge list did not fit: grow to the exact need and run again (rare: > 4 hits / amplicon)
+    SWA_TRY(swa_reserve(ctx, ctx->d_edges, n_edges * sizeof(uint64_t)));
+  }
+  *total = n_edges;
+  // CSR: offsets are always complete; neighbours only if they fit
+  swa_t0(ctx, 4);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+                     static_cast<const uint32_t *>(ctx->d_counts.ptr), count, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
+  hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+                     static_cast<const uint32_t *>(ctx->d_counts.ptr), count,
+                     static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), d_offsets);
+  SWA_HIP(ctx, hipGetLastError());
+  if (n_edges > cap) {
+    swa_t1(ctx, 4);
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network: neighbour buffer too small");
+  }
+  if (n_edges > 0) {
+    SWA_HIP(ctx, hipMemsetAsync(ctx->d_cursor.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_scatter_edges, dim3(grid_for(ctx, n_edges, 256, 8)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint64_t *>(ctx->d_edges.ptr), n_edges, first, d_offsets,
+                       static_cast<uint32_t *>(ctx->d_cursor.ptr), d_neighbours, cap);
+    hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, d_offsets, count,
+                       d_neighbours, cap);
+    hipLaunchKernelGGL(k_sort_long_rows, dim3(grid_for(ctx, count, 1, 16)), dim3(64), 0, ctx->stream, d_offsets,
+                       count, d_neighbours, cap);
+    SWA_HIP(ctx, hipGetLastError());
+  }
+  swa_t1(ctx, 4);
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
+                              uint64_t * offsets, uint32_t * neighbours, uint64_t cap, uint64_t * total) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (offsets == nullptr || total == nullptr) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: null buffer"); }
+  SWA_TRY(swa_reserve(ctx, ctx->d_offsets_tmp, (uint64_t(count) + 1) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_nb_tmp, (cap > 0 ? cap : 1) * sizeof(uint32_t)));
+  const int rc = swa_d1_network_device(ctx, no_cluster_breaking, first, count,
+                                       static_cast<uint64_t *>(ctx->d_offsets_tmp.ptr),
+                                       static_cast<uint32_t *>(ctx->d_nb_tmp.ptr), cap, total);
+  if (rc != SWA_OK && rc != SWA_E_CAPACITY) { return rc; }
+  SWA_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_offsets_tmp.ptr, (uint64_t(count) + 1) * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  if (rc == SWA_OK && *total > 0) {
+    SWA_HIP(ctx, hipMemcpyAsync(neighbours, ctx->d_nb_tmp.ptr, *total * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  }
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return rc;
+}
+
+extern "C" int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out_bytes) {
+  if (ctx == nullptr || out == nullptr) { return SWA_E_ARG; }
+  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: no index"); }
+  const void * src = nullptr;
+  size_t bytes = 0;
+  switch (what) {
+    case 0: src = ctx->d_seqhash.ptr; bytes = uint64_t(ctx->db.n) * sizeof(uint64_t); break;
+    case 1: src = ctx->d_bloom.ptr; bytes = ctx->bloom_words * sizeof(uint64_t); break;
+    case 2: src = ctx->d_zobrist.ptr; bytes = 4ull * ctx->zobrist_len * sizeof(uint64_t); break;
+    case 3: src = ctx->d_stats.ptr; bytes = 8 * sizeof(uint64_t); break;
+    default: return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: unknown selector");
+  }
+  if (out_bytes < bytes) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_debug_read: buffer too small"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}

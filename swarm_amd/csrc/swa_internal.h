@@ -1,0 +1,153 @@
+// swa_internal.h — shared by the HIP translation units of libswarm_amd.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/swarm_amd.h"
+
+// ---- device-side layout of one amplicon hash-table slot ----------------------------
+// The reference keeps an occupied bitmap + u64 hash_values[] + u32 hash_data[]
+// (src/hashtable.cc:41-44): three cache lines per probe step.  Here one 16-byte slot
+// carries all three, so a probe step is ONE 16-B HBM/L2 transaction.
+struct alignas(16) swa_slot {
+  uint64_t hash;
+  uint32_t amp;   // SWA_NO_AMPLICON = empty
+  uint32_t pad;
+};
+
+// a growable device buffer (never shrinks; the db and tables stay resident in HBM)
+struct swa_dbuf {
+  void * ptr = nullptr;
+  size_t bytes = 0;
+};
+
+struct swa_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 256;
+  std::string err;
+
+  // optional per-kernel timing (HIP events on `stream`)
+  bool timing = false;
+  hipEvent_t ev[16] = {};
+  bool ev_ready = false;
+  bool ev_used[8] = {};
+
+  // database (device pointers)
+  swa_db_view db{};
+  bool db_owned = false;
+  swa_dbuf d_seqs, d_seq_off, d_seqlen, d_abund;
+
+  // d=1 index
+  bool d1_ready = false;
+  uint64_t table_size = 0;       // slots, power of two
+  uint64_t bloom_words = 0;      // u64 words in the amplicon Bloom
+  uint32_t zobrist_len = 0;      // positions in the Zobrist table (longest + 2)
+  swa_dbuf d_zobrist, d_seqhash, d_table, d_bloom, d_patterns;
+  swa_dbuf d_flags;              // u32[16]: [0] duplicate flag
+  swa_dbuf d_stats;              // u64[8] probe statistics + [8] edge counter
+  swa_dbuf d_edges;              // u64 edge list (src << 32 | dst)
+  swa_dbuf d_counts, d_cursor, d_scan_tmp, d_offsets_tmp, d_nb_tmp;
+
+  // q-gram / alignment state
+  bool qgram_ready = false;
+  swa_dbuf d_qgrams, d_list_a, d_list_b, d_list_c, d_list_d;
+  uint64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13, resolution = 1;
+  bool search_ready = false;
+
+  // fastidious state
+  swa_dbuf d_light, d_graft, d_bloomflex, d_fpatterns, d_queue, d_fcounters;
+};
+
+int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e);
+int swa_fail_msg(swa_ctx * ctx, int code, const std::string & msg);
+int swa_reserve(swa_ctx * ctx, swa_dbuf & buf, size_t bytes);   // grow-only hipMalloc
+void swa_release(swa_dbuf & buf);
+
+// RAII-less timing brackets: SWA_T0(ctx, slot) ... SWA_T1(ctx, slot)
+inline void swa_t0(swa_ctx * ctx, int slot) {
+  if (ctx->timing && ctx->ev_ready) { (void)hipEventRecord(ctx->ev[2 * slot], ctx->stream); }
+}
+inline void swa_t1(swa_ctx * ctx, int slot) {
+  if (ctx->timing && ctx->ev_ready) { (void)hipEventRecord(ctx->ev[2 * slot + 1], ctx->stream); ctx->ev_used[slot] = true; }
+}
+
+#define SWA_HIP(ctx, expr)                                                     \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) return swa_fail((ctx), SWA_E_DEVICE, #expr, e_);     \
+  } while (0)
+
+#define SWA_TRY(expr)                  \
+  do {                                 \
+    int rc_ = (expr);                  \
+    if (rc_ != SWA_OK) return rc_;     \
+  } while (0)
+
+// host-side table generators (host_tables.cpp): bit-identical to the reference's
+// first zobrist_init()/bloom_init()/bloomflex_init() of a process
+void swa_zobrist_table(uint32_t zobrist_len, std::vector<uint64_t> & tab);    // src/zobrist.cc:49-80
+void swa_bloom_patterns(uint32_t count, uint32_t k, std::vector<uint64_t> & pat); // src/bloompat.cc:74-90, src/bloomflex.cc:72-88
+uint64_t swa_hashtable_size(uint64_t n);                                       // src/utils/hashtable_size.cc:29-42
+
+// ---- device helpers -------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ unsigned swa_nt(const uint64_t * seq, uint32_t pos) {
+  return (unsigned)((seq[pos >> 5] >> ((pos & 31u) << 1)) & 3u);
+}
+
+__device__ __forceinline__ uint64_t swa_shfl_u64(uint64_t v, int src) {
+  const int lo = __shfl((int)(uint32_t)v, src, 64);
+  const int hi = __shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t swa_shfl_up_u64(uint64_t v, unsigned d) {
+  const int lo = __shfl_up((int)(uint32_t)v, d, 64);
+  const int hi = __shfl_up((int)(uint32_t)(v >> 32), d, 64);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t swa_shfl_down_u64(uint64_t v, unsigned d) {
+  const int lo = __shfl_down((int)(uint32_t)v, d, 64);
+  const int hi = __shfl_down((int)(uint32_t)(v >> 32), d, 64);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// Word `w` of the microvariant of `seed` (len nt, nw = ceil(len/32) valid words,
+// zero padded) described by (type, pos, base): what generate_variant_sequence
+// (src/variants.cc:78-115) materialises nucleotide by nucleotide, computed here
+// with 64-bit shifts.  type: 0 substitution, 1 deletion, 2 insertion.
+__device__ __forceinline__ uint64_t swa_variant_word(const uint64_t * seed, uint32_t nw, uint32_t type,
+                                                     uint32_t pos, uint32_t base, uint32_t w) {
+  const uint32_t wp = pos >> 5;
+  const uint32_t sh = (pos & 31u) << 1;
+  const uint64_t cur = (w < nw) ? seed[w] : 0ull;
+  if (type == 0u) {
+    if (w != wp) return cur;
+    return (cur & ~(3ull << sh)) | ((uint64_t)base << sh);
+  }
+  const uint64_t lowmask = (1ull << sh) - 1ull;   // nts below `pos` inside word wp (sh < 64)
+  if (type == 1u) {
+    const uint64_t nxt = (w + 1 < nw) ? seed[w + 1] : 0ull;
+    const uint64_t shifted = (cur >> 2) | (nxt << 62);      // every nt one position down
+    if (w < wp) return cur;
+    if (w > wp) return shifted;
+    return (cur & lowmask) | (shifted & ~lowmask);
+  }
+  {
+    const uint64_t prv = (w >= 1 && w - 1 < nw) ? seed[w - 1] : 0ull;
+    const uint64_t shifted = (cur << 2) | (prv >> 62);      // every nt one position up
+    if (w < wp) return cur;
+    if (w > wp) return shifted;
+    return (cur & lowmask) | ((uint64_t)base << sh) | (shifted & ~(lowmask | (3ull << sh)));
+  }
+}
+
+#endif  // __HIPCC__

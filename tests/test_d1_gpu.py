@@ -1,0 +1,117 @@
+"""B1 parity on the GPU: swa_d1_* (HIP, through the C ABI) vs the oracle on the same inputs."""
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _upload(ctx, db):
+    ctx.upload_db(db.seqs, db.seq_off, db.seqlen, db.abundance, db.longest)
+
+
+def _oracle_sorted_rows(db, ncb=False, first=0, count=None):
+    off, nb, dup = S.oracle_d1_network(db, ncb, first, count)
+    nb = nb.copy()
+    for i in range(len(off) - 1):
+        nb[int(off[i]):int(off[i + 1])].sort()
+    return off, nb, dup
+
+
+@pytest.mark.parametrize("n,L,seed,ncb", [(1000, 150, 11, False), (3000, 150, 12, True), (500, 33, 14, False),
+                                          (2000, 400, 15, False), (300, 1000, 16, False), (64, 9, 17, True)])
+def test_network_matches_oracle(gpu_ctx, tmp_path, n, L, seed, ncb):
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, n, L, seed)
+    db = S.db_from_fasta(fa)
+    _upload(gpu_ctx, db)
+    assert gpu_ctx.d1_index_build() is False
+    # intermediates are bit-exact: Zobrist table, sequence hashes, Bloom bitmap
+    lib = S.oracle()
+    zob = S.oracle_zobrist(db.longest + 2)
+    assert np.array_equal(gpu_ctx.d1_debug(2, 4 * (db.longest + 2)), zob)
+    want_hash = np.array([lib.orc_zobrist_hash(S._p(zob, S.u64p), S._p(db.words(i), S.u64p), int(db.seqlen[i]))
+                          for i in range(db.n)], dtype=np.uint64)
+    assert np.array_equal(gpu_ctx.d1_debug(0, db.n), want_hash)
+    assert gpu_ctx.d1_table_size() == lib.orc_hashtable_size(db.n)
+    off, nb = gpu_ctx.d1_network(ncb)
+    woff, wnb, _ = _oracle_sorted_rows(db, ncb)
+    assert np.array_equal(off, woff)
+    assert np.array_equal(nb, wnb)
+
+
+def test_network_subrange_and_capacity(gpu_ctx, tmp_path):
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 5000, 150, 21)
+    db = S.db_from_fasta(fa)
+    _upload(gpu_ctx, db)
+    gpu_ctx.d1_index_build()
+    full_off, full_nb = gpu_ctx.d1_network()
+    for first, count in [(0, 1), (17, 1000), (4000, 1000), (4999, 1)]:
+        off, nb = gpu_ctx.d1_network(False, first, count)
+        lo, hi = int(full_off[first]), int(full_off[first + count])
+        assert np.array_equal(off, full_off[first:first + count + 1] - full_off[first])
+        assert np.array_equal(nb, full_nb[lo:hi])
+
+
+def test_duplicates_are_reported(gpu_ctx, tmp_path):
+    fa = tmp_path / "dup.fa"
+    fa.write_text(">a_3\nACGTACGTACGTAAAC\n>b_2\nACGTACGTACGTAAAC\n>c_1\nACGTACGTACGTAAAG\n")
+    db = S.db_from_fasta(fa)
+    _upload(gpu_ctx, db)
+    assert gpu_ctx.d1_index_build() is True
+
+
+def test_star_with_many_neighbours(gpu_ctx, tmp_path):
+    """One centre with every one of its microvariants present: rows of > 64 and queue overflow."""
+    centre = "ACGTTGCAAGCTTAGCGATCGGATCCATGCAAGTCTAGCTAGGCTAACGT"
+    lib = S.oracle()
+    seqs = {centre}
+    for p in range(len(centre)):
+        for b in "ACGT":
+            if b != centre[p]:
+                seqs.add(centre[:p] + b + centre[p + 1:])
+            seqs.add(centre[:p] + b + centre[p:])
+        seqs.add(centre[:p] + centre[p + 1:])
+    for b in "ACGT":
+        seqs.add(centre + b)
+    seqs = sorted(seqs)
+    fa = tmp_path / "star.fa"
+    fa.write_text("".join(f">s{i}_{1000 if s == centre else 1}\n{s}\n" for i, s in enumerate(seqs)))
+    db = S.db_from_fasta(fa)
+    _upload(gpu_ctx, db)
+    assert gpu_ctx.d1_index_build() is False
+    off, nb = gpu_ctx.d1_network()
+    woff, wnb, _ = _oracle_sorted_rows(db)
+    assert int(off[1] - off[0]) == len(seqs) - 1      # the centre sees everybody
+    assert np.array_equal(off, woff)
+    assert np.array_equal(nb, wnb)
+
+
+def test_full_size_1m_properties(gpu_ctx, tmp_path):
+    """BASELINE config 2 (1M x 150, d=1) through size-independent properties: the network is
+    symmetric up to the abundance rule, rows are sorted/unique/self-free, and a random sample
+    of rows equals the oracle's."""
+    fa = tmp_path / "big.fa"
+    S.gen_fasta(fa, 1_000_000, 150, 1)
+    db = S.db_from_fasta(fa)
+    _upload(gpu_ctx, db)
+    assert gpu_ctx.d1_index_build() is False
+    off, nb = gpu_ctx.d1_network(True)       # -n: no abundance rule => symmetric relation
+    rows = np.repeat(np.arange(db.n, dtype=np.uint64), np.diff(off).astype(np.int64))
+    fwd = (rows << np.uint64(32)) | nb.astype(np.uint64)
+    rev = (nb.astype(np.uint64) << np.uint64(32)) | rows
+    assert np.array_equal(np.sort(fwd), np.sort(rev))
+    assert (rows != nb).all()
+    assert (np.diff(fwd) > 0).all()           # ascending and unique within and across rows
+    off2, nb2 = gpu_ctx.d1_network(False)
+    rows2 = np.repeat(np.arange(db.n, dtype=np.uint64), np.diff(off2).astype(np.int64))
+    assert (db.abundance[rows2.astype(np.int64)] >= db.abundance[nb2.astype(np.int64)]).all()
+    keep = db.abundance[rows.astype(np.int64)] >= db.abundance[nb.astype(np.int64)]
+    assert np.array_equal(fwd[keep], (rows2 << np.uint64(32)) | nb2.astype(np.uint64))
+    rng = np.random.default_rng(3)
+    for first in rng.integers(0, db.n - 2000, size=3):
+        woff, wnb, _ = _oracle_sorted_rows(db, False, int(first), 2000)
+        lo, hi = int(off2[first]), int(off2[first + 2000])
+        assert np.array_equal(nb2[lo:hi], wnb)
