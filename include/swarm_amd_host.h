@@ -34,6 +34,35 @@ uint64_t swa_hostdb_nucleotides(const swa_hostdb * db);
 /* header of amplicon i (db order), NUL terminated; replaces db_getheader (src/db.h:47) */
 const char * swa_hostdb_header(const swa_hostdb * db, uint32_t i, uint32_t * len);
 
+/* ---- d = 1 host side: clustering over the neighbour CSR, grafting, writers --------- */
+typedef struct swa_d1_result swa_d1_result;
+
+/* Greedy breadth-first agglomeration over the CSR returned by swa_d1_network
+   (replaces the clustering loop of algo_d1_run, src/algod1.cc:1185-1280). */
+int  swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
+                    swa_d1_result ** out);
+void swa_d1_result_free(swa_d1_result * res);
+/* out4 = {swarms after grafting, largest swarm, max generations, swarms before grafting}
+   (the numbers of the log's summary lines, src/algod1.cc:1484-1487) */
+void swa_d1_result_summary(const swa_d1_result * res, uint64_t * out4);
+const uint32_t * swa_d1_result_swarmid(const swa_d1_result * res);     /* [n] */
+const uint32_t * swa_d1_result_parent(const swa_d1_result * res);      /* [n], SWA_NO_AMPLICON for seeds */
+const uint32_t * swa_d1_result_generation(const swa_d1_result * res);  /* [n] */
+/* is_light[n] <- swarm mass < boundary; stats5 = {light swarms, amplicons in light swarms,
+   nt in light swarms, heavy swarms, amplicons in heavy swarms} (src/algod1.cc:1291-1328) */
+void swa_d1_light_flags(const swa_d1_result * res, int64_t boundary, uint8_t * is_light, uint64_t * stats5);
+/* attach_candidates (src/algod1.cc:274-336): graft_cand[n] as returned by swa_d1_fastidious;
+   returns the number of grafts made */
+uint32_t swa_d1_graft(swa_d1_result * res, const uint32_t * graft_cand);
+/* writers (path "-" = stdout): -o/-r, -s, -i, -w, -j  (src/algod1.cc:755-1062) */
+int swa_d1_write_swarms(const swa_d1_result * res, const swa_hostdb * db, const char * path, int mothur,
+                        int usearch_abundance, int64_t append_abundance, int64_t differences);
+int swa_d1_write_stats(const swa_d1_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_d1_write_structure(const swa_d1_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_d1_write_seeds(const swa_d1_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_d1_write_network(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
+                         const char * path, int usearch_abundance, int64_t append_abundance);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,7 +41,9 @@ EXPORTS = [
     "swa_d1_debug_read", "swa_d1_table_size", "swa_d1_fastidious", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
-    "swa_hostdb_header",
+    "swa_hostdb_header", "swa_d1_cluster", "swa_d1_result_free", "swa_d1_result_summary", "swa_d1_result_swarmid",
+    "swa_d1_result_parent", "swa_d1_result_generation", "swa_d1_light_flags", "swa_d1_graft", "swa_d1_write_swarms",
+    "swa_d1_write_stats", "swa_d1_write_structure", "swa_d1_write_seeds", "swa_d1_write_network",
 ]
 
 
@@ -100,8 +102,29 @@ def load_library() -> C.CDLL:
     lib.swa_hostdb_nucleotides.restype = C.c_uint64
     lib.swa_hostdb_header.argtypes = [C.c_void_p, C.c_uint32, u32p]
     lib.swa_hostdb_header.restype = C.c_char_p
+    lib.swa_d1_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.swa_d1_result_free.argtypes = [C.c_void_p]
+    lib.swa_d1_result_free.restype = None
+    lib.swa_d1_result_summary.argtypes = [C.c_void_p, u64p]
+    lib.swa_d1_result_summary.restype = None
+    for fn in (lib.swa_d1_result_swarmid, lib.swa_d1_result_parent, lib.swa_d1_result_generation):
+        fn.argtypes = [C.c_void_p]
+        fn.restype = C.c_void_p
+    lib.swa_d1_light_flags.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, u64p]
+    lib.swa_d1_light_flags.restype = None
+    lib.swa_d1_graft.argtypes = [C.c_void_p, C.c_void_p]
+    lib.swa_d1_graft.restype = C.c_uint32
+    lib.swa_d1_write_swarms.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_int64]
+    lib.swa_d1_write_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.swa_d1_write_structure.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.swa_d1_write_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.swa_d1_write_network.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int64]
     _lib = lib
     return lib
+
+
+def _p64(a: np.ndarray):
+    return a.ctypes.data_as(u64p)
 
 
 def _ptr(a) -> int:
@@ -152,6 +175,74 @@ class HostDb:
     def close(self) -> None:
         if getattr(self, "h", None):
             self.lib.swa_hostdb_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class D1Clusters:
+    """Host-side greedy clustering of the d=1 network (mirror of algo_d1_run's host loop,
+    src/algod1.cc:1185-1280) with the fastidious bookkeeping and the writers."""
+
+    def __init__(self, hdb: HostDb, offsets: np.ndarray, neighbours: np.ndarray):
+        self.lib = load_library()
+        self.hdb = hdb
+        self._keep = (np.ascontiguousarray(offsets, dtype=np.uint64), np.ascontiguousarray(neighbours, dtype=np.uint32))
+        h = C.c_void_p()
+        rc = self.lib.swa_d1_cluster(hdb.h, _ptr(self._keep[0]), _ptr(self._keep[1]) if len(self._keep[1]) else 0,
+                                     C.byref(h))
+        if rc != SWA_OK:
+            raise SwaError(rc, "swa_d1_cluster failed")
+        self.h = h
+
+    def summary(self) -> dict:
+        out = np.zeros(4, dtype=np.uint64)
+        self.lib.swa_d1_result_summary(self.h, _p64(out))
+        return {"swarms": int(out[0]), "largest": int(out[1]), "maxgen": int(out[2]), "swarms_before_grafting": int(out[3])}
+
+    def _arr(self, fn) -> np.ndarray:
+        ptr = fn(self.h)
+        n = self.hdb.n
+        buf = (C.c_char * (4 * n)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint32, count=n).copy()
+
+    def swarmid(self) -> np.ndarray:
+        return self._arr(self.lib.swa_d1_result_swarmid)
+
+    def light_flags(self, boundary: int = 3):
+        flags = np.zeros(self.hdb.n, dtype=np.uint8)
+        stats = np.zeros(5, dtype=np.uint64)
+        self.lib.swa_d1_light_flags(self.h, boundary, _ptr(flags), _p64(stats))
+        return flags, [int(x) for x in stats]
+
+    def graft(self, graft_cand: np.ndarray) -> int:
+        g = np.ascontiguousarray(graft_cand, dtype=np.uint32)
+        return int(self.lib.swa_d1_graft(self.h, _ptr(g)))
+
+    def write_swarms(self, path, mothur=False, usearch=False, append_abundance=0, differences=1) -> None:
+        assert self.lib.swa_d1_write_swarms(self.h, self.hdb.h, str(path).encode(), int(mothur), int(usearch),
+                                            append_abundance, differences) == SWA_OK
+
+    def write_stats(self, path, usearch=False) -> None:
+        assert self.lib.swa_d1_write_stats(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_structure(self, path, usearch=False) -> None:
+        assert self.lib.swa_d1_write_structure(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_seeds(self, path, usearch=False) -> None:
+        assert self.lib.swa_d1_write_seeds(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_network(self, path, usearch=False, append_abundance=0) -> None:
+        assert self.lib.swa_d1_write_network(self.hdb.h, _ptr(self._keep[0]), _ptr(self._keep[1]),
+                                             str(path).encode(), int(usearch), append_abundance) == SWA_OK
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.swa_d1_result_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,334 @@
+// cluster_d1.cpp — host side of the d = 1 path: greedy single-linkage agglomeration
+// over the GPU-returned neighbour lists, fastidious bookkeeping and grafting, writers.
+//
+// Behaviour mirrors algo_d1_run's host part (src/algod1.cc:1185-1280 clustering,
+// 214-336 grafting, 755-1095 writers) so that every output file is byte-identical.
+// Shape is this repo's own: swarms are contiguous ranges of one discovery-order array
+// (the reference threads a linked list through ampinfo[].next); a grafted light swarm
+// is a range appended to its heavy swarm's piece list.
+#include "hostdb.h"
+
+#include <algorithm>
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+struct swa_d1_result {
+  uint32_t n = 0;
+  std::vector<uint32_t> swarmid, parent, generation;
+  std::vector<uint32_t> order;              // amplicons in discovery order, swarm after swarm
+  struct Swarm {
+    uint64_t mass = 0, sumlen = 0;
+    uint32_t seed = 0, size = 0, singletons = 0, maxgen = 0;
+    uint32_t begin = 0, end = 0;            // own members = order[begin, end)
+    bool attached = false;
+    std::vector<uint32_t> grafted;          // light swarm ids appended, in graft order
+  };
+  std::vector<Swarm> swarms;
+  std::vector<uint32_t> graft_cand;         // per amplicon, after swa_d1_graft
+  uint64_t swarmcount_adjusted = 0;
+  uint32_t largest = 0, maxgen = 0;
+  std::string error;
+};
+
+namespace {
+
+inline const char * hdr(const swa_hostdb * db, uint32_t i) { return db->headers.data() + db->hdr_off[i]; }
+inline uint32_t hdrlen(const swa_hostdb * db, uint32_t i) { return (uint32_t)(db->hdr_off[i + 1] - db->hdr_off[i] - 1); }
+
+// fprint_id (src/db.cc:946-968)
+void print_id(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch, int64_t append_abundance) {
+  if (append_abundance != 0 && db->ab_start[i] == db->ab_end[i]) {
+    if (usearch) { std::fprintf(fp, "%.*s;size=%" PRIu64 ";", (int)hdrlen(db, i), hdr(db, i), db->abundance[i]); }
+    else { std::fprintf(fp, "%.*s_%" PRIu64, (int)hdrlen(db, i), hdr(db, i), db->abundance[i]); }
+  } else {
+    std::fwrite(hdr(db, i), 1, hdrlen(db, i), fp);
+  }
+}
+
+// fprint_id_noabundance (src/db.cc:971-999)
+void print_id_noabundance(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch) {
+  const int s = db->ab_start[i];
+  const int e = db->ab_end[i];
+  const int len = (int)hdrlen(db, i);
+  if (s < e) {
+    std::fprintf(fp, "%.*s", s, hdr(db, i));
+    if (usearch) {
+      if (s > 0 && e < len) { std::fputc(';', fp); }
+      std::fprintf(fp, "%.*s", len - e, hdr(db, i) + e);
+    }
+  } else {
+    std::fwrite(hdr(db, i), 1, (size_t)len, fp);
+  }
+}
+
+// fprint_id_with_new_abundance (src/db.cc:1002-1026)
+void print_id_new_abundance(FILE * fp, const swa_hostdb * db, uint32_t i, uint64_t abundance, bool usearch) {
+  if (usearch) {
+    std::fprintf(fp, "%.*s%ssize=%" PRIu64 ";%.*s", db->ab_start[i], hdr(db, i), db->ab_start[i] > 0 ? ";" : "",
+                 abundance, (int)hdrlen(db, i) - db->ab_end[i], hdr(db, i) + db->ab_end[i]);
+  } else {
+    std::fprintf(fp, "%.*s_%" PRIu64, db->ab_start[i], hdr(db, i), abundance);
+  }
+}
+
+FILE * open_out(const char * path) {
+  if (path == nullptr) { return nullptr; }
+  if (std::strcmp(path, "-") == 0) { return stdout; }
+  return std::fopen(path, "w");
+}
+void close_out(FILE * fp) { if (fp != nullptr && fp != stdout) { std::fclose(fp); } else if (fp == stdout) { std::fflush(fp); } }
+
+template <typename F>
+void for_each_member(const swa_d1_result * r, const swa_d1_result::Swarm & s, F && f) {
+  for (uint32_t k = s.begin; k < s.end; ++k) { f(r->order[k]); }
+  for (uint32_t g : s.grafted) {
+    const auto & l = r->swarms[g];
+    for (uint32_t k = l.begin; k < l.end; ++k) { f(r->order[k]); }
+  }
+}
+
+}  // namespace
+
+// ---- clustering (src/algod1.cc:1185-1280, process_seed 673-718) ------------------------
+extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
+                              swa_d1_result ** out) {
+  if (db == nullptr || out == nullptr || (db->n > 0 && (offsets == nullptr))) { return SWA_E_ARG; }
+  auto * r = new swa_d1_result();
+  *out = r;
+  const uint32_t n = db->n;
+  r->n = n;
+  r->swarmid.assign(n, SWA_NO_AMPLICON);
+  r->parent.assign(n, SWA_NO_AMPLICON);
+  r->generation.assign(n, 0);
+  r->graft_cand.assign(n, SWA_NO_AMPLICON);
+  r->order.reserve(n);
+  std::vector<uint32_t> fresh;
+  for (uint32_t seed = 0; seed < n; ++seed) {
+    if (r->swarmid[seed] != SWA_NO_AMPLICON) { continue; }
+    const uint32_t sid = (uint32_t)r->swarms.size();
+    swa_d1_result::Swarm sw;
+    sw.seed = seed;
+    sw.begin = (uint32_t)r->order.size();
+    r->swarmid[seed] = sid;
+    r->order.push_back(seed);
+    uint32_t gen_begin = sw.begin;            // current generation = order[gen_begin, gen_end)
+    uint32_t gen_end = gen_begin + 1;
+    uint32_t gen = 0;
+    while (gen_begin < gen_end) {
+      fresh.clear();
+      for (uint32_t k = gen_begin; k < gen_end; ++k) {
+        const uint32_t s = r->order[k];
+        for (uint64_t e = offsets[s]; e < offsets[s + 1]; ++e) {
+          const uint32_t amp = neighbours[e];
+          if (r->swarmid[amp] == SWA_NO_AMPLICON) {
+            r->swarmid[amp] = sid;
+            r->generation[amp] = gen + 1;
+            r->parent[amp] = s;
+            fresh.push_back(amp);
+          }
+        }
+      }
+      // each generation joins the swarm sorted by db index (= abundance, then header)
+      std::sort(fresh.begin(), fresh.end());
+      r->order.insert(r->order.end(), fresh.begin(), fresh.end());
+      gen_begin = gen_end;
+      gen_end = (uint32_t)r->order.size();
+      if (!fresh.empty()) { ++gen; }
+    }
+    sw.end = (uint32_t)r->order.size();
+    sw.size = sw.end - sw.begin;
+    sw.maxgen = gen;
+    for (uint32_t k = sw.begin; k < sw.end; ++k) {
+      const uint32_t a = r->order[k];
+      sw.mass += db->abundance[a];
+      sw.sumlen += db->seqlen[a];
+      if (db->abundance[a] == 1) { ++sw.singletons; }
+    }
+    r->largest = std::max(r->largest, sw.size);
+    r->maxgen = std::max(r->maxgen, sw.maxgen);
+    r->swarms.push_back(std::move(sw));
+  }
+  r->swarmcount_adjusted = r->swarms.size();
+  return SWA_OK;
+}
+
+extern "C" void swa_d1_result_free(swa_d1_result * r) { delete r; }
+
+extern "C" void swa_d1_result_summary(const swa_d1_result * r, uint64_t * out4) {
+  out4[0] = r->swarmcount_adjusted;
+  out4[1] = r->largest;
+  out4[2] = r->maxgen;
+  out4[3] = r->swarms.size();
+}
+
+extern "C" const uint32_t * swa_d1_result_swarmid(const swa_d1_result * r) { return r->swarmid.data(); }
+extern "C" const uint32_t * swa_d1_result_parent(const swa_d1_result * r) { return r->parent.data(); }
+extern "C" const uint32_t * swa_d1_result_generation(const swa_d1_result * r) { return r->generation.data(); }
+
+// ---- fastidious bookkeeping (src/algod1.cc:1291-1328) -----------------------------------
+extern "C" void swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, uint8_t * is_light, uint64_t * stats5) {
+  uint64_t light_swarms = 0, light_amps = 0, light_nt = 0;
+  for (const auto & s : r->swarms) {
+    const bool light = s.mass < (uint64_t)boundary;
+    if (light) { ++light_swarms; light_amps += s.size; light_nt += s.sumlen; }
+    for (uint32_t k = s.begin; k < s.end; ++k) { is_light[r->order[k]] = light ? 1 : 0; }
+  }
+  stats5[0] = light_swarms;
+  stats5[1] = light_amps;
+  stats5[2] = light_nt;
+  stats5[3] = r->swarms.size() - light_swarms;
+  stats5[4] = r->n - light_amps;
+}
+
+// ---- grafting (src/algod1.cc:214-241 attach, 274-336 attach_candidates) -----------------
+extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand) {
+  struct Pair { uint32_t parent, child; };
+  std::vector<Pair> pairs;
+  for (uint32_t i = 0; i < r->n; ++i) {
+    r->graft_cand[i] = graft_cand[i];
+    if (graft_cand[i] != SWA_NO_AMPLICON) { pairs.push_back({graft_cand[i], i}); }
+  }
+  std::sort(pairs.begin(), pairs.end(), [](const Pair & a, const Pair & b) {
+    return a.parent != b.parent ? a.parent < b.parent : a.child < b.child;
+  });
+  uint32_t grafts = 0;
+  for (const Pair & p : pairs) {
+    auto & light = r->swarms[r->swarmid[p.child]];
+    if (light.attached) {
+      r->graft_cand[p.child] = SWA_NO_AMPLICON;     // this light swarm already hangs somewhere
+      continue;
+    }
+    auto & heavy = r->swarms[r->swarmid[p.parent]];
+    heavy.grafted.push_back(r->swarmid[p.child]);
+    heavy.size += light.size;
+    heavy.singletons += light.singletons;
+    heavy.mass += light.mass;
+    heavy.sumlen += light.sumlen;                   // maxgen untouched, like the reference
+    light.attached = true;
+    r->largest = std::max(r->largest, heavy.size);
+    --r->swarmcount_adjusted;
+    ++grafts;
+  }
+  return grafts;
+}
+
+// ---- writers ------------------------------------------------------------------------------
+// -o / -r  (src/algod1.cc:790-846)
+extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * db, const char * path, int mothur,
+                                   int usearch, int64_t append_abundance, int64_t differences) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  if (mothur) { std::fprintf(fp, "swarm_%" PRId64 "\t%" PRIu64, differences, r->swarmcount_adjusted); }
+  for (const auto & s : r->swarms) {
+    if (s.attached) { continue; }
+    bool first = true;
+    for_each_member(r, s, [&](uint32_t a) {
+      if (mothur) { std::fputc(first ? '\t' : ',', fp); }
+      else if (!first) { std::fputc(' ', fp); }
+      first = false;
+      print_id(fp, db, a, usearch != 0, append_abundance);
+    });
+    if (!mothur) { std::fputc('\n', fp); }
+  }
+  if (mothur) { std::fputc('\n', fp); }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -s  (src/algod1.cc:1040-1062): maxgen is printed twice for d = 1
+extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  for (const auto & s : r->swarms) {
+    if (s.attached) { continue; }
+    std::fprintf(fp, "%u\t%" PRIu64 "\t", s.size, s.mass);
+    print_id_noabundance(fp, db, s.seed, usearch != 0);
+    std::fprintf(fp, "\t%" PRIu64 "\t%u\t%u\t%u\n", db->abundance[s.seed], s.singletons, s.maxgen, s.maxgen);
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -i  (src/algod1.cc:985-1037)
+extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  uint32_t cluster_no = 0;
+  for (const auto & s : r->swarms) {
+    if (s.attached) { continue; }
+    for_each_member(r, s, [&](uint32_t a) {
+      if (a == s.seed) { return; }
+      const uint32_t gp = r->graft_cand[a];
+      if (gp != SWA_NO_AMPLICON) {
+        print_id_noabundance(fp, db, gp, usearch != 0);
+        std::fputc('\t', fp);
+        print_id_noabundance(fp, db, a, usearch != 0);
+        std::fprintf(fp, "\t%d\t%u\t%u\n", 2, cluster_no + 1, r->generation[gp] + 1);
+      }
+      const uint32_t p = r->parent[a];
+      if (p != SWA_NO_AMPLICON) {
+        print_id_noabundance(fp, db, p, usearch != 0);
+        std::fputc('\t', fp);
+        print_id_noabundance(fp, db, a, usearch != 0);
+        std::fprintf(fp, "\t%u\t%u\t%u\n", 1u, cluster_no + 1, r->generation[a]);
+      }
+    });
+    ++cluster_no;
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -w  (src/algod1.cc:935-982 + db_fprintseq src/db.cc:925-943)
+extern "C" int swa_d1_write_seeds(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  std::vector<uint32_t> idx(r->swarms.size());
+  std::iota(idx.begin(), idx.end(), 0u);
+  std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+    const auto & a = r->swarms[x];
+    const auto & b = r->swarms[y];
+    if (a.mass != b.mass) { return a.mass > b.mass; }
+    return std::strcmp(hdr(db, a.seed), hdr(db, b.seed)) < 0;
+  });
+  std::string line;
+  for (uint32_t k : idx) {
+    const auto & s = r->swarms[k];
+    if (s.attached) { continue; }
+    std::fputc('>', fp);
+    print_id_new_abundance(fp, db, s.seed, s.mass, usearch != 0);
+    std::fputc('\n', fp);
+    const uint64_t * w = db->seqs.data() + db->seq_off[s.seed];
+    const uint32_t len = db->seqlen[s.seed];
+    line.resize(len);
+    for (uint32_t p = 0; p < len; ++p) { line[p] = "ACGT"[(w[p >> 5] >> ((p & 31u) << 1)) & 3u]; }
+    std::fwrite(line.data(), 1, len, fp);
+    std::fputc('\n', fp);
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -j  (src/algod1.cc:755-788): rows ascending by target id (the C ABI already sorts them)
+extern "C" int swa_d1_write_network(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
+                                    const char * path, int usearch, int64_t append_abundance) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  std::vector<uint32_t> row;
+  for (uint32_t i = 0; i < db->n; ++i) {
+    row.assign(neighbours + offsets[i], neighbours + offsets[i + 1]);
+    std::sort(row.begin(), row.end());
+    for (uint32_t j : row) {
+      print_id(fp, db, i, usearch != 0, append_abundance);
+      std::fputc('\t', fp);
+      print_id(fp, db, j, usearch != 0, append_abundance);
+      std::fputc('\n', fp);
+    }
+  }
+  close_out(fp);
+  return SWA_OK;
+}

@@ -1,0 +1,136 @@
+"""Host-side product code (no GPU): the C ABI's exported surface, the FASTA database reader and
+the d=1 clustering / grafting / writers, checked against the reference's own output files under
+tests/golden/.  The neighbour lists fed to the host logic here come from the oracle (the GPU
+tests feed it the HIP path's lists)."""
+import filecmp
+import re
+
+import numpy as np
+import pytest
+
+import support as S
+from swarm_amd import D1Clusters, HostDb, SwaError, capi
+
+G = S.GOLDEN
+INCLUDE = S.ROOT / "include"
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_library()
+    declared = set()
+    for hdr in INCLUDE.glob("*.h"):
+        text = re.sub(r"/\*.*?\*/", "", hdr.read_text(), flags=re.S)
+        declared |= set(re.findall(r"\b(swa_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) > 30
+    missing = sorted(s for s in declared if not hasattr(lib, s))
+    assert not missing, missing
+    assert set(capi.EXPORTS) <= declared
+    assert lib.swa_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import ctypes as C
+    lib = capi.load_library()
+    h = C.c_void_p()
+    rc = lib.swa_ctx_create(99, None, C.byref(h))       # device ordinal that cannot exist
+    assert rc == capi.SWA_E_DEVICE and not h
+
+
+@pytest.mark.parametrize("name", ["d1_1k", "d1_short", "d3_400", "d1_fastidious"])
+def test_hostdb_matches_independent_packing(name):
+    hdb = HostDb(G / f"{name}.fasta")
+    db = S.db_from_fasta(G / f"{name}.fasta")
+    assert (hdb.n, hdb.longest) == (db.n, db.longest)
+    assert np.array_equal(hdb.seq_off, db.seq_off)
+    assert np.array_equal(hdb.seqs, db.seqs[:len(hdb.seqs)])
+    assert np.array_equal(hdb.seqlen, db.seqlen)
+    assert np.array_equal(hdb.abundance, db.abundance)
+    assert [hdb.header(i) for i in range(db.n)] == db.headers
+    assert hdb.nucleotides == int(db.seqlen.astype(np.uint64).sum())
+    info = re.search(r"Database info:\s+(\d+) nt in (\d+) sequences, longest (\d+) nt", (G / f"{name}.log").read_text())
+    assert (hdb.nucleotides, hdb.n, hdb.longest) == tuple(int(x) for x in info.groups())
+
+
+def test_hostdb_usearch_and_append_abundance():
+    hdb = HostDb(G / "d1_usearch.fasta", usearch_abundance=True, append_abundance=2)
+    db = S.build_db([(h, s) for h, s in S.read_fasta(G / "d1_short.fasta")])
+    assert hdb.n == db.n
+    # same sequences, same abundances except the one entry that took -a 2
+    assert sorted(hdb.seqlen.tolist()) == sorted(db.seqlen.tolist())
+    assert int((hdb.abundance == 2).sum()) >= 1
+
+
+@pytest.mark.parametrize("text,msg", [
+    ("ACGT\n", "Illegal header line in fasta file."),
+    (">a_1\nACGN\n", "Illegal character 'N' in sequence on line 2."),
+    (">a_1\nAC\x01GT\n", "Illegal character (ascii no 1) in sequence on line 2."),
+    (">a_1\n>b_1\nACGT\n", "Empty sequence found on line 1."),
+    (">a_1\nACGT\n>a_2\nACGA\n", "Duplicated sequence identifier: a"),
+    (">a\nACGT\n", "Abundance annotations not found for 1 sequences, starting on line 1."),
+    (">a_0\nACGT\n", "Illegal abundance value on line 1"),
+    (">_3\nACGT\n", "Empty sequence identifier."),
+])
+def test_hostdb_error_messages(tmp_path, text, msg):
+    fa = tmp_path / "bad.fa"
+    fa.write_text(text)
+    with pytest.raises(SwaError) as e:
+        HostDb(fa)
+    assert msg in str(e.value)
+
+
+def _cluster(name, ncb=False):
+    hdb = HostDb(G / f"{name}.fasta", usearch_abundance=name == "d1_usearch", append_abundance=2 if name == "d1_usearch" else 0)
+    db = S.Db(headers=[hdb.header(i) for i in range(hdb.n)], seqs=hdb.seqs, seq_off=hdb.seq_off, seqlen=hdb.seqlen,
+              abundance=hdb.abundance, longest=hdb.longest)
+    off, nb, dup = S.oracle_d1_network(db, ncb)
+    assert not dup
+    return hdb, db, D1Clusters(hdb, off, nb)
+
+
+@pytest.mark.parametrize("name", ["d1_1k", "d1_nobreak", "d1_mothur", "d1_short", "d1_usearch"])
+def test_d1_outputs_byte_identical(tmp_path, name):
+    args = (G / f"{name}.args").read_text().split()
+    hdb, db, cl = _cluster(name, "-n" in args)
+    usearch = "-z" in args
+    append = 2 if "-a" in args else 0
+    cl.write_swarms(tmp_path / "o", mothur="-r" in args, usearch=usearch, append_abundance=append)
+    assert filecmp.cmp(tmp_path / "o", G / f"{name}.o", shallow=False)
+    for suffix, writer in (("s", cl.write_stats), ("i", cl.write_structure), ("w", cl.write_seeds)):
+        if (G / f"{name}.{suffix}").exists():
+            writer(tmp_path / suffix, usearch=usearch)
+            assert filecmp.cmp(tmp_path / suffix, G / f"{name}.{suffix}", shallow=False), suffix
+    if (G / f"{name}.j").exists():
+        cl.write_network(tmp_path / "j", usearch=usearch, append_abundance=append)
+        assert filecmp.cmp(tmp_path / "j", G / f"{name}.j", shallow=False)
+    log = (G / f"{name}.log").read_text() if (G / f"{name}.log").exists() else ""
+    if log:
+        s = cl.summary()
+        assert f"Number of swarms:  {s['swarms']}\n" in log
+        assert f"Largest swarm:     {s['largest']}\n" in log
+        assert f"Max generations:   {s['maxgen']}\n" in log
+
+
+@pytest.mark.parametrize("name,boundary,bits", [("d1_fastidious", 3, 16), ("d1_fastidious_b10_y8", 10, 8)])
+def test_fastidious_outputs_byte_identical(tmp_path, name, boundary, bits):
+    hdb, db, cl = _cluster(name)
+    log = (G / f"{name}.log").read_text()
+    before = cl.summary()
+    assert f"Number of swarms:  {before['swarms']}\n" in log.split("Heavy swarms")[0]
+    flags, stats = cl.light_flags(boundary)
+    assert f"Heavy swarms: {stats[3]}, with {stats[4]} amplicons" in log
+    assert f"Light swarms: {stats[0]}, with {stats[1]} amplicons" in log
+    assert f"Total length of amplicons in light swarms: {stats[2]}" in log
+    graft, counters = S.oracle_fastidious(db, flags, bits)
+    grafts = cl.graft(graft)
+    assert f"Made {grafts} grafts" in log
+    cl.write_swarms(tmp_path / "o")
+    cl.write_stats(tmp_path / "s")
+    cl.write_structure(tmp_path / "i")
+    for suffix in "osi":
+        assert filecmp.cmp(tmp_path / suffix, G / f"{name}.{suffix}", shallow=False), suffix
+    if (G / f"{name}.w").exists():
+        cl.write_seeds(tmp_path / "w")
+        assert filecmp.cmp(tmp_path / "w", G / f"{name}.w", shallow=False)
+    after = cl.summary()
+    tail = log.split("Made")[1]
+    assert f"Number of swarms:  {after['swarms']}\n" in tail and f"Largest swarm:     {after['largest']}\n" in tail
