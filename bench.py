@@ -222,7 +222,7 @@ def main() -> None:
                 "phase_ms": {"seqhash": timings[0], "table_bloom_build": timings[1], "dup_check": timings[2],
                              "network_kernel": k_ms, "csr": timings[4]},
             },
-            "roofline": {"bound": "hbm", "kernel": "k_d1_network", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_d1_probe<MODE 0> (d=1 network)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_kernel_ms": k_ms},
         }

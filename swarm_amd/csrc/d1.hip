@@ -34,6 +34,12 @@ constexpr int kQueueCap = 128;            // per-wave candidate queue (>= 64 + 6
 constexpr uint32_t kEmpty = SWA_NO_AMPLICON;
 constexpr size_t kMaxZobristLds = 96 * 1024;
 
+struct alignas(16) swa_task {   // one surviving first-level microvariant of a heavy amplicon
+  uint64_t hash;
+  uint32_t heavy;
+  uint32_t code;
+};
+
 struct NetArgs {
   const uint64_t * seqs;
   const uint64_t * seq_off;
@@ -55,6 +61,10 @@ struct NetArgs {
   unsigned long long * edge_counter;
   uint32_t * counts;            // per query amplicon (index k = amp - first)
   unsigned long long * stats;   // [0] variants [1] bloom pass [2] hash match [3] verified
+  // MODE 1 (fastidious second level)
+  const swa_task * tasks;
+  uint32_t * graft;
+  unsigned long long * cand_counter;
 };
 
 // ---- sequence hashes (db.cc:761 zobrist_hash) --------------------------------------
@@ -145,10 +155,106 @@ __global__ __launch_bounds__(256) void k_dup_check(const uint64_t * __restrict__
   }
 }
 
-// ---- the network kernel --------------------------------------------------------------
+// ---- the probe kernels ------------------------------------------------------------------
+
+// Wave-cooperative enumeration of all microvariants of the staged sequence `sw` (len nt).
+// Lane l owns positions [l*K, (l+1)*K), K = ceil((len+1)/64); `f(slots)` is called once
+// per owned position (K times, wave-uniformly) with that position's 8 candidate slots:
+//   [0..3] insertion of base b before p        (variants.cc:226-246)
+//   [4..6] substitution of p by the 3 others   (variants.cc:192-206)
+//   [7]    deletion of p, once per run          (variants.cc:210-222)
+// code = type | base << 2 | pos << 4.  Returns the sequence's own hash.
+struct Slots {
+  uint64_t hs[8];
+  bool ok[8];
+  uint32_t code[8];
+};
+
+template <class F>
+__device__ __forceinline__ uint64_t enumerate_variants(const uint64_t * sw, uint32_t len, const uint64_t * zob,
+                                                       int lane, F && f) {
+  // pass 1: per-lane XOR of the three Zobrist streams over the owned positions
+  const uint32_t K = (len + 64u) >> 6;                     // ceil((len + 1) / 64)
+  const uint32_t p0 = (uint32_t)lane * K;
+  uint64_t xa = 0, xd = 0, xi = 0;
+  for (uint32_t j = 0; j < K; ++j) {
+    const uint32_t p = p0 + j;
+    if (p < len) {
+      const uint32_t c = swa_nt(sw, p);
+      xa ^= zob[4u * p + c];
+      if (p >= 1u) { xd ^= zob[4u * (p - 1u) + c]; }
+      xi ^= zob[4u * (p + 1u) + c];
+    }
+  }
+  // wave scans: exclusive prefix of xa; inclusive suffixes of xd, xi
+  uint64_t pa = xa, sd = xd, si = xi;
+#pragma unroll
+  for (unsigned d = 1; d < 64; d <<= 1) {
+    const uint64_t ta = swa_shfl_up_u64(pa, d);
+    const uint64_t td = swa_shfl_down_u64(sd, d);
+    const uint64_t ti = swa_shfl_down_u64(si, d);
+    if (lane >= (int)d) { pa ^= ta; }
+    if (lane + (int)d < 64) { sd ^= td; si ^= ti; }
+  }
+  const uint64_t H = swa_shfl_u64(pa, 63);                 // hash of the whole sequence
+  pa ^= xa;                                                // exclusive
+
+  // pass 2: the variants of the owned positions
+  uint32_t prevc = (p0 >= 1u && p0 - 1u < len) ? swa_nt(sw, p0 - 1u) : 4u;
+  for (uint32_t j = 0; j < K; ++j) {
+    const uint32_t p = p0 + j;
+    const bool in_seq = p < len;
+    const bool in_ins = p <= len;
+    const uint32_t c = in_seq ? swa_nt(sw, p) : 4u;
+    uint64_t z[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) { z[b] = in_ins ? zob[4u * p + b] : 0ull; }
+    // z[c] without dynamic register indexing
+    const uint64_t zc = (c == 0u) ? z[0] : (c == 1u) ? z[1] : (c == 2u) ? z[2] : z[3];
+    const uint64_t za = in_seq ? zc : 0ull;
+    const uint64_t zd = (in_seq && p >= 1u) ? zob[4u * (p - 1u) + c] : 0ull;
+    const uint64_t zi = in_seq ? zob[4u * (p + 1u) + c] : 0ull;
+
+    Slots s;
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) {
+      s.hs[b] = pa ^ z[b] ^ si;
+      s.ok[b] = in_ins && (p == 0u || b != prevc);
+      s.code[b] = 2u | (b << 2) | (p << 4);
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < 3u; ++t) {
+      const uint32_t b = (t < c) ? t : t + 1u;               // the t-th base that is not c
+      s.hs[4 + t] = H ^ za ^ ((t < c) ? z[t] : z[t + 1u]);
+      s.ok[4 + t] = in_seq;
+      s.code[4 + t] = 0u | (b << 2) | (p << 4);
+    }
+    s.hs[7] = pa ^ sd ^ zd;
+    s.ok[7] = in_seq && (p == 0u || c != prevc);
+    s.code[7] = 1u | (p << 4);
+
+    f(s);
+
+    // advance the running prefix / suffixes past position p
+    pa ^= za;
+    sd ^= zd;
+    si ^= zi;
+    prevc = c;
+  }
+  return H;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // one probe of the candidate (hash h, edit code) drawn from the queue: walk the cluster,
-// apply the abundance rule, verify exactly (algod1.cc:558-603, variants.cc:118-165)
+// apply the abundance rule, verify exactly (algod1.cc:558-603, variants.cc:118-165).
+// SECOND = the fastidious second level (hash_check_attach, algod1.cc:339-371): no self /
+// abundance test there.
+template <bool SECOND>
 __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64_t * sw, uint32_t slen,
                                                  uint32_t snw, uint32_t seed, uint64_t seed_abundance,
                                                  uint64_t h, uint32_t code, uint32_t & out_amp,
@@ -165,8 +271,8 @@ __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64
     if (s.hash == h) {
       ++n_match;
       const uint32_t amp = s.amp;
-      if (amp != seed && (a.no_cluster_breaking != 0 || seed_abundance >= a.abundance[amp]) &&
-          a.seqlen[amp] == vlen) {
+      const bool allowed = SECOND || (amp != seed && (a.no_cluster_breaking != 0 || seed_abundance >= a.abundance[amp]));
+      if (allowed && a.seqlen[amp] == vlen) {
         const uint64_t * y = a.seqs + a.seq_off[amp];
         bool same = true;
         for (uint32_t w = 0; w < vnw; ++w) {
@@ -182,8 +288,11 @@ __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64
   }
 }
 
-template <bool ZLDS, bool STATS>
-__global__ __launch_bounds__(kThreads) void k_d1_network(const NetArgs a) {
+// MODE 0: the d=1 network (query = amplicon first+k of the database).
+// MODE 1: fastidious second level (query k = the microvariant tasks[k] of a heavy amplicon;
+//         every verified light amplicon gets graft_cand = min(heavy id), algod1.cc:244-258).
+template <bool ZLDS, bool STATS, int MODE>
+__global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
   extern __shared__ uint64_t lds[];
   // LDS carve-up (all 8-byte aligned)
   uint64_t * zob_lds = lds;
@@ -209,51 +318,40 @@ __global__ __launch_bounds__(kThreads) void k_d1_network(const NetArgs a) {
 
   const uint32_t nwaves = gridDim.x * kWaves;
   for (uint32_t k = blockIdx.x * kWaves + wave; k < a.count; k += nwaves) {
-    const uint32_t seed = a.first + k;
-    const uint32_t len = a.seqlen[seed];
-    const uint32_t nw = (len + 31u) >> 5;
-    const uint64_t * gs = a.seqs + a.seq_off[seed];
-    const uint64_t seed_ab = a.abundance[seed];
-    for (uint32_t w = lane; w < nw + 2u; w += 64u) { sw[w] = (w < nw) ? gs[w] : 0ull; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- pass 1: per-lane XOR of the three Zobrist streams over the owned positions
-    const uint32_t K = (len + 64u) >> 6;                     // ceil((len + 1) / 64)
-    const uint32_t p0 = (uint32_t)lane * K;
-    uint64_t xa = 0, xd = 0, xi = 0;
-    for (uint32_t j = 0; j < K; ++j) {
-      const uint32_t p = p0 + j;
-      if (p < len) {
-        const uint32_t c = swa_nt(sw, p);
-        xa ^= zob[4u * p + c];
-        if (p >= 1u) { xd ^= zob[4u * (p - 1u) + c]; }
-        xi ^= zob[4u * (p + 1u) + c];
+    uint32_t seed, len, nw;
+    uint64_t seed_ab = 0;
+    if (MODE == 0) {
+      seed = a.first + k;
+      len = a.seqlen[seed];
+      nw = (len + 31u) >> 5;
+      const uint64_t * gs = a.seqs + a.seq_off[seed];
+      seed_ab = a.abundance[seed];
+      for (uint32_t w = lane; w < nw + 2u; w += 64u) { sw[w] = (w < nw) ? gs[w] : 0ull; }
+    } else {
+      // materialise the first-level microvariant (generate_variant_sequence, variants.cc:78-115)
+      const swa_task t = a.tasks[k];
+      seed = t.heavy;
+      const uint32_t hlen = a.seqlen[seed];
+      const uint32_t hnw = (hlen + 31u) >> 5;
+      const uint64_t * gs = a.seqs + a.seq_off[seed];
+      const uint32_t type = t.code & 3u;
+      len = (type == 0u) ? hlen : (type == 1u ? hlen - 1u : hlen + 1u);
+      nw = (len + 31u) >> 5;
+      for (uint32_t w = lane; w < nw + 2u; w += 64u) {
+        sw[w] = (w < nw) ? swa_variant_word(gs, hnw, type, t.code >> 4, (t.code >> 2) & 3u, w) : 0ull;
       }
     }
-    // wave scans: exclusive prefix of xa; inclusive suffix of xd, xi
-    uint64_t pa = xa, sd = xd, si = xi;
-#pragma unroll
-    for (unsigned d = 1; d < 64; d <<= 1) {
-      const uint64_t ta = swa_shfl_up_u64(pa, d);
-      const uint64_t td = swa_shfl_down_u64(sd, d);
-      const uint64_t ti = swa_shfl_down_u64(si, d);
-      if (lane >= (int)d) { pa ^= ta; }
-      if (lane + (int)d < 64) { sd ^= td; si ^= ti; }
-    }
-    const uint64_t H = swa_shfl_u64(pa, 63);                 // == seqhash[seed]
-    pa ^= xa;                                                // exclusive
+    wave_lds_sync();
 
     uint32_t qn = 0;          // queue fill (wave uniform)
-    uint32_t row = 0;         // hits of this amplicon (wave uniform)
+    uint32_t row = 0;         // hits of this query (wave uniform)
 
     auto drain = [&](uint32_t cnt) {
       bool hit = false;
       uint32_t amp = 0;
       uint32_t nmatch = 0;
       if ((uint32_t)lane < cnt) {
-        hit = probe_and_verify(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch);
+        hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch);
       }
       const uint64_t hm = __ballot(hit);
       if (STATS) {
@@ -262,12 +360,16 @@ __global__ __launch_bounds__(kThreads) void k_d1_network(const NetArgs a) {
       }
       if (hm != 0ull) {
         const uint32_t nh = (uint32_t)__popcll(hm);
-        unsigned long long base = 0;
-        if (lane == 0) { base = atomicAdd(a.edge_counter, (unsigned long long)nh); }
-        base = swa_shfl_u64(base, 0);
-        if (hit) {
-          const unsigned long long at = base + (unsigned long long)__popcll(hm & lane_lt);
-          if (at < a.edge_cap) { a.edges[at] = ((uint64_t)seed << 32) | amp; }
+        if (MODE == 0) {
+          unsigned long long base = 0;
+          if (lane == 0) { base = atomicAdd(a.edge_counter, (unsigned long long)nh); }
+          base = swa_shfl_u64(base, 0);
+          if (hit) {
+            const unsigned long long at = base + (unsigned long long)__popcll(hm & lane_lt);
+            if (at < a.edge_cap) { a.edges[at] = ((uint64_t)seed << 32) | amp; }
+          }
+        } else {
+          if (hit) { atomicMin(&a.graft[amp], seed); }
         }
         row += nh;
         if (STATS) { st_ver += nh; }
@@ -285,9 +387,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_network(const NetArgs a) {
       qn += (uint32_t)__popcll(m);
       if (STATS) { st_pass += (unsigned long long)__popcll(m); }
       if (qn >= 64u) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
         drain(64u);
         const uint32_t rest = qn - 64u;
         uint64_t th = 0;
@@ -299,71 +399,29 @@ __global__ __launch_bounds__(kThreads) void k_d1_network(const NetArgs a) {
       }
     };
 
-    // ---- pass 2: the variants of the owned positions, 8 Bloom loads in flight per lane
-    uint64_t sd_run = sd, si_run = si;
-    uint32_t prevc = (p0 >= 1u && p0 - 1u < len) ? swa_nt(sw, p0 - 1u) : 4u;
-    for (uint32_t j = 0; j < K; ++j) {
-      const uint32_t p = p0 + j;
-      const bool in_seq = p < len;
-      const bool in_ins = p <= len;
-      const uint32_t c = in_seq ? swa_nt(sw, p) : 4u;
-      uint64_t z[4];
-#pragma unroll
-      for (uint32_t b = 0; b < 4u; ++b) { z[b] = in_ins ? zob[4u * p + b] : 0ull; }
-      // z[c] without dynamic register indexing
-      const uint64_t zc = (c == 0u) ? z[0] : (c == 1u) ? z[1] : (c == 2u) ? z[2] : z[3];
-      const uint64_t za = in_seq ? zc : 0ull;
-      const uint64_t zd = (in_seq && p >= 1u) ? zob[4u * (p - 1u) + c] : 0ull;
-      const uint64_t zi = in_seq ? zob[4u * (p + 1u) + c] : 0ull;
-
-      uint64_t hs[8];
-      bool ok[8];
-      uint32_t code[8];
-      // insertions before position p (variants.cc:226-246): all 4 bases at p == 0,
-      // otherwise every base but the left neighbour
-#pragma unroll
-      for (uint32_t b = 0; b < 4u; ++b) {
-        hs[b] = pa ^ z[b] ^ si_run;
-        ok[b] = in_ins && (p == 0u || b != prevc);
-        code[b] = 2u | (b << 2) | (p << 4);
-      }
-      // substitutions at p (variants.cc:192-206): the three other bases
-#pragma unroll
-      for (uint32_t t = 0; t < 3u; ++t) {
-        const uint32_t b = (t < c) ? t : t + 1u;               // the t-th base that is not c
-        hs[4 + t] = H ^ za ^ ((t < c) ? z[t] : z[t + 1u]);
-        ok[4 + t] = in_seq;
-        code[4 + t] = 0u | (b << 2) | (p << 4);
-      }
-      // deletion of p (variants.cc:210-222): once per homopolymer run
-      hs[7] = pa ^ sd_run ^ zd;
-      ok[7] = in_seq && (p == 0u || c != prevc);
-      code[7] = 1u | (p << 4);
-
+    // 8 Bloom-word loads in flight per lane, then test + compact
+    (void)enumerate_variants(sw, len, zob, lane, [&](const Slots & s) {
       uint64_t word[8];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        word[s] = ok[s] ? a.bloom[(hs[s] >> 10) & a.bmask] : ~0ull;
+      for (int i = 0; i < 8; ++i) {
+        word[i] = s.ok[i] ? a.bloom[(s.hs[i] >> 10) & a.bmask] : ~0ull;
       }
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bool pass = ok[s] && ((word[s] & pat[hs[s] & 1023u]) == 0ull);   // bloompat.cc:68-71
-        if (STATS) { st_var += (unsigned long long)__popcll(__ballot(ok[s])); }
-        enqueue(pass, hs[s], code[s]);
+      for (int i = 0; i < 8; ++i) {
+        const bool pass = s.ok[i] && ((word[i] & pat[s.hs[i] & 1023u]) == 0ull);   // bloompat.cc:68-71
+        if (STATS) { st_var += (unsigned long long)__popcll(__ballot(s.ok[i])); }
+        enqueue(pass, s.hs[i], s.code[i]);
       }
-      // advance the running prefix / suffixes past position p
-      pa ^= za;
-      sd_run ^= zd;
-      si_run ^= zi;
-      prevc = c;
-    }
+    });
     if (qn > 0u) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_lds_sync();
       drain(qn);
     }
-    if (lane == 0) { a.counts[k] = row; }
+    if (MODE == 0) {
+      if (lane == 0) { a.counts[k] = row; }
+    } else {
+      if (lane == 0 && row != 0u) { atomicAdd(a.cand_counter, (unsigned long long)row); }
+    }
     __builtin_amdgcn_wave_barrier();
   }
   if (STATS && lane == 0) {
@@ -372,6 +430,104 @@ __global__ __launch_bounds__(kThreads) void k_d1_network(const NetArgs a) {
     atomicAdd(&a.stats[2], st_match);
     atomicAdd(&a.stats[3], st_ver);
   }
+}
+
+// ---- fastidious first level (algod1.cc:495-518 mark_light_var, 398-450 check_heavy_var) ---
+struct FlexArgs {
+  const uint64_t * seqs;
+  const uint64_t * seq_off;
+  const uint32_t * seqlen;
+  const uint64_t * zobrist;
+  uint32_t zlen;
+  uint32_t maxwords;
+  unsigned long long * fbits;     // the flexible Bloom, inverted polarity (bloomflex.cc:61-70)
+  uint64_t fsize;                 // words
+  double finv;                    // 1.0 / fsize
+  const uint64_t * fpat;          // 65536 patterns with k bits
+  const uint32_t * list;          // amplicon ids to process
+  uint32_t count;
+  swa_task * tasks;               // PASS 1: surviving (heavy, variant) pairs
+  unsigned long long * task_counter;
+  uint64_t task_cap;
+  unsigned long long * variant_counter;
+};
+
+// (h >> 16) % fsize for an arbitrary (non power-of-two) fsize: bloomflex.cc:43-49.
+// x < 2^48 is exact in a double, so the quotient estimate is off by at most one.
+__device__ __forceinline__ uint64_t flex_word(uint64_t h, uint64_t fsize, double finv) {
+  const uint64_t x = h >> 16;
+  uint64_t q = (uint64_t)((double)x * finv);
+  int64_t r = (int64_t)(x - q * fsize);
+  if (r < 0) { r += (int64_t)fsize; }
+  else if ((uint64_t)r >= fsize) { r -= (int64_t)fsize; }
+  return (uint64_t)r;
+}
+
+// PASS 0: clear the pattern bits of every microvariant of a light amplicon.
+// PASS 1: test every microvariant of a heavy amplicon, emit the survivors as tasks.
+template <bool ZLDS, int PASS>
+__global__ __launch_bounds__(kThreads) void k_d1_flex(const FlexArgs a) {
+  extern __shared__ uint64_t lds[];
+  uint64_t * zob_lds = lds;
+  uint64_t * wave_base = lds + (ZLDS ? 4u * a.zlen : 0u);
+  const uint32_t seed_words = a.maxwords + 2u;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t * sw = wave_base + (size_t)wave * seed_words;
+  if (ZLDS) {
+    for (uint32_t i = threadIdx.x; i < 4u * a.zlen; i += kThreads) { zob_lds[i] = a.zobrist[i]; }
+    __syncthreads();
+  }
+  const uint64_t * zob = ZLDS ? zob_lds : a.zobrist;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  unsigned long long nvar = 0;
+  const uint32_t nwaves = gridDim.x * kWaves;
+  for (uint32_t k = blockIdx.x * kWaves + wave; k < a.count; k += nwaves) {
+    const uint32_t amp = a.list[k];
+    const uint32_t len = a.seqlen[amp];
+    const uint32_t nw = (len + 31u) >> 5;
+    const uint64_t * gs = a.seqs + a.seq_off[amp];
+    for (uint32_t w = lane; w < nw + 2u; w += 64u) { sw[w] = (w < nw) ? gs[w] : 0ull; }
+    wave_lds_sync();
+    (void)enumerate_variants(sw, len, zob, lane, [&](const Slots & s) {
+      if (PASS == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (s.ok[i]) {
+            atomicAnd(&a.fbits[flex_word(s.hs[i], a.fsize, a.finv)], ~(unsigned long long)a.fpat[s.hs[i] & 0xFFFFu]);
+          }
+          nvar += (unsigned long long)__popcll(__ballot(s.ok[i]));
+        }
+      } else {
+        uint64_t word[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          word[i] = s.ok[i] ? (uint64_t)a.fbits[flex_word(s.hs[i], a.fsize, a.finv)] : ~0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool pass = s.ok[i] && ((word[i] & a.fpat[s.hs[i] & 0xFFFFu]) == 0ull);   // bloomflex_get
+          nvar += (unsigned long long)__popcll(__ballot(s.ok[i]));
+          const uint64_t m = __ballot(pass);
+          if (m != 0ull) {
+            unsigned long long base = 0;
+            if (lane == 0) { base = atomicAdd(a.task_counter, (unsigned long long)__popcll(m)); }
+            base = swa_shfl_u64(base, 0);
+            if (pass) {
+              const unsigned long long at = base + (unsigned long long)__popcll(m & lane_lt);
+              if (at < a.task_cap) {
+                swa_task t;
+                t.hash = s.hs[i]; t.heavy = amp; t.code = s.code[i];
+                a.tasks[at] = t;
+              }
+            }
+          }
+        }
+      }
+    });
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0 && nvar != 0ull) { atomicAdd(a.variant_counter, nvar); }
 }
 
 // ---- CSR assembly: counts -> offsets (exclusive scan), edges -> rows, sort rows ------
@@ -618,13 +774,13 @@ static int launch_network(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count
   const int grid = grid_for(ctx, count, kWaves, 8);
   swa_t0(ctx, 3);
   if (zlds && stats) {
-    hipLaunchKernelGGL((k_d1_network<true, true>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_d1_probe<true, true, 0>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
   } else if (zlds) {
-    hipLaunchKernelGGL((k_d1_network<true, false>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_d1_probe<true, false, 0>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
   } else if (stats) {
-    hipLaunchKernelGGL((k_d1_network<false, true>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_d1_probe<false, true, 0>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
   } else {
-    hipLaunchKernelGGL((k_d1_network<false, false>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_d1_probe<false, false, 0>), dim3(grid), dim3(kThreads), lds, ctx->stream, a);
   }
   swa_t1(ctx, 3);
   SWA_HIP(ctx, hipGetLastError());
@@ -725,5 +881,165 @@ extern "C" int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   SWA_HIP(ctx, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}
+
+// ---- seam B2: the fastidious second pass --------------------------------------------------
+// Orchestration of algo_d1_run's fastidious branch (src/algod1.cc:1337-1467) on the GPU:
+//   pass A  table + amplicon Bloom rebuilt with the light-swarm amplicons only (1411-1412,
+//           mark_light_var's hash_insert), then every microvariant of every light amplicon
+//           clears its k pattern bits in the flexible Bloom with atomicAnd (the reference's
+//           plain `&=` from many threads can lose a bit; -t 1 is the specification);
+//   pass B  first level: every microvariant of every heavy amplicon is tested against the
+//           flexible Bloom; survivors become 16-byte tasks in HBM (batched so the task
+//           buffer can never overflow silently);
+//           second level: one wave per task re-runs the d=1 probe kernel on the materialised
+//           microvariant (k_d1_probe<MODE 1>) and atomicMin's graft_cand of each verified
+//           light amplicon — the reference's add_graft_candidate under a mutex.
+extern "C" int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
+                                 uint32_t * graft_cand, uint64_t * counters) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: call swa_d1_index_build first"); }
+  if (is_light == nullptr || graft_cand == nullptr || counters == nullptr || bloom_bits < 2 || bloom_bits > 64) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: bad argument");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  // sizing: src/algod1.cc:1337-1357, 1383-1403; bloomflex.cc:91-115
+  uint32_t k = static_cast<uint32_t>(0.4 * static_cast<double>(bloom_bits));
+  if (k < 1) { k = 1; }
+  uint64_t m = light_nt * 7ull * bloom_bits;
+  if (m < 64) { m = 64; }
+  const uint64_t n_bytes = ((m - 1) / 8) + 1;
+  const uint64_t fsize = n_bytes >> 3;
+
+  std::vector<uint32_t> light_ids, heavy_ids;
+  for (uint32_t i = 0; i < n; ++i) { (is_light[i] != 0 ? light_ids : heavy_ids).push_back(i); }
+  std::vector<uint64_t> fpat;
+  swa_bloom_patterns(65536, k, fpat);
+
+  SWA_TRY(swa_reserve(ctx, ctx->d_light, n));
+  SWA_TRY(swa_reserve(ctx, ctx->d_graft, uint64_t(n) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_bloomflex, fsize * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_fpatterns, fpat.size() * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_a, (light_ids.size() + 1) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_b, (heavy_ids.size() + 1) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_fcounters, 8 * sizeof(uint64_t)));
+  const uint64_t maxv = 7ull * ctx->db.longest + 4ull;
+  uint64_t task_cap = heavy_ids.size() * maxv;
+  const uint64_t cap_limit = (1ull << 30) / sizeof(swa_task);            // 1 GiB of tasks
+  if (task_cap > cap_limit) { task_cap = cap_limit; }
+  if (task_cap < maxv) { task_cap = maxv; }
+  SWA_TRY(swa_reserve(ctx, ctx->d_queue, task_cap * sizeof(swa_task)));
+
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_light.ptr, is_light, n, hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_fpatterns.ptr, fpat.data(), fpat.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  if (!light_ids.empty()) {
+    SWA_HIP(ctx, hipMemcpyAsync(ctx->d_list_a.ptr, light_ids.data(), light_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!heavy_ids.empty()) {
+    SWA_HIP(ctx, hipMemcpyAsync(ctx->d_list_b.ptr, heavy_ids.data(), heavy_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_graft.ptr, 0xFF, uint64_t(n) * sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_bloomflex.ptr, 0xFF, fsize * sizeof(uint64_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_fcounters.ptr, 0, 8 * sizeof(uint64_t), ctx->stream));
+  ctx->d1_ready = false;                                     // the table now holds light amplicons only
+  SWA_TRY(swa_d1_rebuild_table(ctx, static_cast<const uint8_t *>(ctx->d_light.ptr)));
+
+  auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);   // [0] light var [1] heavy var [2] cand [3] tasks
+  FlexArgs f{};
+  f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen;
+  f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
+  f.zlen = ctx->zobrist_len;
+  f.maxwords = (ctx->db.longest + 1u + 31u) >> 5;
+  f.fbits = static_cast<unsigned long long *>(ctx->d_bloomflex.ptr);
+  f.fsize = fsize;
+  f.finv = 1.0 / static_cast<double>(fsize);
+  f.fpat = static_cast<const uint64_t *>(ctx->d_fpatterns.ptr);
+  f.tasks = static_cast<swa_task *>(ctx->d_queue.ptr);
+  f.task_counter = fc + 3;
+  f.task_cap = task_cap;
+  const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
+  const size_t flex_lds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + kWaves * (size_t)(f.maxwords + 2u));
+
+  // pass A
+  swa_t0(ctx, 5);
+  if (!light_ids.empty()) {
+    f.list = static_cast<const uint32_t *>(ctx->d_list_a.ptr);
+    f.count = static_cast<uint32_t>(light_ids.size());
+    f.variant_counter = fc + 0;
+    const int grid = grid_for(ctx, f.count, kWaves, 8);
+    if (zlds) { hipLaunchKernelGGL((k_d1_flex<true, 0>), dim3(grid), dim3(kThreads), flex_lds, ctx->stream, f); }
+    else { hipLaunchKernelGGL((k_d1_flex<false, 0>), dim3(grid), dim3(kThreads), flex_lds, ctx->stream, f); }
+    SWA_HIP(ctx, hipGetLastError());
+  }
+  swa_t1(ctx, 5);
+
+  // pass B
+  NetArgs a{};
+  a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen; a.abundance = ctx->db.abundance;
+  a.zobrist = f.zobrist; a.zlen = ctx->zobrist_len;
+  a.maxwords = f.maxwords;                                   // a microvariant can be one nt longer
+  a.table = static_cast<const swa_slot *>(ctx->d_table.ptr);
+  a.tmask = ctx->table_size - 1;
+  a.bloom = static_cast<const uint64_t *>(ctx->d_bloom.ptr);
+  a.bmask = ctx->bloom_words - 1;
+  a.patterns = static_cast<const uint64_t *>(ctx->d_patterns.ptr);
+  a.stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
+  a.tasks = f.tasks;
+  a.graft = static_cast<uint32_t *>(ctx->d_graft.ptr);
+  a.cand_counter = fc + 2;
+  const size_t probe_lds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull +
+                                               kWaves * ((size_t)(a.maxwords + 2u) + kQueueCap + kQueueCap / 2));
+  swa_t0(ctx, 6);
+  uint64_t done = 0;
+  uint64_t heavy_variants = 0;
+  uint64_t batch = task_cap / maxv;                          // cannot overflow
+  double rate = -1.0;                                        // observed tasks per heavy amplicon
+  while (done < heavy_ids.size()) {
+    uint64_t want = batch;
+    if (rate >= 0.0) {                                       // optimistic sizing, overflow is detected below
+      const double est = static_cast<double>(task_cap) / (4.0 * rate + 1.0);
+      want = est > 4.0e9 ? 4000000000ull : static_cast<uint64_t>(est);
+      if (want < batch) { want = batch; }
+    }
+    if (want > heavy_ids.size() - done) { want = heavy_ids.size() - done; }
+    SWA_HIP(ctx, hipMemsetAsync(fc + 3, 0, 2 * sizeof(uint64_t), ctx->stream));    // tasks + batch variants
+    f.list = static_cast<const uint32_t *>(ctx->d_list_b.ptr) + done;
+    f.count = static_cast<uint32_t>(want);
+    f.variant_counter = fc + 4;
+    const int grid = grid_for(ctx, f.count, kWaves, 8);
+    if (zlds) { hipLaunchKernelGGL((k_d1_flex<true, 1>), dim3(grid), dim3(kThreads), flex_lds, ctx->stream, f); }
+    else { hipLaunchKernelGGL((k_d1_flex<false, 1>), dim3(grid), dim3(kThreads), flex_lds, ctx->stream, f); }
+    SWA_HIP(ctx, hipGetLastError());
+    uint64_t got[2] = {0, 0};
+    SWA_HIP(ctx, hipMemcpyAsync(got, fc + 3, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (got[0] > task_cap) {                                 // optimistic batch did not fit: redo it smaller
+      rate = static_cast<double>(got[0]) / static_cast<double>(want);
+      continue;
+    }
+    rate = static_cast<double>(got[0]) / static_cast<double>(want);
+    heavy_variants += got[1];
+    if (got[0] > 0) {
+      a.count = static_cast<uint32_t>(got[0]);
+      const int pgrid = grid_for(ctx, a.count, kWaves, 8);
+      if (zlds) { hipLaunchKernelGGL((k_d1_probe<true, false, 1>), dim3(pgrid), dim3(kThreads), probe_lds, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_probe<false, false, 1>), dim3(pgrid), dim3(kThreads), probe_lds, ctx->stream, a); }
+      SWA_HIP(ctx, hipGetLastError());
+    }
+    done += want;
+  }
+  swa_t1(ctx, 6);
+
+  uint64_t host_fc[8] = {};
+  SWA_HIP(ctx, hipMemcpyAsync(host_fc, fc, sizeof(host_fc), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(graft_cand, ctx->d_graft.ptr, uint64_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  counters[0] = host_fc[0];
+  counters[1] = heavy_variants;
+  counters[2] = host_fc[2];
+  counters[3] = m;
+  counters[4] = k;
   return SWA_OK;
 }

@@ -2,11 +2,6 @@
 // (never a CPU fallback).  Each stub disappears when its kernel file lands.
 #include "swa_internal.h"
 
-#ifndef SWA_HAVE_FASTIDIOUS
-extern "C" int swa_d1_fastidious(swa_ctx * ctx, const uint8_t *, uint64_t, uint32_t, uint32_t *, uint64_t *) {
-  return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: not implemented in this build");
-}
-#endif
 #ifndef SWA_HAVE_QGRAM
 extern "C" int swa_qgram_build(swa_ctx * ctx) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_qgram_build: not implemented in this build"); }
 extern "C" int swa_qgram_diff(swa_ctx * ctx, uint64_t, uint64_t, const uint64_t *, uint64_t *) {

@@ -1,0 +1,57 @@
+"""B2 parity on the GPU: swa_d1_fastidious (HIP) vs the oracle and vs the reference's own
+output files (tests/golden), through the C ABI; the host clustering consumes the HIP path's
+neighbour lists here."""
+import filecmp
+import re
+
+import numpy as np
+import pytest
+
+import support as S
+from swarm_amd import D1Clusters, HostDb
+
+pytestmark = pytest.mark.gpu
+G = S.GOLDEN
+
+
+def _pipeline(ctx, fasta, boundary, bits):
+    hdb = HostDb(fasta)
+    ctx.upload_hostdb(hdb)
+    assert ctx.d1_index_build() is False
+    off, nb = ctx.d1_network()
+    cl = D1Clusters(hdb, off, nb)
+    flags, stats = cl.light_flags(boundary)
+    graft, counters = ctx.d1_fastidious(flags, stats[2], bits)
+    return hdb, cl, flags, stats, graft, counters
+
+
+@pytest.mark.parametrize("name,boundary,bits", [("d1_fastidious", 3, 16), ("d1_fastidious_b10_y8", 10, 8)])
+def test_fastidious_matches_reference_outputs(gpu_ctx, tmp_path, name, boundary, bits):
+    hdb, cl, flags, stats, graft, counters = _pipeline(gpu_ctx, G / f"{name}.fasta", boundary, bits)
+    log = (G / f"{name}.log").read_text()
+    pick = lambda pat: int(re.search(pat, log).group(1))
+    assert int(counters[0]) == pick(r"Generated (\d+) variants")
+    assert int(counters[1]) == pick(r"Heavy variants: (\d+)")
+    assert int(counters[2]) == pick(r"Got (\d+) graft")
+    assert (int(counters[3]), int(counters[4])) == (pick(r"m=(\d+)"), pick(r"k=(\d+)"))
+    db = S.db_from_fasta(G / f"{name}.fasta")
+    want_graft, want_counters = S.oracle_fastidious(db, flags, bits)
+    assert np.array_equal(graft, want_graft)
+    assert cl.graft(graft) == pick(r"Made (\d+) grafts")
+    cl.write_swarms(tmp_path / "o")
+    cl.write_stats(tmp_path / "s")
+    cl.write_structure(tmp_path / "i")
+    for suffix in "osi":
+        assert filecmp.cmp(tmp_path / suffix, G / f"{name}.{suffix}", shallow=False), suffix
+
+
+@pytest.mark.parametrize("n,length,seed,light,boundary,bits", [(20000, 150, 41, 0.3, 3, 16), (6000, 400, 42, 0.2, 3, 16),
+                                                            (8000, 40, 43, 0.4, 5, 4), (3000, 150, 44, 0.0, 3, 16)])
+def test_fastidious_matches_oracle(gpu_ctx, tmp_path, n, length, seed, light, boundary, bits):
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, n, length, seed, 1, light)
+    hdb, cl, flags, stats, graft, counters = _pipeline(gpu_ctx, fa, boundary, bits)
+    db = S.db_from_fasta(fa)
+    want_graft, want_counters = S.oracle_fastidious(db, flags, bits)
+    assert np.array_equal(graft, want_graft)
+    assert [int(x) for x in counters[:5]] == [int(x) for x in want_counters[:5]]
