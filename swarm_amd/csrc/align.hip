@@ -1,0 +1,333 @@
+// align.hip — seam B4: one-vs-many alignment scan on gfx950.
+//
+// Replaces search_do -> search8/search16 -> backtrack<> (src/scan.cc:221-256,
+// src/search8.cc:629-903, src/search16.cc:385-678, src/utils/backtrack.h:51-138): for a
+// query amplicon and a list of targets, the number of non-identical columns ("diff") of the
+// reference's tie-broken minimum-cost global alignment with affine gaps.
+//
+// The reference fills a full qlen x dlen matrix in 16 (or 8) SIMD channels, stores four
+// direction bits per cell and walks them backwards.  This kernel is built differently:
+//
+//   * forward-only: besides H/E/F each cell carries three small counters A_M, A_I, A_D = the
+//     number of non-identical columns the reference's backtrack WOULD collect from that cell
+//     to the origin when it arrives in state match / continuing-insertion / continuing-
+//     deletion.  They obey local recurrences driven by the very comparisons the reference
+//     records as direction bits (nw.cc:91-103, backtrack priority nw.cc:139-172), so no
+//     direction matrix and no serial backtrack exist; diff = A_M(last cell).
+//   * banded: a pair can only be accepted if diff <= d, hence cost <= T = d*max(mismatch,
+//     gapopen+gapextend); every value that can influence the accepted path is < T + gapopen,
+//     which confines the computation to |row - column| <= W = floor(T / gapextend) + 1.
+//     Out-of-band inputs read as the saturation value.  Values saturate at 255 / 65535 like
+//     the reference's v_add8 / v_add16 (src/utils/intrinsics_to_functions_x86_64.cc:103-125).
+//     For pairs the reference would accept the result is bit-identical; any other pair gets
+//     some value > d (proof sketch in DESIGN.md, exhaustive parity in tests/).
+//   * anti-diagonal wavefront: G = 32 or 64 lanes per (query, target) pair, lane <-> band
+//     offset (column - row); a cell needs its own lane's value from two steps ago (diagonal)
+//     and its two neighbour lanes' values from the previous step, so each step is one
+//     shuffle up + one shuffle down and pure integer VALU work.  Sequences sit 2-bit packed
+//     in LDS.
+#include "swa_internal.h"
+
+namespace {
+
+struct AlignArgs {
+  const uint64_t * seqs;
+  const uint64_t * seq_off;
+  const uint32_t * seqlen;
+  uint32_t query;
+  uint32_t ntargets;
+  const uint64_t * targets;
+  uint64_t * scores;        // may be null
+  uint64_t * diffs;
+  uint64_t * alnlens;       // may be null
+  uint32_t mismatch, gapopen, gapextend;
+  uint32_t sat;             // 255 or 65535
+  int W;                    // band half-width
+  uint32_t maxwords;        // words per staged sequence
+};
+
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b, uint32_t sat) {
+  const uint32_t s = a + b;
+  return s < sat ? s : sat;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
+  extern __shared__ uint64_t lds[];
+  constexpr int kGroups = 256 / G;
+  uint64_t * qw = lds;                                        // query words (shared by the block)
+  const int group = threadIdx.x / G;
+  const int t = threadIdx.x % G;
+  uint64_t * dw = lds + a.maxwords + (size_t)group * a.maxwords;   // this group's target words
+
+  const uint32_t ql = a.seqlen[a.query];
+  {
+    const uint64_t * gq = a.seqs + a.seq_off[a.query];
+    const uint32_t qn = (ql + 31u) >> 5;
+    for (uint32_t w = threadIdx.x; w < qn; w += 256u) { qw[w] = gq[w]; }
+  }
+  __syncthreads();
+
+  const uint32_t SAT = a.sat;
+  const int W = a.W;
+  const int o = t - W;                                        // band offset = column - row
+  const bool lane_in_band = t <= 2 * W;
+  const uint32_t go = a.gapopen, ge = a.gapextend, mm = a.mismatch;
+  constexpr uint32_t kBigCount = 0xFFFFu;
+
+  for (uint32_t pair = blockIdx.x * kGroups + group; pair < a.ntargets; pair += gridDim.x * kGroups) {
+    const uint32_t target = (uint32_t)a.targets[pair];
+    const uint32_t dl = a.seqlen[target];
+    {
+      const uint64_t * gd = a.seqs + a.seq_off[target];
+      const uint32_t dn = (dl + 31u) >> 5;
+      for (uint32_t w = t; w < dn; w += G) { dw[w] = gd[w]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    const int delta = (int)ql - (int)dl;
+    const bool feasible = (delta <= W) && (-delta <= W);      // the end cell lies inside the band
+    // per-lane state: values of the last cell this lane computed
+    uint32_t Hown = 0, AMown = 0, LMown = 0;                  // H, A_M, alignment length (diagonal input)
+    uint32_t Edn = SAT, AIdn = kBigCount, LIdn = 0;           // E passed down to (r+1, c) with A_I, L_I
+    uint32_t Frt = SAT, ADrt = kBigCount, LDrt = 0;           // F passed right to (r, c+1) with A_D, L_D
+    if (feasible) {
+      const int last = (int)dl + (int)ql - 2;
+      for (int s = 0; s <= last; ++s) {
+        // neighbour values from the previous step (computed by every lane of the group)
+        const uint32_t vE = __shfl_down(Edn, 1, G), vAI = __shfl_down(AIdn, 1, G), vLI = __shfl_down(LIdn, 1, G);
+        const uint32_t vF = __shfl_up(Frt, 1, G), vAD = __shfl_up(ADrt, 1, G), vLD = __shfl_up(LDrt, 1, G);
+        const int rs = s - o;
+        const int r = rs >> 1;
+        const int c = s - r;
+        const bool act = lane_in_band && ((rs & 1) == 0) && rs >= 0 && r < (int)dl && c >= 0 && c < (int)ql;
+        if (act) {
+          // diagonal input: H(r-1, c-1), boundary per nw.cc:66-79
+          uint32_t hd, amd, lmd;
+          if (r == 0) { hd = (c == 0) ? 0u : sat_add(go, (uint32_t)c * ge, SAT); amd = (uint32_t)c; lmd = (uint32_t)c; }
+          else if (c == 0) { hd = sat_add(go, (uint32_t)r * ge, SAT); amd = (uint32_t)r; lmd = (uint32_t)r; }
+          else { hd = Hown; amd = AMown; lmd = LMown; }
+          // vertical input ("left" in nw.cc): E from (r-1, c), held by lane t+1
+          uint32_t left, aiv, liv;
+          if (r == 0) { left = sat_add(2u * go, (uint32_t)(c + 2) * ge, SAT); aiv = (uint32_t)c + 1u; liv = (uint32_t)c + 1u; }
+          else if (t + 1 <= 2 * W) { left = vE; aiv = vAI; liv = vLI; }
+          else { left = SAT; aiv = kBigCount; liv = 0u; }
+          // horizontal input ("top" in nw.cc): F from (r, c-1), held by lane t-1
+          uint32_t top, adh, ldh;
+          if (c == 0) { top = sat_add(2u * go, (uint32_t)(r + 2) * ge, SAT); adh = (uint32_t)r + 1u; ldh = (uint32_t)r + 1u; }
+          else if (t >= 1) { top = vF; adh = vAD; ldh = vLD; }
+          else { top = SAT; adh = kBigCount; ldh = 0u; }
+
+          const uint32_t dnt = (uint32_t)((dw[r >> 5] >> ((r & 31) << 1)) & 3u);
+          const uint32_t qnt = (uint32_t)((qw[c >> 5] >> ((c & 31) << 1)) & 3u);
+          const uint32_t mis = dnt != qnt ? 1u : 0u;
+          const uint32_t dp = sat_add(hd, mis ? mm : 0u, SAT);
+          const bool up = top < dp;                            // nw.cc:91
+          uint32_t h = dp < top ? dp : top;
+          h = h < left ? h : left;
+          const bool lb = left == h;                           // nw.cc:94
+          const uint32_t d2 = sat_add(h, go + ge, SAT);
+          const uint32_t l2 = sat_add(left, ge, SAT);
+          const uint32_t t2 = sat_add(top, ge, SAT);
+          const bool eu = t2 < d2;                             // nw.cc:102
+          const bool el = l2 < d2;                             // nw.cc:103
+          // what the backtrack would count from here (priority: nw.cc:139-172)
+          uint32_t am, lm;
+          if (lb) { am = aiv + 1u; lm = liv + 1u; }
+          else if (up) { am = adh + 1u; lm = ldh + 1u; }
+          else { am = amd + mis; lm = lmd + 1u; }
+          if (am > kBigCount) { am = kBigCount; }
+          uint32_t ai = el ? aiv + 1u : am;
+          uint32_t ad = eu ? adh + 1u : am;
+          if (ai > kBigCount) { ai = kBigCount; }
+          if (ad > kBigCount) { ad = kBigCount; }
+          Hown = h; AMown = am; LMown = lm;
+          Edn = d2 < l2 ? d2 : l2; AIdn = ai; LIdn = el ? liv + 1u : lm;
+          Frt = d2 < t2 ? d2 : t2; ADrt = ad; LDrt = eu ? ldh + 1u : lm;
+        }
+      }
+    }
+    // the lane whose offset equals ql - dl holds the end cell
+    if (!feasible) {
+      if (t == 0) {
+        a.diffs[pair] = SAT;
+        if (a.scores != nullptr) { a.scores[pair] = SAT; }
+        if (a.alnlens != nullptr) { a.alnlens[pair] = 0; }
+      }
+    } else if (o == delta) {
+      // like the reference: a saturated score means "no alignment", diff = SAT (search8.cc:776-810)
+      const bool overflow = Hown >= SAT;
+      a.diffs[pair] = overflow ? SAT : AMown;
+      if (a.scores != nullptr) { a.scores[pair] = Hown; }
+      if (a.alnlens != nullptr) { a.alnlens[pair] = overflow ? 0 : LMown; }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Generic fallback for bands wider than 64 lanes (large d or unusual penalties): one thread
+// per pair walks the band row by row with the previous row kept in an interleaved global
+// scratch (column-major across threads, so a wave's accesses coalesce).  Same recurrences,
+// same saturation, same result; only slower.
+__global__ __launch_bounds__(256) void k_align_generic(const AlignArgs a, uint32_t * __restrict__ scratch,
+                                                       uint32_t nthreads, uint32_t qcap) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= nthreads) { return; }
+  const uint32_t SAT = a.sat;
+  const int W = a.W;
+  const uint32_t go = a.gapopen, ge = a.gapextend, mm = a.mismatch;
+  constexpr uint32_t kBigCount = 0xFFFFu;
+  const uint32_t ql = a.seqlen[a.query];
+  const uint64_t * qw = a.seqs + a.seq_off[a.query];
+  // six planes of qcap columns each: H, E, A_M, A_I, L_M, L_I of the previous row
+  uint32_t * pH = scratch;
+  uint32_t * pE = pH + (size_t)qcap * nthreads;
+  uint32_t * pAM = pE + (size_t)qcap * nthreads;
+  uint32_t * pAI = pAM + (size_t)qcap * nthreads;
+  uint32_t * pLM = pAI + (size_t)qcap * nthreads;
+  uint32_t * pLI = pLM + (size_t)qcap * nthreads;
+  for (uint32_t pair = tid; pair < a.ntargets; pair += nthreads) {
+    const uint32_t target = (uint32_t)a.targets[pair];
+    const uint32_t dl = a.seqlen[target];
+    const uint64_t * dw = a.seqs + a.seq_off[target];
+    const int delta = (int)ql - (int)dl;
+    uint32_t endH = SAT, endAM = kBigCount, endLM = 0;
+    const bool feasible = (delta <= W) && (-delta <= W);
+    if (feasible) {
+      for (int r = 0; r < (int)dl; ++r) {
+        const uint32_t dnt = (uint32_t)((dw[r >> 5] >> ((r & 31) << 1)) & 3u);
+        const int c0 = r - W > 0 ? r - W : 0;
+        const int c1 = r + W < (int)ql - 1 ? r + W : (int)ql - 1;
+        // running horizontal state and the diagonal inputs for column c0
+        uint32_t top, adh, ldh, hd, amd, lmd;
+        if (c0 == 0) {
+          top = sat_add(2u * go, (uint32_t)(r + 2) * ge, SAT); adh = (uint32_t)r + 1u; ldh = (uint32_t)r + 1u;
+          hd = (r == 0) ? 0u : sat_add(go, (uint32_t)r * ge, SAT); amd = (uint32_t)r; lmd = (uint32_t)r;
+        } else {
+          top = SAT; adh = kBigCount; ldh = 0u;                  // (r, c0-1) lies outside the band
+          const size_t at = (size_t)(c0 - 1) * nthreads + tid;   // (r-1, c0-1): same offset, inside
+          hd = pH[at]; amd = pAM[at]; lmd = pLM[at];
+        }
+        for (int c = c0; c <= c1; ++c) {
+          const size_t at = (size_t)c * nthreads + tid;
+          uint32_t left, aiv, liv;
+          if (r == 0) { left = sat_add(2u * go, (uint32_t)(c + 2) * ge, SAT); aiv = (uint32_t)c + 1u; liv = (uint32_t)c + 1u; }
+          else if (c <= r - 1 + W) { left = pE[at]; aiv = pAI[at]; liv = pLI[at]; }
+          else { left = SAT; aiv = kBigCount; liv = 0u; }
+          // the diagonal input of the NEXT column is this column's previous-row value
+          uint32_t nhd, namd, nlmd;
+          if (r == 0) { nhd = sat_add(go, (uint32_t)(c + 1) * ge, SAT); namd = (uint32_t)c + 1u; nlmd = (uint32_t)c + 1u; }
+          else { nhd = pH[at]; namd = pAM[at]; nlmd = pLM[at]; }
+          const uint32_t qnt = (uint32_t)((qw[c >> 5] >> ((c & 31) << 1)) & 3u);
+          const uint32_t mis = dnt != qnt ? 1u : 0u;
+          const uint32_t dp = sat_add(hd, mis ? mm : 0u, SAT);
+          const bool up = top < dp;
+          uint32_t h = dp < top ? dp : top;
+          h = h < left ? h : left;
+          const bool lb = left == h;
+          const uint32_t d2 = sat_add(h, go + ge, SAT);
+          const uint32_t l2 = sat_add(left, ge, SAT);
+          const uint32_t t2 = sat_add(top, ge, SAT);
+          const bool eu = t2 < d2;
+          const bool el = l2 < d2;
+          uint32_t am, lm;
+          if (lb) { am = aiv + 1u; lm = liv + 1u; }
+          else if (up) { am = adh + 1u; lm = ldh + 1u; }
+          else { am = amd + mis; lm = lmd + 1u; }
+          if (am > kBigCount) { am = kBigCount; }
+          uint32_t ai = el ? aiv + 1u : am;
+          uint32_t ad = eu ? adh + 1u : am;
+          if (ai > kBigCount) { ai = kBigCount; }
+          if (ad > kBigCount) { ad = kBigCount; }
+          pH[at] = h; pAM[at] = am; pLM[at] = lm;
+          pE[at] = d2 < l2 ? d2 : l2; pAI[at] = ai; pLI[at] = el ? liv + 1u : lm;
+          top = d2 < t2 ? d2 : t2; adh = ad; ldh = eu ? ldh + 1u : lm;
+          hd = nhd; amd = namd; lmd = nlmd;
+          if (r == (int)dl - 1 && c == (int)ql - 1) { endH = h; endAM = am; endLM = lm; }
+        }
+      }
+    }
+    const bool overflow = !feasible || endH >= SAT;
+    a.diffs[pair] = overflow ? SAT : endAM;
+    if (a.scores != nullptr) { a.scores[pair] = feasible ? endH : SAT; }
+    if (a.alnlens != nullptr) { a.alnlens[pair] = overflow ? 0 : endLM; }
+  }
+}
+
+}  // namespace
+
+extern "C" int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, uint64_t d) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (mismatch == 0 || gapextend == 0 || mismatch > 65535 || gapopen > 65535 || gapextend > 65535 || d == 0 || d > 255) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_search_begin: penalties must be positive and d in 1..255");
+  }
+  ctx->pen_mismatch = mismatch;
+  ctx->pen_gapopen = gapopen;
+  ctx->pen_gapextend = gapextend;
+  ctx->resolution = d;
+  ctx->search_ready = true;
+  return SWA_OK;
+}
+
+extern "C" int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listlength, const uint64_t * targets,
+                             uint64_t * scores, uint64_t * diffs, uint64_t * alignlengths) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->search_ready || ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_search_do: call swa_search_begin first"); }
+  if (listlength == 0) { return SWA_OK; }
+  if (targets == nullptr || diffs == nullptr || query_no >= ctx->db.n || listlength > 0xFFFFFFFFull) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_search_do: bad argument");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t mm = ctx->pen_mismatch, go = ctx->pen_gapopen, ge = ctx->pen_gapextend, d = ctx->resolution;
+  // 8- or 16-bit arithmetic exactly as set_bit_mode decides (src/algo.cc:96-120)
+  const uint64_t diff_saturation = std::min<uint64_t>(255 / mm, 255 / (go + ge));
+  const uint32_t sat = d > diff_saturation ? 65535u : 255u;
+  const uint64_t T = d * std::max<uint64_t>(mm, go + ge);
+  const uint64_t W64 = T / ge + 1;
+  const bool generic = 2 * W64 + 1 > 64;
+  AlignArgs a{};
+  a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen;
+  a.query = (uint32_t)query_no;
+  a.ntargets = (uint32_t)listlength;
+  a.mismatch = (uint32_t)mm; a.gapopen = (uint32_t)go; a.gapextend = (uint32_t)ge;
+  a.sat = sat;
+  a.W = (int)W64;
+  a.maxwords = ((ctx->db.longest + 31u) >> 5) + 1u;
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_a, listlength * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_b, listlength * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_c, listlength * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_d, listlength * sizeof(uint64_t)));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_list_a.ptr, targets, listlength * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  a.targets = static_cast<const uint64_t *>(ctx->d_list_a.ptr);
+  a.diffs = static_cast<uint64_t *>(ctx->d_list_b.ptr);
+  a.scores = scores != nullptr ? static_cast<uint64_t *>(ctx->d_list_c.ptr) : nullptr;
+  a.alnlens = alignlengths != nullptr ? static_cast<uint64_t *>(ctx->d_list_d.ptr) : nullptr;
+  const bool wide = 2 * W64 + 1 > 32;
+  const int groups = wide ? 4 : 8;
+  uint64_t blocks = (listlength + groups - 1) / groups;
+  const uint64_t cap = uint64_t(ctx->num_cus) * 8;
+  if (blocks > cap) { blocks = cap; }
+  const size_t lds = sizeof(uint64_t) * (size_t)a.maxwords * (groups + 1);
+  if (generic) {
+    a.W = W64 > 0x3FFFFFFF ? 0x3FFFFFFF : (int)W64;
+    const uint32_t qcap = ctx->db.longest + 1u;
+    uint64_t nthreads = listlength < 65536 ? ((listlength + 63) / 64) * 64 : 65536;
+    while (nthreads > 64 && nthreads * 6ull * qcap * sizeof(uint32_t) > (2ull << 30)) { nthreads /= 2; }
+    SWA_TRY(swa_reserve(ctx, ctx->d_queue, nthreads * 6ull * qcap * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_align_generic, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, a,
+                       static_cast<uint32_t *>(ctx->d_queue.ptr), (uint32_t)nthreads, qcap);
+  } else if (wide) { hipLaunchKernelGGL(k_align<64>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
+  else { hipLaunchKernelGGL(k_align<32>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
+  SWA_HIP(ctx, hipGetLastError());
+  SWA_HIP(ctx, hipMemcpyAsync(diffs, ctx->d_list_b.ptr, listlength * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (scores != nullptr) {
+    SWA_HIP(ctx, hipMemcpyAsync(scores, ctx->d_list_c.ptr, listlength * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (alignlengths != nullptr) {
+    SWA_HIP(ctx, hipMemcpyAsync(alignlengths, ctx->d_list_d.ptr, listlength * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}

@@ -1,0 +1,118 @@
+// qgram.hip — seam B3: the q-gram (5-mer parity) prefilter on gfx950.
+//
+// Replaces db_qgrams_init/findqgrams (src/db.cc:819-842, src/qgram.cc:68-96) and
+// qgram_diff_fast/compareqgramvectors (src/qgram.cc:104-335, src/popcnt.cc:45-62).
+//
+//   * signatures: one wave per amplicon; lane l handles positions l, l+64, ...; the 5-mer
+//     ending at p is read straight out of the 2-bit packed words (a funnel shift across the
+//     word boundary + a 2-bit-group reversal, because the reference shifts new nucleotides in
+//     at the LOW end); parity is accumulated with LDS atomic XOR into a 128-byte per-wave
+//     signature that is then written with one coalesced 128-byte store;
+//   * scan: 8 lanes per candidate, 16 bytes per lane = one coalesced 128-byte gather per
+//     candidate; XOR against the seed signature held in registers, __popcll, 3-step
+//     butterfly, ceil(x / 10).  HBM-bound: 128 B in, 8 B out per (seed, candidate) pair.
+#include "swa_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_qgram_build(const uint64_t * __restrict__ seqs,
+                                                     const uint64_t * __restrict__ seq_off,
+                                                     const uint32_t * __restrict__ seqlen, uint32_t n,
+                                                     uint32_t * __restrict__ sigs /* n x 32 words */) {
+  __shared__ uint32_t sig[4][32];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t a = blockIdx.x * 4 + wave; a < n; a += gridDim.x * 4) {
+    if (lane < 32) { sig[wave][lane] = 0u; }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t * s = seqs + seq_off[a];
+    const uint32_t len = seqlen[a];
+    for (uint32_t p = 4u + (uint32_t)lane; p < len; p += 64u) {
+      // nucleotides p-4 .. p as a 10-bit field, oldest in the low bits
+      const uint32_t first = p - 4u;
+      const uint32_t w = first >> 5;
+      const uint32_t sh = (first & 31u) << 1;
+      uint64_t field = s[w] >> sh;
+      if (sh > 54u) { field |= s[w + 1] << (64u - sh); }        // 5-mer straddles two words
+      const uint32_t f = (uint32_t)field & 1023u;
+      // the reference builds qgram = (qgram << 2) | nt: newest nucleotide in bits 0-1
+      const uint32_t q = ((f & 3u) << 8) | (((f >> 2) & 3u) << 6) | (((f >> 4) & 3u) << 4) |
+                         (((f >> 6) & 3u) << 2) | ((f >> 8) & 3u);
+      atomicXor(&sig[wave][q >> 5], 1u << (q & 31u));            // byte q>>3, bit q&7 (little endian)
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) { sigs[(uint64_t)a * 32u + lane] = sig[wave][lane]; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_qgram_diff(const ulonglong2 * __restrict__ sigs /* n x 8 */,
+                                                    uint64_t seed, uint64_t listlen,
+                                                    const uint64_t * __restrict__ amplist,
+                                                    uint64_t * __restrict__ difflist) {
+  const uint32_t sub = threadIdx.x & 7u;                        // 16-byte chunk of the signature
+  const ulonglong2 mine = sigs[seed * 8u + sub];
+  const uint64_t stride = (uint64_t)gridDim.x * (blockDim.x >> 3);
+  for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); i < listlen; i += stride) {
+    const ulonglong2 other = sigs[amplist[i] * 8u + sub];
+    uint32_t pop = (uint32_t)__popcll(mine.x ^ other.x) + (uint32_t)__popcll(mine.y ^ other.y);
+    pop += __shfl_xor(pop, 1, 8);
+    pop += __shfl_xor(pop, 2, 8);
+    pop += __shfl_xor(pop, 4, 8);
+    if (sub == 0u) { difflist[i] = (pop + 9u) / 10u; }         // qgram.cc:247-252
+  }
+}
+
+}  // namespace
+
+extern "C" int swa_qgram_build(swa_ctx * ctx) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_qgram_build: no database"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  SWA_TRY(swa_reserve(ctx, ctx->d_qgrams, uint64_t(n) * 128u));
+  uint64_t blocks = (uint64_t(n) + 3) / 4;
+  const uint64_t cap = uint64_t(ctx->num_cus) * 8;
+  if (blocks > cap) { blocks = cap; }
+  hipLaunchKernelGGL(k_qgram_build, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->db.seqlen, n, static_cast<uint32_t *>(ctx->d_qgrams.ptr));
+  SWA_HIP(ctx, hipGetLastError());
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->qgram_ready = true;
+  return SWA_OK;
+}
+
+extern "C" int swa_qgram_diff(swa_ctx * ctx, uint64_t seed, uint64_t listlen, const uint64_t * amplist,
+                              uint64_t * difflist) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->qgram_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_qgram_diff: call swa_qgram_build first"); }
+  if (listlen == 0) { return SWA_OK; }
+  if (amplist == nullptr || difflist == nullptr || seed >= ctx->db.n) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_qgram_diff: bad argument");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_a, listlen * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_b, listlen * sizeof(uint64_t)));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_list_a.ptr, amplist, listlen * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  uint64_t blocks = (listlen + 31) / 32;
+  const uint64_t cap = uint64_t(ctx->num_cus) * 8;
+  if (blocks > cap) { blocks = cap; }
+  hipLaunchKernelGGL(k_qgram_diff, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                     static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr), seed, listlen,
+                     static_cast<const uint64_t *>(ctx->d_list_a.ptr), static_cast<uint64_t *>(ctx->d_list_b.ptr));
+  SWA_HIP(ctx, hipGetLastError());
+  SWA_HIP(ctx, hipMemcpyAsync(difflist, ctx->d_list_b.ptr, listlen * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}
+
+extern "C" int swa_qgram_debug_read(swa_ctx * ctx, uint8_t * out, size_t out_bytes) {
+  if (ctx == nullptr || out == nullptr) { return SWA_E_ARG; }
+  if (!ctx->qgram_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_qgram_debug_read: no signatures"); }
+  const size_t bytes = size_t(ctx->db.n) * 128u;
+  if (out_bytes < bytes) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_qgram_debug_read: buffer too small"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_HIP(ctx, hipMemcpyAsync(out, ctx->d_qgrams.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}
