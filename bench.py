@@ -64,14 +64,23 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
             sample = Path(tmp) / "sample.fa"
             subprocess.run([str(gen_tool()), str(sample_n), str(length), str(seed), "1", "0", str(sample)], check=True)
         if ref.exists():
-            threads = min(cores, 256)
-            t0 = time.perf_counter()
-            subprocess.run([str(ref), "-d", "1", "-t", str(threads), "-o", "/dev/null", "-l", "/dev/null", str(sample)],
-                           check=True)
-            dt = time.perf_counter() - t0
+            # the reference scales to about 8-16 threads at 150 bp (its README): try a few thread
+            # counts within the 10-30 s budget and report the best one
+            best = None
+            tried = []
+            for threads in sorted({min(cores, t) for t in (8, 16, 32)}):
+                t0 = time.perf_counter()
+                subprocess.run([str(ref), "-d", "1", "-t", str(threads), "-o", "/dev/null", "-l", "/dev/null",
+                                str(sample)], check=True)
+                dt = time.perf_counter() - t0
+                tried.append(f"-t {threads}: {dt:.2f} s")
+                if best is None or dt < best[1]:
+                    best = (threads, dt)
+            threads, dt = best
             return {"value": sample_n / dt, "unit": "amplicons/s", "cores": threads, "kind": "reference",
-                    "sample": f"reference swarm 3.1.6 -d 1 -t {threads}, whole run (FASTA read + network + clustering "
-                              f"+ output) on {sample_n} x {length} bp synthetic amplicons, {dt:.2f} s wall"}
+                    "sample": f"unmodified reference swarm 3.1.6 (oracle/_ref/swarm) -d 1, whole run (FASTA read + "
+                              f"network + clustering + output) on {sample_n} x {length} bp synthetic amplicons, best "
+                              f"of [{'; '.join(tried)}] on a {cores}-core host"}
         # port: the single-threaded C oracle's network construction (test infrastructure, timed only)
         sys.path.insert(0, str(ROOT / "tests"))
         import support as S
@@ -110,7 +119,7 @@ def main() -> None:
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from swarm_amd import Context, HostDb
+    from swarm_amd import Context, HostDb, sharding
 
     n_total = args.per_gpu * world
     fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n_total}x{args.length}_s{args.seed}.fa"
@@ -137,15 +146,11 @@ def main() -> None:
     ctx.attach_db(t_seqs, t_off, t_len, t_ab, hdb.longest)
     ctx.timing_enable(True)
 
-    first = rank * args.per_gpu
-    count = args.per_gpu
+    parts = sharding.partition_even(n_total, world)
+    first, count = parts[rank]
     cap = 8 * count
     d_offsets = torch.zeros(count + 1, dtype=torch.int64, device=dev)
     d_nb = torch.zeros(cap, dtype=torch.int32, device=dev)
-    if world > 1:
-        g_counts = torch.zeros(world, dtype=torch.int64, device=dev)
-        g_offsets = torch.zeros(world * (count + 1), dtype=torch.int64, device=dev)
-        g_nb = torch.zeros(world * cap, dtype=torch.int32, device=dev)
 
     kernel_ms = []
     hits_seen = [0]
@@ -156,13 +161,9 @@ def main() -> None:
         total = ctx.d1_network_device(d_offsets, d_nb, cap, False, first, count)
         hits_seen[0] = total
         if world > 1:
-            # exchange step named by the north star: all-gather hit counts, then the hit lists
-            # padded to the largest slice, so every rank holds the whole CSR
-            mine = torch.tensor([total], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(g_counts, mine)
-            longest = int(g_counts.max().item())
-            dist.all_gather_into_tensor(g_offsets, d_offsets)
-            dist.all_gather_into_tensor(g_nb[: world * longest].view(world, longest), d_nb[:longest].contiguous())
+            # exchange step named by the north star: all-gather hit counts, then row offsets and
+            # hit lists padded to the largest slice, so every rank holds the whole CSR
+            sharding.allgather_csr(d_offsets, d_nb, total, [c for _, c in parts])
         if record:
             kernel_ms.append(ctx.timing_read()[3])
 

@@ -1,0 +1,88 @@
+"""Multi-GPU sharding of the d=1 path: the database, hash table and Bloom
+filter are replicated on every GPU, the QUERY range [0, n) is cut into contiguous slices (one
+per rank), every rank produces the CSR of its slice, and the slices are exchanged with
+all-gather (RCCL over xGMI on GPUs — backend "nccl" IS RCCL on ROCm —, gloo in the CPU tests).
+
+Everything here is backend-agnostic torch.distributed plumbing on tensors; the per-rank CSR
+comes from swa_d1_network_device on a GPU (bench.py) or from whatever the caller supplies.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_even(n: int, world: int) -> list:
+    """Contiguous (first, count) slices with counts differing by at most one."""
+    base, extra = divmod(n, world)
+    out, first = [], 0
+    for r in range(world):
+        count = base + (1 if r < extra else 0)
+        out.append((first, count))
+        first += count
+    return out
+
+
+def partition_by_length(seqlen: np.ndarray, world: int) -> list:
+    """Contiguous slices balanced by total nucleotides (work per query ~ 7 L probes)."""
+    n = int(seqlen.shape[0])
+    if n == 0:
+        return [(0, 0)] * world
+    csum = np.cumsum(seqlen.astype(np.int64))
+    total = int(csum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r // world
+        cuts.append(int(np.searchsorted(csum, target, side="left")))
+    cuts.append(n)
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
+def allgather_csr(local_offsets: torch.Tensor, local_nb: torch.Tensor, local_total: int, counts: list,
+                  group=None):
+    """Exchange per-rank CSR slices so that every rank holds the whole network.
+
+    local_offsets : int64 [count_r + 1]  row offsets of this rank's slice (starting at 0)
+    local_nb      : int32 [>= local_total] neighbour ids of this rank's slice
+    counts        : per-rank query counts (from partition_*), identical on all ranks
+    Returns (offsets int64 [n + 1], neighbours int32 [total]) on the tensors' device.
+
+    Collectives: one all_gather of the hit counts (8 bytes per rank), one of the row offsets
+    padded to the largest slice, one of the hit lists padded to the largest hit count.
+    """
+    world = dist.get_world_size(group)
+    dev = local_offsets.device
+    mine = torch.tensor([local_total], dtype=torch.int64, device=dev)
+    totals = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(totals, mine, group=group)
+    totals_host = [int(x) for x in totals.tolist()]
+    max_rows = max(counts) + 1
+    max_hits = max(max(totals_host), 1)
+
+    pad_off = torch.zeros(max_rows, dtype=torch.int64, device=dev)
+    pad_off[: local_offsets.numel()] = local_offsets
+    all_off = torch.empty(world * max_rows, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_off, pad_off, group=group)
+
+    pad_nb = torch.zeros(max_hits, dtype=torch.int32, device=dev)
+    pad_nb[:local_total] = local_nb[:local_total]
+    all_nb = torch.empty(world * max_hits, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_nb, pad_nb, group=group)
+
+    n = sum(counts)
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    pieces = []
+    row = 0
+    base = 0
+    for r in range(world):
+        c = counts[r]
+        offsets[row: row + c] = all_off[r * max_rows: r * max_rows + c] + base
+        pieces.append(all_nb[r * max_hits: r * max_hits + totals_host[r]])
+        row += c
+        base += totals_host[r]
+    offsets[n] = base
+    neighbours = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.int32, device=dev)
+    return offsets, neighbours

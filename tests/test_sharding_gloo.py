@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) gloo processes shard the query range, each
+computes the CSR of its slice (here with the oracle standing in for the GPU kernel) and the
+slices are all-gathered by swarm_amd.sharding exactly as bench.py does over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import support as S
+from swarm_amd import sharding
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+    import support as S
+    from swarm_amd import sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    db = S.db_from_fasta(sys.argv[2])
+    parts = sharding.partition_by_length(db.seqlen, world) if sys.argv[3] == "length" else sharding.partition_even(db.n, world)
+    first, count = parts[rank]
+    off, nb, _ = S.oracle_d1_network(db, False, first, count)
+    nb = nb.copy()
+    for i in range(count):
+        nb[int(off[i]):int(off[i + 1])].sort()
+    t_off = torch.from_numpy(off.astype(np.int64))
+    t_nb = torch.from_numpy(np.concatenate([nb, np.zeros(5, dtype=np.uint32)]).view(np.int32))   # capacity > total
+    g_off, g_nb = sharding.allgather_csr(t_off, t_nb, len(nb), [c for _, c in parts])
+    full_off, full_nb, _ = S.oracle_d1_network(db)
+    full_nb = full_nb.copy()
+    for i in range(db.n):
+        full_nb[int(full_off[i]):int(full_off[i + 1])].sort()
+    assert np.array_equal(g_off.numpy().astype(np.uint64), full_off), "offsets differ"
+    assert np.array_equal(g_nb.numpy().view(np.uint32), full_nb), "neighbours differ"
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+''')
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "length"), (3, "length")])
+def test_sharded_network_equals_single(tmp_path, world, mode):
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 3001, 90, 77)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), str(S.ROOT),
+                        str(fa), mode], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == world
+
+
+def test_partitions_cover_range():
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 7, 1000):
+        lens = rng.integers(1, 500, size=n).astype(np.uint32)
+        for world in (1, 2, 3, 8):
+            for parts in (sharding.partition_even(n, world), sharding.partition_by_length(lens, world)):
+                assert len(parts) == world
+                assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+                for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+                    assert f0 + c0 == f1
+    lens = np.full(1000, 150, dtype=np.uint32)
+    assert all(abs(c - 125) <= 1 for _, c in sharding.partition_by_length(lens, 8))
