@@ -148,6 +148,24 @@ int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapopen, uint64_
 int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listlength, const uint64_t * targets,
                   uint64_t * scores, uint64_t * diffs, uint64_t * alignlengths);
 
+/* ---- B3 + B4 fused: one (sub)seed of the d >= 2 greedy loop, pool state in HBM ------
+   Replaces, per step of src/algo.cc:384-602, the host-side candidate list construction
+   (abundance rule + `diffestimate <= radius + d` prune), qgram_diff_fast, the `qdiff <= d`
+   filter, search_do and the `diff <= d` filter.  Requires swa_qgram_build and
+   swa_search_begin.  swa_scan_begin: every amplicon unswarmed.
+   swa_scan_step(seed, lowest_unswarmed, first_generation, radius, ncb, ...):
+     candidates = unswarmed amplicons i >= lowest_unswarmed, i != seed, with
+       (first_generation or est[i] <= radius + d) and (ncb or abundance[i] <= abundance[seed]);
+     first_generation != 0 also marks `seed` as swarmed and stores est[i] = q-gram bound
+       against this seed (src/algo.cc:442);
+     hits = candidates with q-gram bound <= d and alignment diff <= d, returned in ascending
+       id order (= the reference's pool order) with their diffs, and marked swarmed. */
+int swa_scan_begin(swa_ctx * ctx);
+int swa_scan_step(swa_ctx * ctx, uint32_t seed, uint32_t lowest_unswarmed, int first_generation, uint32_t radius,
+                  int no_cluster_breaking, uint32_t * hit_ids, uint32_t * hit_diffs, uint32_t cap, uint32_t * nhits);
+/* out3 = {q-gram comparisons, aligned pairs, reserved} since swa_scan_begin */
+int swa_scan_totals(swa_ctx * ctx, uint64_t * out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,32 @@ int swa_d1_write_seeds(const swa_d1_result * res, const swa_hostdb * db, const c
 int swa_d1_write_network(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
                          const char * path, int usearch_abundance, int64_t append_abundance);
 
+/* -u for d = 1 (src/algod1.cc:849-932); penalties after gcd reduction (18/24/13 by default) */
+int swa_d1_write_uclust(const swa_d1_result * res, const swa_hostdb * db, const char * path, int usearch_abundance,
+                        int64_t append_abundance, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend);
+
+/* ---- d >= 2 host side: the greedy loop of algo_run over the GPU's fused scan step ------- */
+typedef struct swa_dn_result swa_dn_result;
+
+/* Replaces algo_run's clustering loop (src/algo.cc:384-602).  Needs a context with the
+   database resident (swa_db_upload of the same hostdb); runs swa_qgram_build,
+   swa_search_begin, swa_scan_begin itself, then one swa_scan_step per seed / sub-seed.
+   Penalties after the reference's gcd reduction (src/swarm.cc:466-483). */
+int  swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
+                    uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out);
+void swa_dn_result_free(swa_dn_result * res);
+const char * swa_dn_result_error(const swa_dn_result * res);
+/* out3 = {number of swarms, largest swarm, max generations} (src/algo.cc:699-705) */
+void swa_dn_result_summary(const swa_dn_result * res, uint64_t * out3);
+/* writers: -o/-r, -s, -i, -w, -u  (src/algo.cc:122-325, 473-488, 573-589, 608-674) */
+int swa_dn_write_swarms(const swa_dn_result * res, const swa_hostdb * db, const char * path, int mothur,
+                        int usearch_abundance, int64_t append_abundance);
+int swa_dn_write_stats(const swa_dn_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_dn_write_structure(const swa_dn_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_dn_write_seeds(const swa_dn_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_dn_write_uclust(const swa_dn_result * res, const swa_hostdb * db, const char * path, int usearch_abundance,
+                        int64_t append_abundance);
+
 #ifdef __cplusplus
 }
 #endif

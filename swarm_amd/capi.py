@@ -390,3 +390,109 @@ class Context:
         self._check(self.lib.swa_search_do(self.h, int(query), m, _ptr(targets), _ptr(scores), _ptr(diffs),
                                            _ptr(alens)))
         return scores, diffs, alens
+
+
+# ---- d >= 2: host greedy loop over the GPU's fused scan step ---------------------------------
+
+_DN_EXPORTS = ["swa_dn_cluster", "swa_dn_result_free", "swa_dn_result_error", "swa_dn_result_summary",
+               "swa_dn_write_swarms", "swa_dn_write_stats", "swa_dn_write_structure", "swa_dn_write_seeds",
+               "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_totals"]
+EXPORTS.extend(_DN_EXPORTS)
+
+
+def reduced_penalties(match_reward: int = 5, mismatch_penalty: int = 4, gap_open: int = 12, gap_extend: int = 4):
+    """The reference's scoring reduction (src/swarm.cc:466-483): (2m+2p, 2g, m+2e) / gcd -> 18, 24, 13."""
+    from math import gcd
+    mm = 2 * match_reward + 2 * mismatch_penalty
+    go = 2 * gap_open
+    ge = match_reward + 2 * gap_extend
+    f = gcd(gcd(mm, go), ge)
+    return mm // f, go // f, ge // f
+
+
+def _declare_dn(lib) -> None:
+    if getattr(lib, "_dn_declared", False):
+        return
+    lib.swa_dn_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                   C.POINTER(C.c_void_p)]
+    lib.swa_dn_result_free.argtypes = [C.c_void_p]
+    lib.swa_dn_result_free.restype = None
+    lib.swa_dn_result_error.argtypes = [C.c_void_p]
+    lib.swa_dn_result_error.restype = C.c_char_p
+    lib.swa_dn_result_summary.argtypes = [C.c_void_p, u64p]
+    lib.swa_dn_result_summary.restype = None
+    lib.swa_dn_write_swarms.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int64]
+    for fn in (lib.swa_dn_write_stats, lib.swa_dn_write_structure, lib.swa_dn_write_seeds):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.swa_dn_write_uclust.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int64]
+    lib.swa_d1_write_uclust.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint64,
+                                        C.c_uint64]
+    lib.swa_scan_begin.argtypes = [C.c_void_p]
+    lib.swa_scan_step.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_uint32, u32p]
+    lib.swa_scan_totals.argtypes = [C.c_void_p, u64p]
+    lib._dn_declared = True
+
+
+class DnClusters:
+    """d >= 2 clustering: the reference's algo_run loop (src/algo.cc:384-676) with every
+    q-gram / alignment step executed on the GPU (swa_scan_step)."""
+
+    def __init__(self, ctx: "Context", hdb: HostDb, differences: int, no_cluster_breaking: bool = False,
+                 penalties=None):
+        self.lib = load_library()
+        _declare_dn(self.lib)
+        self.hdb = hdb
+        self.ctx = ctx
+        mm, go, ge = penalties or reduced_penalties()
+        h = C.c_void_p()
+        rc = self.lib.swa_dn_cluster(ctx.h, hdb.h, differences, int(no_cluster_breaking), mm, go, ge, C.byref(h))
+        self.h = h
+        if rc != SWA_OK:
+            raise SwaError(rc, self.lib.swa_dn_result_error(h).decode() if h else "swa_dn_cluster failed")
+
+    def summary(self) -> dict:
+        out = np.zeros(3, dtype=np.uint64)
+        self.lib.swa_dn_result_summary(self.h, _p64(out))
+        return {"swarms": int(out[0]), "largest": int(out[1]), "maxgen": int(out[2])}
+
+    def scan_totals(self) -> dict:
+        out = np.zeros(3, dtype=np.uint64)
+        self.ctx._check(self.lib.swa_scan_totals(self.ctx.h, _p64(out)))
+        return {"qgram_comparisons": int(out[0]), "aligned_pairs": int(out[1])}
+
+    def write_swarms(self, path, mothur=False, usearch=False, append_abundance=0) -> None:
+        assert self.lib.swa_dn_write_swarms(self.h, self.hdb.h, str(path).encode(), int(mothur), int(usearch),
+                                            append_abundance) == SWA_OK
+
+    def write_stats(self, path, usearch=False) -> None:
+        assert self.lib.swa_dn_write_stats(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_structure(self, path, usearch=False) -> None:
+        assert self.lib.swa_dn_write_structure(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_seeds(self, path, usearch=False) -> None:
+        assert self.lib.swa_dn_write_seeds(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_uclust(self, path, usearch=False, append_abundance=0) -> None:
+        assert self.lib.swa_dn_write_uclust(self.h, self.hdb.h, str(path).encode(), int(usearch),
+                                            append_abundance) == SWA_OK
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.swa_dn_result_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def d1_write_uclust(clusters: "D1Clusters", path, usearch=False, append_abundance=0, penalties=None) -> None:
+    lib = load_library()
+    _declare_dn(lib)
+    mm, go, ge = penalties or reduced_penalties()
+    assert lib.swa_d1_write_uclust(clusters.h, clusters.hdb.h, str(path).encode(), int(usearch), append_abundance,
+                                   mm, go, ge) == SWA_OK

@@ -35,11 +35,12 @@ struct AlignArgs {
   const uint64_t * seq_off;
   const uint32_t * seqlen;
   uint32_t query;
-  uint32_t ntargets;
-  const uint64_t * targets;
-  uint64_t * scores;        // may be null
-  uint64_t * diffs;
-  uint64_t * alnlens;       // may be null
+  uint32_t ntargets;          // upper bound; the real count is *ntargets_dev when that is set
+  const uint32_t * ntargets_dev;
+  const uint32_t * targets;
+  uint32_t * scores;        // may be null
+  uint32_t * diffs;
+  uint32_t * alnlens;       // may be null
   uint32_t mismatch, gapopen, gapextend;
   uint32_t sat;             // 255 or 65535
   int W;                    // band half-width
@@ -75,8 +76,9 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
   const uint32_t go = a.gapopen, ge = a.gapextend, mm = a.mismatch;
   constexpr uint32_t kBigCount = 0xFFFFu;
 
-  for (uint32_t pair = blockIdx.x * kGroups + group; pair < a.ntargets; pair += gridDim.x * kGroups) {
-    const uint32_t target = (uint32_t)a.targets[pair];
+  const uint32_t ntargets = a.ntargets_dev != nullptr ? min(*a.ntargets_dev, a.ntargets) : a.ntargets;
+  for (uint32_t pair = blockIdx.x * kGroups + group; pair < ntargets; pair += gridDim.x * kGroups) {
+    const uint32_t target = a.targets[pair];
     const uint32_t dl = a.seqlen[target];
     {
       const uint64_t * gd = a.seqs + a.seq_off[target];
@@ -188,8 +190,9 @@ __global__ __launch_bounds__(256) void k_align_generic(const AlignArgs a, uint32
   uint32_t * pAI = pAM + (size_t)qcap * nthreads;
   uint32_t * pLM = pAI + (size_t)qcap * nthreads;
   uint32_t * pLI = pLM + (size_t)qcap * nthreads;
-  for (uint32_t pair = tid; pair < a.ntargets; pair += nthreads) {
-    const uint32_t target = (uint32_t)a.targets[pair];
+  const uint32_t ntargets = a.ntargets_dev != nullptr ? min(*a.ntargets_dev, a.ntargets) : a.ntargets;
+  for (uint32_t pair = tid; pair < ntargets; pair += nthreads) {
+    const uint32_t target = a.targets[pair];
     const uint32_t dl = a.seqlen[target];
     const uint64_t * dw = a.seqs + a.seq_off[target];
     const int delta = (int)ql - (int)dl;
@@ -271,15 +274,26 @@ extern "C" int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapop
   return SWA_OK;
 }
 
-extern "C" int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listlength, const uint64_t * targets,
-                             uint64_t * scores, uint64_t * diffs, uint64_t * alignlengths) {
-  if (ctx == nullptr) { return SWA_E_ARG; }
-  if (!ctx->search_ready || ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_search_do: call swa_search_begin first"); }
-  if (listlength == 0) { return SWA_OK; }
-  if (targets == nullptr || diffs == nullptr || query_no >= ctx->db.n || listlength > 0xFFFFFFFFull) {
-    return swa_fail_msg(ctx, SWA_E_ARG, "swa_search_do: bad argument");
+namespace {
+
+__global__ __launch_bounds__(256) void k_narrow(const uint64_t * __restrict__ in, uint32_t * __restrict__ out, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    out[i] = (uint32_t)in[i];
   }
-  SWA_HIP(ctx, hipSetDevice(ctx->device));
+}
+__global__ __launch_bounds__(256) void k_widen(const uint32_t * __restrict__ in, uint64_t * __restrict__ out, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    out[i] = in[i];
+  }
+}
+
+}  // namespace
+
+// Enqueue the alignment of `query` against d_targets[0 .. count) on the context's stream.
+// count = *d_count (device) when d_count != nullptr, bounded by max_count; all pointers are
+// device memory.  Shared by swa_search_do and the fused scan (scan.hip).
+int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_targets, const uint32_t * d_count,
+                     uint32_t max_count, uint32_t * d_diffs, uint32_t * d_scores, uint32_t * d_alnlens) {
   const uint64_t mm = ctx->pen_mismatch, go = ctx->pen_gapopen, ge = ctx->pen_gapextend, d = ctx->resolution;
   // 8- or 16-bit arithmetic exactly as set_bit_mode decides (src/algo.cc:96-120)
   const uint64_t diff_saturation = std::min<uint64_t>(255 / mm, 255 / (go + ge));
@@ -289,31 +303,27 @@ extern "C" int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listleng
   const bool generic = 2 * W64 + 1 > 64;
   AlignArgs a{};
   a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen;
-  a.query = (uint32_t)query_no;
-  a.ntargets = (uint32_t)listlength;
+  a.query = query;
+  a.ntargets = max_count;
+  a.ntargets_dev = d_count;
+  a.targets = d_targets;
+  a.diffs = d_diffs; a.scores = d_scores; a.alnlens = d_alnlens;
   a.mismatch = (uint32_t)mm; a.gapopen = (uint32_t)go; a.gapextend = (uint32_t)ge;
   a.sat = sat;
   a.W = (int)W64;
   a.maxwords = ((ctx->db.longest + 31u) >> 5) + 1u;
-  SWA_TRY(swa_reserve(ctx, ctx->d_list_a, listlength * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_list_b, listlength * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_list_c, listlength * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_list_d, listlength * sizeof(uint64_t)));
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_list_a.ptr, targets, listlength * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  a.targets = static_cast<const uint64_t *>(ctx->d_list_a.ptr);
-  a.diffs = static_cast<uint64_t *>(ctx->d_list_b.ptr);
-  a.scores = scores != nullptr ? static_cast<uint64_t *>(ctx->d_list_c.ptr) : nullptr;
-  a.alnlens = alignlengths != nullptr ? static_cast<uint64_t *>(ctx->d_list_d.ptr) : nullptr;
   const bool wide = 2 * W64 + 1 > 32;
   const int groups = wide ? 4 : 8;
-  uint64_t blocks = (listlength + groups - 1) / groups;
+  uint64_t blocks = ((uint64_t)max_count + groups - 1) / groups;
   const uint64_t cap = uint64_t(ctx->num_cus) * 8;
   if (blocks > cap) { blocks = cap; }
+  if (blocks < 1) { blocks = 1; }
   const size_t lds = sizeof(uint64_t) * (size_t)a.maxwords * (groups + 1);
   if (generic) {
     a.W = W64 > 0x3FFFFFFF ? 0x3FFFFFFF : (int)W64;
     const uint32_t qcap = ctx->db.longest + 1u;
-    uint64_t nthreads = listlength < 65536 ? ((listlength + 63) / 64) * 64 : 65536;
+    uint64_t nthreads = max_count < 65536 ? (((uint64_t)max_count + 63) / 64) * 64 : 65536;
+    if (nthreads < 64) { nthreads = 64; }
     while (nthreads > 64 && nthreads * 6ull * qcap * sizeof(uint32_t) > (2ull << 30)) { nthreads /= 2; }
     SWA_TRY(swa_reserve(ctx, ctx->d_queue, nthreads * 6ull * qcap * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_align_generic, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, a,
@@ -321,13 +331,38 @@ extern "C" int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listleng
   } else if (wide) { hipLaunchKernelGGL(k_align<64>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
   else { hipLaunchKernelGGL(k_align<32>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
   SWA_HIP(ctx, hipGetLastError());
-  SWA_HIP(ctx, hipMemcpyAsync(diffs, ctx->d_list_b.ptr, listlength * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  if (scores != nullptr) {
-    SWA_HIP(ctx, hipMemcpyAsync(scores, ctx->d_list_c.ptr, listlength * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  return SWA_OK;
+}
+
+extern "C" int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listlength, const uint64_t * targets,
+                             uint64_t * scores, uint64_t * diffs, uint64_t * alignlengths) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->search_ready || ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_search_do: call swa_search_begin first"); }
+  if (listlength == 0) { return SWA_OK; }
+  if (targets == nullptr || diffs == nullptr || query_no >= ctx->db.n || listlength > 0xFFFFFFFFull) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_search_do: bad argument");
   }
-  if (alignlengths != nullptr) {
-    SWA_HIP(ctx, hipMemcpyAsync(alignlengths, ctx->d_list_d.ptr, listlength * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  // staging: [a] u64 in/out, [b] u32 targets, [c] u32 diffs | scores | alnlens
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_a, listlength * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_b, listlength * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_c, 3 * listlength * sizeof(uint32_t)));
+  auto * d64 = static_cast<uint64_t *>(ctx->d_list_a.ptr);
+  auto * t32 = static_cast<uint32_t *>(ctx->d_list_b.ptr);
+  auto * r32 = static_cast<uint32_t *>(ctx->d_list_c.ptr);
+  unsigned cb = (unsigned)std::min<uint64_t>((listlength + 255) / 256, uint64_t(ctx->num_cus) * 8);
+  SWA_HIP(ctx, hipMemcpyAsync(d64, targets, listlength * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_narrow, dim3(cb), dim3(256), 0, ctx->stream, d64, t32, listlength);
+  SWA_TRY(swa_align_launch(ctx, (uint32_t)query_no, t32, nullptr, (uint32_t)listlength, r32,
+                           scores != nullptr ? r32 + listlength : nullptr,
+                           alignlengths != nullptr ? r32 + 2 * listlength : nullptr));
+  uint64_t * outs[3] = {diffs, scores, alignlengths};
+  for (int k = 0; k < 3; ++k) {
+    if (outs[k] == nullptr) { continue; }
+    hipLaunchKernelGGL(k_widen, dim3(cb), dim3(256), 0, ctx->stream, r32 + k * listlength, d64, listlength);
+    SWA_HIP(ctx, hipMemcpyAsync(outs[k], d64, listlength * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   }
+  SWA_HIP(ctx, hipGetLastError());
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SWA_OK;
 }

@@ -73,7 +73,8 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_stats, &ctx->d_edges, &ctx->d_counts, &ctx->d_cursor, &ctx->d_scan_tmp,
                        &ctx->d_offsets_tmp, &ctx->d_nb_tmp, &ctx->d_qgrams, &ctx->d_list_a, &ctx->d_list_b,
                        &ctx->d_list_c, &ctx->d_list_d, &ctx->d_light, &ctx->d_graft, &ctx->d_bloomflex,
-                       &ctx->d_fpatterns, &ctx->d_queue, &ctx->d_fcounters}) {
+                       &ctx->d_fpatterns, &ctx->d_queue, &ctx->d_fcounters, &ctx->d_scan_est, &ctx->d_scan_swarmed,
+                       &ctx->d_scan_targets, &ctx->d_scan_diffs, &ctx->d_scan_hits, &ctx->d_scan_counters}) {
     swa_release(*b);
   }
   if (ctx->ev_ready) { for (auto & e : ctx->ev) { (void)hipEventDestroy(e); } }
@@ -127,6 +128,7 @@ static int check_view(swa_ctx * ctx, const swa_db_view * v) {
 static void invalidate(swa_ctx * ctx) {
   ctx->d1_ready = false;
   ctx->qgram_ready = false;
+  ctx->scan_ready = false;
 }
 
 extern "C" int swa_db_upload(swa_ctx * ctx, const swa_db_view * h) {

@@ -7,6 +7,7 @@
 // (the reference threads a linked list through ampinfo[].next); a grafted light swarm
 // is a range appended to its heavy swarm's piece list.
 #include "hostdb.h"
+#include "nw_host.h"
 
 #include <algorithm>
 #include <cinttypes>
@@ -328,6 +329,42 @@ extern "C" int swa_d1_write_network(const swa_hostdb * db, const uint64_t * offs
       print_id(fp, db, j, usearch != 0, append_abundance);
       std::fputc('\n', fp);
     }
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -u  (src/algod1.cc:849-932): members in swarm order, each aligned against the seed
+extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch,
+                                   int64_t append_abundance, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  swa_nw_scratch scratch;
+  uint32_t cluster_no = 0;
+  for (const auto & s : r->swarms) {
+    if (s.attached) { continue; }
+    std::fprintf(fp, "C\t%u\t%u\t*\t*\t*\t*\t*\t", cluster_no, s.size);
+    print_id(fp, db, s.seed, usearch != 0, append_abundance);
+    std::fprintf(fp, "\t*\n");
+    std::fprintf(fp, "S\t%u\t%u\t*\t*\t*\t*\t*\t", cluster_no, db->seqlen[s.seed]);
+    print_id(fp, db, s.seed, usearch != 0, append_abundance);
+    std::fprintf(fp, "\t*\n");
+    for_each_member(r, s, [&](uint32_t a) {
+      if (a == s.seed) { return; }
+      const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[a], db->seqlen[a],
+                                           db->seqs.data() + db->seq_off[s.seed], db->seqlen[s.seed], mismatch, gapopen,
+                                           gapextend, scratch);
+      const double columns = (double)scratch.ops.size();
+      const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
+      const std::string cigar = swa_cigar(scratch.ops);
+      std::fprintf(fp, "H\t%u\t%u\t%.1f\t+\t0\t0\t%s\t", cluster_no, db->seqlen[a], percentid,
+                   nwdiff > 0 ? cigar.c_str() : "=");
+      print_id(fp, db, a, usearch != 0, append_abundance);
+      std::fputc('\t', fp);
+      print_id(fp, db, s.seed, usearch != 0, append_abundance);
+      std::fputc('\n', fp);
+    });
+    ++cluster_no;
   }
   close_out(fp);
   return SWA_OK;

@@ -1,0 +1,279 @@
+// cluster_dn.cpp — host side of the d >= 2 path: the greedy agglomeration of algo_run
+// (src/algo.cc:384-676) driven by the GPU's fused scan step (swa_scan_step), plus writers.
+//
+// What stays on the host is exactly the sequential, order-defining part: which amplicon seeds
+// next, where an accepted hit is queued (generation, then id: find_correct_position_in_list,
+// src/algo.cc:205-219), and the per-swarm statistics.  The reference keeps one pool array and
+// rotates accepted hits into a "swarmed" prefix; the unswarmed remainder always stays in
+// ascending id order, so here the pool is just a per-amplicon flag on the GPU and each swarm
+// is a small queue on the host.  Outputs are byte-identical (-o -r -s -i -w -u).
+#include "hostdb.h"
+#include "nw_host.h"
+
+#include <algorithm>
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct swa_dn_result {
+  struct Member { uint32_t id, generation, radius; };
+  struct Swarm {
+    uint32_t begin = 0, end = 0;          // members = order[begin, end), seed first
+    uint64_t mass = 0;
+    uint32_t singletons = 0, maxgen = 1, maxradius = 0;
+    uint32_t link_begin = 0, link_end = 0;   // this swarm's accepted pairs inside links[]
+  };
+  struct Link { uint32_t parent, child, diff, swarm, generation; };
+  std::vector<Member> order;
+  std::vector<Swarm> swarms;
+  std::vector<Link> links;                // the -i lines, in acceptance order
+  uint64_t largest = 0, maxgenerations = 0;
+  int64_t differences = 0;
+  uint64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13;
+  std::string error;
+};
+
+namespace {
+
+inline const char * hdr(const swa_hostdb * db, uint32_t i) { return db->headers.data() + db->hdr_off[i]; }
+inline int hdrlen(const swa_hostdb * db, uint32_t i) { return (int)(db->hdr_off[i + 1] - db->hdr_off[i] - 1); }
+
+void print_id(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch, int64_t append_abundance) {
+  if (append_abundance != 0 && db->ab_start[i] == db->ab_end[i]) {
+    if (usearch) { std::fprintf(fp, "%.*s;size=%" PRIu64 ";", hdrlen(db, i), hdr(db, i), db->abundance[i]); }
+    else { std::fprintf(fp, "%.*s_%" PRIu64, hdrlen(db, i), hdr(db, i), db->abundance[i]); }
+  } else {
+    std::fwrite(hdr(db, i), 1, (size_t)hdrlen(db, i), fp);
+  }
+}
+
+void print_id_noabundance(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch) {
+  const int s = db->ab_start[i], e = db->ab_end[i], len = hdrlen(db, i);
+  if (s < e) {
+    std::fprintf(fp, "%.*s", s, hdr(db, i));
+    if (usearch) {
+      if (s > 0 && e < len) { std::fputc(';', fp); }
+      std::fprintf(fp, "%.*s", len - e, hdr(db, i) + e);
+    }
+  } else {
+    std::fwrite(hdr(db, i), 1, (size_t)len, fp);
+  }
+}
+
+void print_id_new_abundance(FILE * fp, const swa_hostdb * db, uint32_t i, uint64_t abundance, bool usearch) {
+  if (usearch) {
+    std::fprintf(fp, "%.*s%ssize=%" PRIu64 ";%.*s", db->ab_start[i], hdr(db, i), db->ab_start[i] > 0 ? ";" : "",
+                 abundance, hdrlen(db, i) - db->ab_end[i], hdr(db, i) + db->ab_end[i]);
+  } else {
+    std::fprintf(fp, "%.*s_%" PRIu64, db->ab_start[i], hdr(db, i), abundance);
+  }
+}
+
+FILE * open_out(const char * path) {
+  if (path == nullptr) { return nullptr; }
+  if (std::strcmp(path, "-") == 0) { return stdout; }
+  return std::fopen(path, "w");
+}
+void close_out(FILE * fp) { if (fp == stdout) { std::fflush(fp); } else if (fp != nullptr) { std::fclose(fp); } }
+
+}  // namespace
+
+extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
+                              uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out) {
+  if (ctx == nullptr || db == nullptr || out == nullptr || differences < 2) { return SWA_E_ARG; }
+  auto * r = new swa_dn_result();
+  *out = r;
+  r->differences = differences;
+  r->pen_mismatch = mismatch; r->pen_gapopen = gapopen; r->pen_gapextend = gapextend;
+  const uint32_t n = db->n;
+  if (n == 0) { return SWA_OK; }
+  int rc = swa_qgram_build(ctx);
+  if (rc == SWA_OK) { rc = swa_search_begin(ctx, mismatch, gapopen, gapextend, (uint64_t)differences); }
+  if (rc == SWA_OK) { rc = swa_scan_begin(ctx); }
+  if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+
+  std::vector<uint8_t> swarmed(n, 0);
+  std::vector<uint32_t> hit_ids(n), hit_diffs(n);
+  std::vector<swa_dn_result::Member> queue;
+  r->order.reserve(n);
+  for (uint32_t seed = 0; seed < n; ++seed) {
+    if (swarmed[seed]) { continue; }                       // next initial seed = lowest unswarmed id
+    const uint32_t swarm_no = (uint32_t)r->swarms.size() + 1;   // 1-based like the reference
+    swa_dn_result::Swarm sw;
+    sw.link_begin = (uint32_t)r->links.size();
+    swarmed[seed] = 1;
+    queue.clear();
+    queue.push_back({seed, 0, 0});
+    uint32_t nh = 0;
+    rc = swa_scan_step(ctx, seed, seed + 1, 1, 0, no_cluster_breaking, hit_ids.data(), hit_diffs.data(), n, &nh);
+    if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+    for (uint32_t k = 0; k < nh; ++k) {                    // first generation, pool (= id) order
+      swarmed[hit_ids[k]] = 1;
+      queue.push_back({hit_ids[k], 1, hit_diffs[k]});
+      sw.maxradius = std::max(sw.maxradius, hit_diffs[k]);
+      r->links.push_back({seed, hit_ids[k], hit_diffs[k], swarm_no, 1});
+    }
+    size_t next = 1;                                       // queue[next..) = swarmed but not yet seeded
+    while (next < queue.size()) {
+      const swa_dn_result::Member sub = queue[next];
+      ++next;
+      rc = swa_scan_step(ctx, sub.id, seed + 1, 0, sub.radius, no_cluster_breaking, hit_ids.data(), hit_diffs.data(),
+                         n, &nh);
+      if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+      for (uint32_t k = 0; k < nh; ++k) {
+        const uint32_t id = hit_ids[k];
+        swarmed[id] = 1;
+        // keep the unseeded part of the queue ordered by generation, then id (algo.cc:205-219)
+        size_t pos = queue.size();
+        while (pos > next && queue[pos - 1].id > id && queue[pos - 1].generation > sub.generation) { --pos; }
+        const swa_dn_result::Member m{id, sub.generation + 1, sub.radius + hit_diffs[k]};
+        queue.insert(queue.begin() + (std::ptrdiff_t)pos, m);
+        sw.maxgen = std::max(sw.maxgen, m.generation);
+        sw.maxradius = std::max(sw.maxradius, m.radius);
+        r->links.push_back({sub.id, id, hit_diffs[k], swarm_no, m.generation});
+      }
+    }
+    sw.link_end = (uint32_t)r->links.size();
+    sw.begin = (uint32_t)r->order.size();
+    for (const auto & m : queue) {
+      r->order.push_back(m);
+      sw.mass += db->abundance[m.id];
+      if (db->abundance[m.id] == 1) { ++sw.singletons; }
+    }
+    sw.end = (uint32_t)r->order.size();
+    r->largest = std::max<uint64_t>(r->largest, sw.end - sw.begin);
+    r->maxgenerations = std::max<uint64_t>(r->maxgenerations, sw.maxgen);
+    r->swarms.push_back(sw);
+  }
+  return SWA_OK;
+}
+
+extern "C" void swa_dn_result_free(swa_dn_result * r) { delete r; }
+extern "C" const char * swa_dn_result_error(const swa_dn_result * r) { return r != nullptr ? r->error.c_str() : ""; }
+
+// {number of swarms, largest swarm, max generations} — the log's summary (src/algo.cc:699-705)
+extern "C" void swa_dn_result_summary(const swa_dn_result * r, uint64_t * out3) {
+  out3[0] = r->swarms.size();
+  out3[1] = r->largest;
+  out3[2] = r->maxgenerations;
+}
+
+// -o / -r  (src/algo.cc:258-325)
+extern "C" int swa_dn_write_swarms(const swa_dn_result * r, const swa_hostdb * db, const char * path, int mothur,
+                                   int usearch, int64_t append_abundance) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  if (!r->order.empty()) {
+    if (mothur) { std::fprintf(fp, "swarm_%" PRId64 "\t%zu\t", r->differences, r->swarms.size()); }
+    bool first_swarm = true;
+    for (const auto & s : r->swarms) {
+      if (!first_swarm) { std::fputc(mothur ? '\t' : '\n', fp); }
+      first_swarm = false;
+      for (uint32_t k = s.begin; k < s.end; ++k) {
+        if (k != s.begin) { std::fputc(mothur ? ',' : ' ', fp); }
+        print_id(fp, db, r->order[k].id, usearch != 0, append_abundance);
+      }
+    }
+    std::fputc('\n', fp);
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -s  (src/algo.cc:662-674)
+extern "C" int swa_dn_write_stats(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  for (const auto & s : r->swarms) {
+    const uint32_t seed = r->order[s.begin].id;
+    std::fprintf(fp, "%" PRIu64 "\t%" PRIu64 "\t", (uint64_t)(s.end - s.begin), s.mass);
+    print_id_noabundance(fp, db, seed, usearch != 0);
+    std::fprintf(fp, "\t%" PRIu64 "\t%" PRIu64 "\t%" PRIu64 "\t%" PRIu64 "\n", db->abundance[seed],
+                 (uint64_t)s.singletons, (uint64_t)s.maxgen, (uint64_t)s.maxradius);
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -i  (src/algo.cc:473-488, 573-589): one line per accepted pair, in acceptance order
+extern "C" int swa_dn_write_structure(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  for (const auto & l : r->links) {
+    print_id_noabundance(fp, db, l.parent, usearch != 0);
+    std::fputc('\t', fp);
+    print_id_noabundance(fp, db, l.child, usearch != 0);
+    std::fprintf(fp, "\t%u\t%u\t%u\n", l.diff, l.swarm, l.generation);
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -w  (src/algo.cc:122-203).  Seeds sorted by decreasing mass; ties: the reference's
+// comparator is `std::strcmp(lhs, rhs) == -1` (not `< 0`), which is libc-dependent and not a
+// strict weak order — reproduced as is, on the same libc/libstdc++, for byte-identical output.
+extern "C" int swa_dn_write_seeds(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  struct Seed { uint64_t mass; uint32_t seed; };
+  std::vector<Seed> seeds;
+  for (const auto & s : r->swarms) { seeds.push_back({s.mass, r->order[s.begin].id}); }
+  std::sort(seeds.begin(), seeds.end(), [&](const Seed & a, const Seed & b) {
+    if (a.mass > b.mass) { return true; }
+    if (a.mass < b.mass) { return false; }
+    return std::strcmp(hdr(db, a.seed), hdr(db, b.seed)) == -1;
+  });
+  std::string line;
+  for (const auto & s : seeds) {
+    std::fputc('>', fp);
+    print_id_new_abundance(fp, db, s.seed, s.mass, usearch != 0);
+    std::fputc('\n', fp);
+    const uint64_t * w = db->seqs.data() + db->seq_off[s.seed];
+    const uint32_t len = db->seqlen[s.seed];
+    line.resize(len);
+    for (uint32_t p = 0; p < len; ++p) { line[p] = "ACGT"[(w[p >> 5] >> ((p & 31u) << 1)) & 3u]; }
+    std::fwrite(line.data(), 1, len, fp);
+    std::fputc('\n', fp);
+  }
+  close_out(fp);
+  return SWA_OK;
+}
+
+// -u  (src/algo.cc:608-659): every member, in the order it was accepted (the reference's
+// hits[] array), aligned against its swarm's seed with the scalar aligner
+extern "C" int swa_dn_write_uclust(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch,
+                                   int64_t append_abundance) {
+  FILE * fp = open_out(path);
+  if (fp == nullptr) { return SWA_E_ARG; }
+  swa_nw_scratch scratch;
+  uint32_t cluster_no = 0;
+  for (const auto & s : r->swarms) {
+    const uint32_t seed = r->order[s.begin].id;
+    std::fprintf(fp, "C\t%u\t%" PRIu64 "\t*\t*\t*\t*\t*\t", cluster_no, (uint64_t)(s.end - s.begin));
+    print_id(fp, db, seed, usearch != 0, append_abundance);
+    std::fprintf(fp, "\t*\n");
+    std::fprintf(fp, "S\t%u\t%u\t*\t*\t*\t*\t*\t", cluster_no, db->seqlen[seed]);
+    print_id(fp, db, seed, usearch != 0, append_abundance);
+    std::fprintf(fp, "\t*\n");
+    for (uint32_t k = s.link_begin; k < s.link_end; ++k) {
+      const uint32_t hit = r->links[k].child;
+      const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[hit], db->seqlen[hit],
+                                           db->seqs.data() + db->seq_off[seed], db->seqlen[seed], r->pen_mismatch,
+                                           r->pen_gapopen, r->pen_gapextend, scratch);
+      const double columns = (double)scratch.ops.size();
+      const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
+      const std::string cigar = swa_cigar(scratch.ops);
+      std::fprintf(fp, "H\t%u\t%u\t%.1f\t+\t0\t0\t%s\t", cluster_no, db->seqlen[hit], percentid,
+                   nwdiff > 0 ? cigar.c_str() : "=");
+      print_id(fp, db, hit, usearch != 0, append_abundance);
+      std::fputc('\t', fp);
+      print_id(fp, db, seed, usearch != 0, append_abundance);
+      std::fputc('\n', fp);
+    }
+    ++cluster_no;
+  }
+  close_out(fp);
+  return SWA_OK;
+}

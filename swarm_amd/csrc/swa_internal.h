@@ -62,6 +62,12 @@ struct swa_ctx {
   uint64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13, resolution = 1;
   bool search_ready = false;
 
+  // fused d >= 2 scan state (scan.hip)
+  bool scan_ready = false;
+  swa_dbuf d_scan_est, d_scan_swarmed, d_scan_targets, d_scan_diffs, d_scan_hits, d_scan_counters;
+  std::vector<uint32_t> scan_host;
+  std::vector<uint64_t> scan_sorted;
+
   // fastidious state
   swa_dbuf d_light, d_graft, d_bloomflex, d_fpatterns, d_queue, d_fcounters;
 };

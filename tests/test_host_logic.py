@@ -134,3 +134,12 @@ def test_fastidious_outputs_byte_identical(tmp_path, name, boundary, bits):
     after = cl.summary()
     tail = log.split("Made")[1]
     assert f"Number of swarms:  {after['swarms']}\n" in tail and f"Largest swarm:     {after['largest']}\n" in tail
+
+
+def test_d1_uclust_byte_identical(tmp_path):
+    from swarm_amd import d1_write_uclust
+    hdb, db, cl = _cluster("d1_uclust")
+    d1_write_uclust(cl, tmp_path / "u")
+    assert filecmp.cmp(tmp_path / "u", G / "d1_uclust.u", shallow=False)
+    cl.write_swarms(tmp_path / "o")
+    assert filecmp.cmp(tmp_path / "o", G / "d1_uclust.o", shallow=False)
