@@ -1,0 +1,405 @@
+// main.cpp — `swarm` command-line front end over the C ABI (drop-in for the reference CLI:
+// same options, same FASTA input, same output files, same log lines; src/swarm.cc:96-124,
+// 269-463, 486-630).  Everything compute-heavy goes through libswarm_amd.so to the GPU; the
+// greedy clustering and the writers are the host code in cluster_d1.cpp / cluster_dn.cpp.
+//
+//   d = 1      swa_d1_index_build + swa_d1_network -> swa_d1_cluster [-> swa_d1_fastidious -> graft]
+//   d >= 2     swa_dn_cluster (one swa_scan_step per seed / sub-seed)
+//   d = 0      dereplication is outside this build's scope: refused with a message.
+//
+// Environment (no new flags, to stay drop-in): SWARM_AMD_DEVICE = HIP device ordinal (default 0).
+#include "../../../include/swarm_amd.h"
+#include "../../../include/swarm_amd_host.h"
+
+#include <getopt.h>
+#include <sys/resource.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Options {
+  int64_t threads = 1, bloom_bits = 16, differences = 1, mismatch_penalty = 4, match_reward = 5;
+  int64_t gap_open = 12, gap_extend = 4, ceiling = 0, append_abundance = 0, boundary = 3;
+  bool help = false, version = false, fastidious = false, usearch = false, mothur = false, no_break = false,
+       disable_sse3 = false;
+  std::string input = "-", network, structure, seeds, stats, uclust, output = "-", log;
+  int64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13;
+  bool used[26] = {};
+};
+
+FILE * g_log = stderr;
+
+[[noreturn]] void die(const std::string & msg) {
+  std::fprintf(stderr, "\nError: %s\n", msg.c_str());
+  std::exit(EXIT_FAILURE);
+}
+
+[[noreturn]] void die_raw(const std::string & text) {       // text already carries "\nError: ..."
+  std::fputs(text.c_str(), stderr);
+  if (text.empty() || text.back() != '\n') { std::fputc('\n', stderr); }
+  std::exit(EXIT_FAILURE);
+}
+
+const char * kVersionText =
+    "Swarm 3.1.6 interface — swarm-amd (MI355X / gfx950 neighbour-finding back end)\n"
+    "Drop-in for https://github.com/torognes/swarm: same options, input and output formats.\n\n";
+
+const char * kUsageText =
+    "Usage: swarm [OPTIONS] [FASTAFILE]\n\n"
+    "General options:\n"
+    " -h, --help                          display this help and exit\n"
+    " -t, --threads INTEGER               accepted for compatibility (the GPU does the work)\n"
+    " -v, --version                       display version information and exit\n\n"
+    "Clustering options:\n"
+    " -d, --differences INTEGER           resolution (1)\n"
+    " -n, --no-otu-breaking               never break clusters (not recommended!)\n\n"
+    "Fastidious options (only when d = 1):\n"
+    " -b, --boundary INTEGER              min mass of large clusters (3)\n"
+    " -c, --ceiling INTEGER               max memory in MB for Bloom filter (unlim.)\n"
+    " -f, --fastidious                    link nearby low-abundance swarms\n"
+    " -y, --bloom-bits INTEGER            bits used per Bloom filter entry (16)\n\n"
+    "Input/output options:\n"
+    " -a, --append-abundance INTEGER      value to use when abundance is missing\n"
+    " -i, --internal-structure FILENAME   write internal cluster structure to file\n"
+    " -j, --network-file FILENAME         dump sequence network to file\n"
+    " -l, --log FILENAME                  log to file, not to stderr\n"
+    " -o, --output-file FILENAME          output result to file (stdout)\n"
+    " -r, --mothur                        output using mothur-like format\n"
+    " -s, --statistics-file FILENAME      dump cluster statistics to file\n"
+    " -u, --uclust-file FILENAME          output using UCLUST-like format to file\n"
+    " -w, --seeds FILENAME                write cluster representatives to FASTA file\n"
+    " -z, --usearch-abundance             abundance annotation in usearch style\n\n"
+    "Pairwise alignment advanced options (only when d > 1):\n"
+    " -m, --match-reward INTEGER          reward for nucleotide match (5)\n"
+    " -p, --mismatch-penalty INTEGER      penalty for nucleotide mismatch (4)\n"
+    " -g, --gap-opening-penalty INTEGER   gap open penalty (12)\n"
+    " -e, --gap-extension-penalty INTEGER gap extension penalty (4)\n"
+    " -x, --disable-sse3                  accepted for compatibility (no effect on the GPU)\n\n";
+
+int64_t number(const char * text, const char * option) {
+  char * end = nullptr;
+  const int64_t v = std::strtol(text, &end, 10);
+  if (*end != '\0') {
+    die(std::string("Invalid numeric argument for option ") + option + ".\n\n"
+        "Frequent causes are:\n"
+        " - a missing space between an argument and the next option,\n"
+        " - a long option name not starting with a double dash\n"
+        "   (swarm accepts '--help' or '-h', but not '-help')\n\n"
+        "Please see 'swarm --help' for more details.");
+  }
+  return v;
+}
+
+Options parse(int argc, char ** argv) {
+  static const struct option longopts[] = {
+      {"append-abundance", required_argument, nullptr, 'a'}, {"boundary", required_argument, nullptr, 'b'},
+      {"ceiling", required_argument, nullptr, 'c'}, {"differences", required_argument, nullptr, 'd'},
+      {"gap-extension-penalty", required_argument, nullptr, 'e'}, {"fastidious", no_argument, nullptr, 'f'},
+      {"gap-opening-penalty", required_argument, nullptr, 'g'}, {"help", no_argument, nullptr, 'h'},
+      {"internal-structure", required_argument, nullptr, 'i'}, {"log", required_argument, nullptr, 'l'},
+      {"network-file", required_argument, nullptr, 'j'}, {"match-reward", required_argument, nullptr, 'm'},
+      {"no-otu-breaking", no_argument, nullptr, 'n'}, {"output-file", required_argument, nullptr, 'o'},
+      {"mismatch-penalty", required_argument, nullptr, 'p'}, {"mothur", no_argument, nullptr, 'r'},
+      {"statistics-file", required_argument, nullptr, 's'}, {"threads", required_argument, nullptr, 't'},
+      {"uclust-file", required_argument, nullptr, 'u'}, {"version", no_argument, nullptr, 'v'},
+      {"seeds", required_argument, nullptr, 'w'}, {"disable-sse3", no_argument, nullptr, 'x'},
+      {"bloom-bits", required_argument, nullptr, 'y'}, {"usearch-abundance", no_argument, nullptr, 'z'},
+      {nullptr, 0, nullptr, 0}};
+  Options o;
+  int ch = 0;
+  while ((ch = getopt_long(argc, argv, "a:b:c:d:e:fg:hi:j:l:m:no:p:rs:t:u:vw:xy:z", longopts, nullptr)) != -1) {
+    if (ch >= 'a' && ch <= 'z') {
+      if (o.used[ch - 'a']) {
+        const char * name = "?";
+        for (const auto & lo : longopts) { if (lo.name != nullptr && lo.val == ch) { name = lo.name; break; } }
+        die(std::string("Option -") + (char)ch + " or --" + name + " specified more than once.");
+      }
+      o.used[ch - 'a'] = true;
+    }
+    switch (ch) {
+      case 'a': o.append_abundance = number(optarg, "-a or --append-abundance"); break;
+      case 'b': o.boundary = number(optarg, "-b or --boundary"); break;
+      case 'c': o.ceiling = number(optarg, "-c or --ceiling"); break;
+      case 'd': o.differences = number(optarg, "-d or --differences"); break;
+      case 'e': o.gap_extend = number(optarg, "-e or --gap-extension-penalty"); break;
+      case 'f': o.fastidious = true; break;
+      case 'g': o.gap_open = number(optarg, "-g or --gap-opening-penalty"); break;
+      case 'h': o.help = true; break;
+      case 'i': o.structure = optarg; break;
+      case 'j': o.network = optarg; break;
+      case 'l': o.log = optarg; break;
+      case 'm': o.match_reward = number(optarg, "-m or --match-reward"); break;
+      case 'n': o.no_break = true; break;
+      case 'o': o.output = optarg; break;
+      case 'p': o.mismatch_penalty = number(optarg, "-p or --mismatch-penalty"); break;
+      case 'r': o.mothur = true; break;
+      case 's': o.stats = optarg; break;
+      case 't': o.threads = number(optarg, "-t or --threads"); break;
+      case 'u': o.uclust = optarg; break;
+      case 'v': o.version = true; break;
+      case 'w': o.seeds = optarg; break;
+      case 'x': o.disable_sse3 = true; break;
+      case 'y': o.bloom_bits = number(optarg, "-y or --bloom-bits"); break;
+      case 'z': o.usearch = true; break;
+      default:
+        std::fputs(kVersionText, stderr);
+        std::fputs(kUsageText, stderr);
+        std::fputc('\n', stderr);
+        std::exit(EXIT_FAILURE);
+    }
+  }
+  if (optind < argc) { o.input = argv[optind]; }
+  // scoring: (2m + 2p, 2g, m + 2e) / gcd   (src/swarm.cc:466-483)
+  o.pen_mismatch = 2 * o.match_reward + 2 * o.mismatch_penalty;
+  o.pen_gapopen = 2 * o.gap_open;
+  o.pen_gapextend = o.match_reward + 2 * o.gap_extend;
+  const int64_t f = std::gcd(std::gcd(o.pen_mismatch, o.pen_gapopen), o.pen_gapextend);
+  if (f != 0) { o.pen_mismatch /= f; o.pen_gapopen /= f; o.pen_gapextend /= f; }
+  return o;
+}
+
+void validate(const Options & o) {            // src/swarm.cc:486-630, same order, same texts
+  if (o.threads < 1 || o.threads > 512) { die("Illegal number of threads specified with -t or --threads, must be in the range 1 to 512."); }
+  if (o.differences < 0 || o.differences > 255) { die("Illegal number of differences specified with -d or --differences, must be in the range 0 to 255."); }
+  if (o.fastidious && o.differences != 1) { die("Fastidious mode (specified with -f or --fastidious) only works when the resolution (specified with -d or --differences) is 1."); }
+  if (o.disable_sse3 && o.differences < 2) { die("Option --disable-sse3 or -x has no effect when d < 2 (SSE3 instructions are only used when d > 1)."); }
+  if (!o.fastidious) {
+    if (o.used['b' - 'a']) { die("Option -b or --boundary specified without -f or --fastidious."); }
+    if (o.used['c' - 'a']) { die("Option -c or --ceiling specified without -f or --fastidious."); }
+    if (o.used['y' - 'a']) { die("Option -y or --bloom-bits specified without -f or --fastidious."); }
+  }
+  if (o.differences < 2) {
+    if (o.used['m' - 'a']) { die("Option -m or --match-reward specified when d < 2."); }
+    if (o.used['p' - 'a']) { die("Option -p or --mismatch-penalty specified when d < 2."); }
+    if (o.used['g' - 'a']) { die("Option -g or --gap-opening-penalty specified when d < 2."); }
+    if (o.used['e' - 'a']) { die("Option -e or --gap-extension-penalty specified when d < 2."); }
+  }
+  if (o.gap_open < 0) { die("Illegal gap opening penalty specified with -g or --gap-opening-penalty, must not be negative."); }
+  if (o.gap_extend < 0) { die("Illegal gap extension penalty specified with -e or --gap-extension-penalty, must not be negative."); }
+  if (o.gap_open + o.gap_extend < 1) { die("Illegal gap penalties specified, the sum of the gap open and the gap extension penalty must be at least 1."); }
+  if (o.match_reward < 1) { die("Illegal match reward specified with -m or --match-reward, must be at least 1."); }
+  if (o.mismatch_penalty < 1) { die("Illegal mismatch penalty specified with -p or --mismatch-penalty, must be at least 1."); }
+  if (o.boundary < 2) { die("Illegal boundary specified with -b or --boundary, must be at least 2."); }
+  if (o.used['c' - 'a'] && (o.ceiling < 40 || o.ceiling > (1 << 30))) { die("Illegal memory ceiling specified with -c or --ceiling, must be in the range 8 to 1,073,741,824 MB."); }
+  if (o.bloom_bits < 2 || o.bloom_bits > 64) { die("Illegal number of Bloom filter bits specified with -y or --bloom-bits, must be in the range 2 to 64."); }
+  if (o.used[0] && o.append_abundance < 1) { die("Illegal abundance value specified with -a or --append-abundance, must be at least 1."); }
+  if (!o.network.empty() && o.differences != 1) { die("A network file can only written when d = 1."); }
+  if (o.version) { std::fputs(kVersionText, stderr); std::exit(EXIT_SUCCESS); }
+  if (o.help) { std::fputs(kVersionText, stderr); std::fputs(kUsageText, stderr); std::exit(EXIT_SUCCESS); }
+  const int64_t sat16 = std::min<int64_t>(65535 / o.pen_mismatch, (65535 - o.pen_gapopen) / o.pen_gapextend);
+  if (o.differences > sat16) { die("Resolution (d) too high for the given scoring system."); }
+  if (o.pen_mismatch > 255) { die("Alignment scoring system yielded a mismatch penalty greater than 255, please use different parameter values."); }
+}
+
+// a phase line of the log: "<prompt> 100%" (the reference animates a percentage on a tty)
+void phase(const Options & o, const char * prompt) {
+  if (!o.log.empty()) { std::fprintf(g_log, "%s 100%%\n", prompt); }
+  else { std::fprintf(g_log, "%s 100%%\n", prompt); }
+  std::fflush(g_log);
+}
+
+void check_writer(int rc, const char * what) {
+  if (rc != SWA_OK) { die(std::string("Unable to open ") + what + " file for writing."); }
+}
+
+}  // namespace
+
+int main(int argc, char ** argv) {
+  Options o = parse(argc, argv);
+  validate(o);
+  if (!o.log.empty()) {
+    g_log = std::strcmp(o.log.c_str(), "-") == 0 ? stdout : std::fopen(o.log.c_str(), "w");
+    if (g_log == nullptr) { die("Unable to open log file for writing."); }
+  }
+  std::fputs(kVersionText, g_log);
+  std::fprintf(g_log, "Database file:     %s\n", o.input.c_str());
+  std::fprintf(g_log, "Output file:       %s\n", o.output.c_str());
+  if (!o.stats.empty()) { std::fprintf(g_log, "Statistics file:   %s\n", o.stats.c_str()); }
+  if (!o.uclust.empty()) { std::fprintf(g_log, "Uclust file:       %s\n", o.uclust.c_str()); }
+  if (!o.structure.empty()) { std::fprintf(g_log, "Int. struct. file  %s\n", o.structure.c_str()); }
+  if (!o.network.empty()) { std::fprintf(g_log, "Network file       %s\n", o.network.c_str()); }
+  std::fprintf(g_log, "Resolution (d):    %" PRId64 "\n", o.differences);
+  std::fprintf(g_log, "Threads:           %" PRId64 "\n", o.threads);
+  if (o.differences > 1) {
+    std::fprintf(g_log, "Scores:            match: %" PRId64 ", mismatch: %" PRId64 "\n", o.match_reward, o.mismatch_penalty);
+    std::fprintf(g_log, "Gap penalties:     opening: %" PRId64 ", extension: %" PRId64 "\n", o.gap_open, o.gap_extend);
+    std::fprintf(g_log, "Converted costs:   mismatch: %" PRId64 ", gap opening: %" PRId64 ", gap extension: %" PRId64 "\n",
+                 o.pen_mismatch, o.pen_gapopen, o.pen_gapextend);
+  }
+  std::fprintf(g_log, "Break clusters:    %s\n", o.no_break ? "No" : "Yes");
+  if (o.fastidious) { std::fprintf(g_log, "Fastidious:        Yes, with boundary %" PRId64 "\n", o.boundary); }
+  else { std::fprintf(g_log, "Fastidious:        No\n"); }
+  std::fprintf(g_log, "\n");
+
+  // ---- read the database (seam L2, host side)
+  swa_hostdb * db = nullptr;
+  int rc = swa_hostdb_read_fasta(o.input.c_str(), o.usearch ? 1 : 0, o.append_abundance, o.differences > 1 ? 1 : 0, &db);
+  if (rc != SWA_OK) { die_raw(db != nullptr ? swa_hostdb_error(db) : "\nError: out of memory"); }
+  phase(o, "Reading sequences:");
+  phase(o, "Indexing database:");
+  phase(o, "Abundance sorting:");
+  swa_db_view view{};
+  swa_hostdb_view(db, &view);
+  std::fprintf(g_log, "Database info:     %" PRIu64 " nt in %u sequences, longest %u nt\n", swa_hostdb_nucleotides(db),
+               view.n, view.longest);
+
+  if (o.differences == 0) {
+    die("d = 0 (dereplication) is not part of the GPU neighbour-finding build; use the reference for -d 0.");
+  }
+
+  const uint32_t n = view.n;
+  swa_ctx * ctx = nullptr;
+  if (n > 0) {
+    const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
+    const int device = dev_env != nullptr ? std::atoi(dev_env) : 0;
+    if (swa_ctx_create(device, nullptr, &ctx) != SWA_OK) {
+      die("no usable gfx950 GPU (this build has no CPU fallback).");
+    }
+    if (swa_db_upload(ctx, &view) != SWA_OK) { die(swa_last_error(ctx)); }
+  }
+
+  if (o.differences == 1) {
+    // ---- seam B1: the network on the GPU
+    std::vector<uint64_t> offsets((size_t)n + 1, 0);
+    std::vector<uint32_t> neighbours;
+    if (n > 0) {
+      int dup = 0;
+      rc = swa_d1_index_build(ctx, &dup);
+      if (rc == SWA_E_DUPLICATES) {
+        die("some fasta entries have identical sequences.\n"
+            "Swarm expects dereplicated fasta files.\n"
+            "Such files can be produced with swarm or vsearch:\n"
+            " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
+            "or\n"
+            " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n");
+      }
+      if (rc != SWA_OK) { die(swa_last_error(ctx)); }
+      phase(o, "Hashing sequences:");
+      uint64_t total = 0;
+      neighbours.resize(std::max<size_t>(4 * (size_t)n, 1024));
+      for (;;) {
+        rc = swa_d1_network(ctx, o.no_break ? 1 : 0, 0, n, offsets.data(), neighbours.data(), neighbours.size(), &total);
+        if (rc == SWA_E_CAPACITY) { neighbours.resize(total); continue; }
+        if (rc != SWA_OK) { die(swa_last_error(ctx)); }
+        break;
+      }
+      neighbours.resize(total);
+      phase(o, "Building network: ");
+    }
+    if (!o.network.empty()) {
+      check_writer(swa_d1_write_network(db, offsets.data(), neighbours.data(), o.network.c_str(), o.usearch, o.append_abundance), "network");
+      phase(o, "Dumping network:  ");
+    }
+    // ---- host: greedy clustering over the neighbour lists
+    swa_d1_result * res = nullptr;
+    if (swa_d1_cluster(db, offsets.data(), neighbours.data(), &res) != SWA_OK) { die("clustering failed"); }
+    phase(o, "Clustering:       ");
+    uint64_t sum[4];
+    swa_d1_result_summary(res, sum);
+
+    if (o.fastidious) {
+      std::fprintf(g_log, "\nResults before fastidious processing:\n");
+      std::fprintf(g_log, "Number of swarms:  %" PRIu64 "\n", sum[0]);
+      std::fprintf(g_log, "Largest swarm:     %" PRIu64 "\n\n", sum[1]);
+      std::vector<uint8_t> is_light(n);
+      uint64_t st[5];
+      swa_d1_light_flags(res, o.boundary, is_light.data(), st);
+      phase(o, "Counting amplicons in heavy and light swarms");
+      std::fprintf(g_log, "Heavy swarms: %" PRIu64 ", with %" PRIu64 " amplicons\n", st[3], st[4]);
+      std::fprintf(g_log, "Light swarms: %" PRIu64 ", with %" PRIu64 " amplicons\n", st[0], st[1]);
+      std::fprintf(g_log, "Total length of amplicons in light swarms: %" PRIu64 "\n", st[2]);
+      if (st[0] == 0 || st[3] == 0) {
+        std::fprintf(g_log, "Only light or heavy swarms found - no need for further analysis.\n");
+      } else {
+        // sizing as src/algod1.cc:1337-1396 (the --ceiling shrink works on the GPU's memory budget:
+        // the filter lives in HBM, so the host RSS terms of the reference do not apply)
+        uint64_t bits = (uint64_t)o.bloom_bits;
+        if (o.ceiling != 0) {
+          const uint64_t budget = (uint64_t)o.ceiling * 1024ull * 1024ull;
+          const uint64_t new_bits = 8ull * budget / (7ull * st[2]);
+          if (new_bits < bits) {
+            if (new_bits < 2) { die("Insufficient memory remaining for Bloom filter."); }
+            std::fprintf(g_log, "Reducing memory used for Bloom filter due to --ceiling option.\n");
+            bits = new_bits;
+          }
+        }
+        std::vector<uint32_t> graft(n);
+        uint64_t counters[8] = {};
+        // the log line needs m and k before the passes run: same arithmetic as the library
+        unsigned k = (unsigned)(0.4 * (double)bits);
+        if (k < 1) { k = 1; }
+        uint64_t m = st[2] * 7ull * bits;
+        if (m < 64) { m = 64; }
+        std::fprintf(g_log, "Bloom filter: bits=%" PRIu64 ", m=%" PRIu64 ", k=%u, size=%.1fMB\n", bits, m, k,
+                     (double)m / (8.0 * 1024.0 * 1024.0));
+        rc = swa_d1_fastidious(ctx, is_light.data(), st[2], (uint32_t)bits, graft.data(), counters);
+        if (rc != SWA_OK) { die(swa_last_error(ctx)); }
+        phase(o, "Adding light swarm amplicons to Bloom filter");
+        std::fprintf(g_log, "Generated %" PRIu64 " variants from light swarms\n", counters[0]);
+        phase(o, "Checking heavy swarm amplicons against Bloom filter");
+        std::fprintf(g_log, "Heavy variants: %" PRIu64 "\n", counters[1]);
+        std::fprintf(g_log, "Got %" PRIu64 " graft candidates\n", counters[2]);
+        const uint32_t grafts = swa_d1_graft(res, graft.data());
+        phase(o, "Grafting light swarms on heavy swarms");
+        std::fprintf(g_log, "Made %u grafts\n\n", grafts);
+      }
+    }
+
+    check_writer(swa_d1_write_swarms(res, db, o.output.c_str(), o.mothur, o.usearch, o.append_abundance, o.differences), "output");
+    phase(o, "Writing swarms:   ");
+    if (!o.seeds.empty()) { check_writer(swa_d1_write_seeds(res, db, o.seeds.c_str(), o.usearch), "seeds"); phase(o, "Writing seeds:    "); }
+    if (!o.structure.empty()) { check_writer(swa_d1_write_structure(res, db, o.structure.c_str(), o.usearch), "internal structure"); phase(o, "Writing structure:"); }
+    if (!o.uclust.empty()) {
+      check_writer(swa_d1_write_uclust(res, db, o.uclust.c_str(), o.usearch, o.append_abundance, (uint64_t)o.pen_mismatch,
+                                       (uint64_t)o.pen_gapopen, (uint64_t)o.pen_gapextend), "uclust");
+      phase(o, "Writing UCLUST:   ");
+    }
+    if (!o.stats.empty()) { check_writer(swa_d1_write_stats(res, db, o.stats.c_str(), o.usearch), "statistics"); phase(o, "Writing stats:    "); }
+    swa_d1_result_summary(res, sum);
+    std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
+                 sum[1], sum[2]);
+    swa_d1_result_free(res);
+  } else {
+    // ---- d >= 2: host greedy loop, every q-gram / alignment step on the GPU
+    swa_dn_result * res = nullptr;
+    if (n > 0) {
+      rc = swa_dn_cluster(ctx, db, o.differences, o.no_break ? 1 : 0, (uint64_t)o.pen_mismatch, (uint64_t)o.pen_gapopen,
+                          (uint64_t)o.pen_gapextend, &res);
+      if (rc != SWA_OK) { die(res != nullptr ? swa_dn_result_error(res) : "clustering failed"); }
+    } else {
+      rc = SWA_OK;
+    }
+    phase(o, "Find qgram vects: ");
+    phase(o, "Clustering:       ");
+    uint64_t sum[3] = {0, 0, 0};
+    if (res != nullptr) {
+      check_writer(swa_dn_write_swarms(res, db, o.output.c_str(), o.mothur, o.usearch, o.append_abundance), "output");
+      if (!o.structure.empty()) { check_writer(swa_dn_write_structure(res, db, o.structure.c_str(), o.usearch), "internal structure"); }
+      if (!o.uclust.empty()) { check_writer(swa_dn_write_uclust(res, db, o.uclust.c_str(), o.usearch, o.append_abundance), "uclust"); }
+      if (!o.stats.empty()) { check_writer(swa_dn_write_stats(res, db, o.stats.c_str(), o.usearch), "statistics"); }
+      if (!o.seeds.empty()) { check_writer(swa_dn_write_seeds(res, db, o.seeds.c_str(), o.usearch), "seeds"); phase(o, "Writing seeds:    "); }
+      swa_dn_result_summary(res, sum);
+      swa_dn_result_free(res);
+    } else {
+      // empty input: the reference creates empty output files
+      for (const std::string * p : {&o.output, &o.structure, &o.uclust, &o.stats, &o.seeds}) {
+        if (!p->empty() && *p != "-") { FILE * fp = std::fopen(p->c_str(), "w"); if (fp != nullptr) { std::fclose(fp); } }
+      }
+    }
+    std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
+                 sum[1], sum[2]);
+  }
+  if (ctx != nullptr) { swa_ctx_destroy(ctx); }
+  swa_hostdb_free(db);
+  if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
+  return EXIT_SUCCESS;
+}
