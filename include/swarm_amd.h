@@ -163,7 +163,19 @@ int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listlength, const u
 int swa_scan_begin(swa_ctx * ctx);
 int swa_scan_step(swa_ctx * ctx, uint32_t seed, uint32_t lowest_unswarmed, int first_generation, uint32_t radius,
                   int no_cluster_breaking, uint32_t * hit_ids, uint32_t * hit_diffs, uint32_t cap, uint32_t * nhits);
-/* out3 = {q-gram comparisons, aligned pairs, reserved} since swa_scan_begin */
+/* Batched form: all sub-seeds of one generation in one launch sequence.  seeds[k] with radius
+   radii[k]; hits come back as triples (index k into seeds[], target id, diff) sorted by
+   (k, id) and are computed against the pool as it was when the call started: a target may
+   appear under several seeds, the caller keeps it for the first (queue order) and drops the
+   others — which is exactly what processing the sub-seeds one by one gives.  Every returned
+   target leaves the pool.  first_generation != 0 requires nseeds == 1. */
+int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * seeds, const uint32_t * radii,
+                   uint32_t lowest_unswarmed, int first_generation, int no_cluster_breaking,
+                   uint32_t * hit_seedidx, uint32_t * hit_ids, uint32_t * hit_diffs, uint32_t cap, uint32_t * nhits);
+/* the (sorted) hits of the most recent swa_scan_batch again — for a caller whose buffers were
+   too small (SWA_E_CAPACITY, *nhits = need): grow to *nhits and fetch; hit_seedidx may be NULL */
+int swa_scan_fetch(swa_ctx * ctx, uint32_t * hit_seedidx, uint32_t * hit_ids, uint32_t * hit_diffs, uint32_t cap);
+/* out3 = {q-gram comparisons, aligned pairs, launch sequences} since swa_scan_begin */
 int swa_scan_totals(swa_ctx * ctx, uint64_t * out3);
 
 #ifdef __cplusplus

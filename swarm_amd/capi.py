@@ -396,7 +396,7 @@ class Context:
 
 _DN_EXPORTS = ["swa_dn_cluster", "swa_dn_result_free", "swa_dn_result_error", "swa_dn_result_summary",
                "swa_dn_write_swarms", "swa_dn_write_stats", "swa_dn_write_structure", "swa_dn_write_seeds",
-               "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_totals"]
+               "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_batch", "swa_scan_fetch", "swa_scan_totals"]
 EXPORTS.extend(_DN_EXPORTS)
 
 
@@ -459,7 +459,7 @@ class DnClusters:
     def scan_totals(self) -> dict:
         out = np.zeros(3, dtype=np.uint64)
         self.ctx._check(self.lib.swa_scan_totals(self.ctx.h, _p64(out)))
-        return {"qgram_comparisons": int(out[0]), "aligned_pairs": int(out[1])}
+        return {"qgram_comparisons": int(out[0]), "aligned_pairs": int(out[1]), "launch_sequences": int(out[2])}
 
     def write_swarms(self, path, mothur=False, usearch=False, append_abundance=0) -> None:
         assert self.lib.swa_dn_write_swarms(self.h, self.hdb.h, str(path).encode(), int(mothur), int(usearch),

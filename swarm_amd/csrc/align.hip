@@ -34,7 +34,8 @@ struct AlignArgs {
   const uint64_t * seqs;
   const uint64_t * seq_off;
   const uint32_t * seqlen;
-  uint32_t query;
+  uint32_t query;             // the query amplicon, unless `queries` gives one per pair
+  const uint32_t * queries;
   uint32_t ntargets;          // upper bound; the real count is *ntargets_dev when that is set
   const uint32_t * ntargets_dev;
   const uint32_t * targets;
@@ -52,38 +53,47 @@ __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b, uint32_t sat
   return s < sat ? s : sat;
 }
 
-template <int G>
+// value of `v` in the neighbouring lane (full-wave DPP shifts, GFX9 family): a few cycles
+// instead of an LDS-crossbar ds_bpermute on the critical path of every anti-diagonal step
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v) {   // lane i <- lane i-1
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {   // lane i <- lane i+1
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+
+template <int G, bool WANT_LEN>
 __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
   extern __shared__ uint64_t lds[];
   constexpr int kGroups = 256 / G;
-  uint64_t * qw = lds;                                        // query words (shared by the block)
   const int group = threadIdx.x / G;
   const int t = threadIdx.x % G;
-  uint64_t * dw = lds + a.maxwords + (size_t)group * a.maxwords;   // this group's target words
-
-  const uint32_t ql = a.seqlen[a.query];
-  {
-    const uint64_t * gq = a.seqs + a.seq_off[a.query];
-    const uint32_t qn = (ql + 31u) >> 5;
-    for (uint32_t w = threadIdx.x; w < qn; w += 256u) { qw[w] = gq[w]; }
-  }
-  __syncthreads();
+  uint64_t * qw = lds + (size_t)(2 * group) * a.maxwords;     // this group's query words
+  uint64_t * dw = qw + a.maxwords;                            // this group's target words
 
   const uint32_t SAT = a.sat;
   const int W = a.W;
   const int o = t - W;                                        // band offset = column - row
   const bool lane_in_band = t <= 2 * W;
+  const bool has_above = t + 1 <= 2 * W;                      // lane t+1 holds an in-band cell
+  const bool has_below = t >= 1;
   const uint32_t go = a.gapopen, ge = a.gapextend, mm = a.mismatch;
   constexpr uint32_t kBigCount = 0xFFFFu;
+  const uint32_t kOutside = SAT | (kBigCount << 16);          // what an out-of-band neighbour provides
 
   const uint32_t ntargets = a.ntargets_dev != nullptr ? min(*a.ntargets_dev, a.ntargets) : a.ntargets;
   for (uint32_t pair = blockIdx.x * kGroups + group; pair < ntargets; pair += gridDim.x * kGroups) {
     const uint32_t target = a.targets[pair];
+    const uint32_t query = a.queries != nullptr ? a.queries[pair] : a.query;
     const uint32_t dl = a.seqlen[target];
+    const uint32_t ql = a.seqlen[query];
     {
       const uint64_t * gd = a.seqs + a.seq_off[target];
+      const uint64_t * gq = a.seqs + a.seq_off[query];
       const uint32_t dn = (dl + 31u) >> 5;
+      const uint32_t qn = (ql + 31u) >> 5;
       for (uint32_t w = t; w < dn; w += G) { dw[w] = gd[w]; }
+      for (uint32_t w = t; w < qn; w += G) { qw[w] = gq[w]; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -91,63 +101,82 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
 
     const int delta = (int)ql - (int)dl;
     const bool feasible = (delta <= W) && (-delta <= W);      // the end cell lies inside the band
-    // per-lane state: values of the last cell this lane computed
+    // Per-lane state = the last cell this lane computed.  The values handed to the neighbour
+    // lanes travel packed: low 16 bits the (saturated) score, high 16 bits the diff counter.
+    // The loop body is branch-free: boundary inputs (row 0 / column 0, nw.cc:66-79) are
+    // wave-uniform functions of the step, everything else is selects, and the nucleotide
+    // comparison of the NEXT step is fetched from LDS while the current step computes.
     uint32_t Hown = 0, AMown = 0, LMown = 0;                  // H, A_M, alignment length (diagonal input)
-    uint32_t Edn = SAT, AIdn = kBigCount, LIdn = 0;           // E passed down to (r+1, c) with A_I, L_I
-    uint32_t Frt = SAT, ADrt = kBigCount, LDrt = 0;           // F passed right to (r, c+1) with A_D, L_D
+    uint32_t dn_pk = kOutside, dn_len = 0;                    // E | A_I  passed down  to (r+1, c)
+    uint32_t rt_pk = kOutside, rt_len = 0;                    // F | A_D  passed right to (r, c+1)
     if (feasible) {
       const int last = (int)dl + (int)ql - 2;
+      const int rmax = (int)dl - 1, cmax = (int)ql - 1;
+      auto mismatch_at = [&](int s) -> uint32_t {             // d[r] != q[c] for this lane's cell of step s
+        const int rs = s - o;
+        int r = rs >> 1;
+        int c = s - r;
+        r = r < 0 ? 0 : (r > rmax ? rmax : r);                // clamped: inactive lanes read something valid
+        c = c < 0 ? 0 : (c > cmax ? cmax : c);
+        const uint32_t dnt = (uint32_t)(dw[r >> 5] >> ((r & 31) << 1));
+        const uint32_t qnt = (uint32_t)(qw[c >> 5] >> ((c & 31) << 1));
+        return ((dnt ^ qnt) & 3u) != 0u ? 1u : 0u;
+      };
+      uint32_t mis_next = mismatch_at(0);
       for (int s = 0; s <= last; ++s) {
-        // neighbour values from the previous step (computed by every lane of the group)
-        const uint32_t vE = __shfl_down(Edn, 1, G), vAI = __shfl_down(AIdn, 1, G), vLI = __shfl_down(LIdn, 1, G);
-        const uint32_t vF = __shfl_up(Frt, 1, G), vAD = __shfl_up(ADrt, 1, G), vLD = __shfl_up(LDrt, 1, G);
+        const uint32_t mis = mis_next;
+        mis_next = mismatch_at(s + 1);                        // LDS latency hides behind this step's math
+        // neighbour values from the previous step (every lane of the group takes part)
+        const uint32_t above_pk = from_lane_above(dn_pk);     // cell (r-1, c) lives in lane t+1
+        const uint32_t below_pk = from_lane_below(rt_pk);     // cell (r, c-1) lives in lane t-1
+        uint32_t above_len = 0, below_len = 0;
+        if (WANT_LEN) { above_len = from_lane_above(dn_len); below_len = from_lane_below(rt_len); }
         const int rs = s - o;
         const int r = rs >> 1;
         const int c = s - r;
-        const bool act = lane_in_band && ((rs & 1) == 0) && rs >= 0 && r < (int)dl && c >= 0 && c < (int)ql;
-        if (act) {
-          // diagonal input: H(r-1, c-1), boundary per nw.cc:66-79
-          uint32_t hd, amd, lmd;
-          if (r == 0) { hd = (c == 0) ? 0u : sat_add(go, (uint32_t)c * ge, SAT); amd = (uint32_t)c; lmd = (uint32_t)c; }
-          else if (c == 0) { hd = sat_add(go, (uint32_t)r * ge, SAT); amd = (uint32_t)r; lmd = (uint32_t)r; }
-          else { hd = Hown; amd = AMown; lmd = LMown; }
-          // vertical input ("left" in nw.cc): E from (r-1, c), held by lane t+1
-          uint32_t left, aiv, liv;
-          if (r == 0) { left = sat_add(2u * go, (uint32_t)(c + 2) * ge, SAT); aiv = (uint32_t)c + 1u; liv = (uint32_t)c + 1u; }
-          else if (t + 1 <= 2 * W) { left = vE; aiv = vAI; liv = vLI; }
-          else { left = SAT; aiv = kBigCount; liv = 0u; }
-          // horizontal input ("top" in nw.cc): F from (r, c-1), held by lane t-1
-          uint32_t top, adh, ldh;
-          if (c == 0) { top = sat_add(2u * go, (uint32_t)(r + 2) * ge, SAT); adh = (uint32_t)r + 1u; ldh = (uint32_t)r + 1u; }
-          else if (t >= 1) { top = vF; adh = vAD; ldh = vLD; }
-          else { top = SAT; adh = kBigCount; ldh = 0u; }
+        const bool act = lane_in_band && ((rs & 1) == 0) && rs >= 0 && r <= rmax && c >= 0 && c <= cmax;
+        const bool row0 = rs == 0;                            // r == 0  (then c == s)
+        const bool col0 = s + o == 0;                         // c == 0  (then r == s)
+        // boundary inputs, uniform over the wave for a given step
+        const uint32_t su = (uint32_t)s;
+        const uint32_t edge_h = s == 0 ? 0u : sat_add(go, su * ge, SAT);
+        const uint32_t edge_pk = sat_add(2u * go, (su + 2u) * ge, SAT) | ((su + 1u) << 16);
+        const uint32_t hd = (row0 || col0) ? edge_h : Hown;
+        const uint32_t amd = (row0 || col0) ? su : AMown;
+        const uint32_t left_pk = row0 ? edge_pk : (has_above ? above_pk : kOutside);   // "left" in nw.cc
+        const uint32_t top_pk = col0 ? edge_pk : (has_below ? below_pk : kOutside);    // "top" in nw.cc
+        const uint32_t left = left_pk & 0xFFFFu, aiv = left_pk >> 16;
+        const uint32_t top = top_pk & 0xFFFFu, adh = top_pk >> 16;
 
-          const uint32_t dnt = (uint32_t)((dw[r >> 5] >> ((r & 31) << 1)) & 3u);
-          const uint32_t qnt = (uint32_t)((qw[c >> 5] >> ((c & 31) << 1)) & 3u);
-          const uint32_t mis = dnt != qnt ? 1u : 0u;
-          const uint32_t dp = sat_add(hd, mis ? mm : 0u, SAT);
-          const bool up = top < dp;                            // nw.cc:91
-          uint32_t h = dp < top ? dp : top;
-          h = h < left ? h : left;
-          const bool lb = left == h;                           // nw.cc:94
-          const uint32_t d2 = sat_add(h, go + ge, SAT);
-          const uint32_t l2 = sat_add(left, ge, SAT);
-          const uint32_t t2 = sat_add(top, ge, SAT);
-          const bool eu = t2 < d2;                             // nw.cc:102
-          const bool el = l2 < d2;                             // nw.cc:103
-          // what the backtrack would count from here (priority: nw.cc:139-172)
-          uint32_t am, lm;
-          if (lb) { am = aiv + 1u; lm = liv + 1u; }
-          else if (up) { am = adh + 1u; lm = ldh + 1u; }
-          else { am = amd + mis; lm = lmd + 1u; }
-          if (am > kBigCount) { am = kBigCount; }
-          uint32_t ai = el ? aiv + 1u : am;
-          uint32_t ad = eu ? adh + 1u : am;
-          if (ai > kBigCount) { ai = kBigCount; }
-          if (ad > kBigCount) { ad = kBigCount; }
-          Hown = h; AMown = am; LMown = lm;
-          Edn = d2 < l2 ? d2 : l2; AIdn = ai; LIdn = el ? liv + 1u : lm;
-          Frt = d2 < t2 ? d2 : t2; ADrt = ad; LDrt = eu ? ldh + 1u : lm;
+        const uint32_t dp = sat_add(hd, mis ? mm : 0u, SAT);
+        const bool up = top < dp;                              // nw.cc:91
+        uint32_t h = dp < top ? dp : top;
+        h = h < left ? h : left;
+        const bool lb = left == h;                             // nw.cc:94
+        const uint32_t d2 = sat_add(h, go + ge, SAT);
+        const uint32_t l2 = sat_add(left, ge, SAT);
+        const uint32_t t2 = sat_add(top, ge, SAT);
+        const bool eu = t2 < d2;                               // nw.cc:102
+        const bool el = l2 < d2;                               // nw.cc:103
+        // what the backtrack would count from here (priority: nw.cc:139-172)
+        uint32_t am = lb ? aiv + 1u : (up ? adh + 1u : amd + mis);
+        am = am < kBigCount ? am : kBigCount;
+        uint32_t ai = el ? aiv + 1u : am;
+        uint32_t ad = eu ? adh + 1u : am;
+        ai = ai < kBigCount ? ai : kBigCount;
+        ad = ad < kBigCount ? ad : kBigCount;
+        Hown = act ? h : Hown;
+        AMown = act ? am : AMown;
+        dn_pk = act ? ((d2 < l2 ? d2 : l2) | (ai << 16)) : dn_pk;
+        rt_pk = act ? ((d2 < t2 ? d2 : t2) | (ad << 16)) : rt_pk;
+        if (WANT_LEN) {
+          const uint32_t lmd = (row0 || col0) ? su : LMown;
+          const uint32_t liv = row0 ? su + 1u : above_len;
+          const uint32_t ldh = col0 ? su + 1u : below_len;
+          const uint32_t lm = lb ? liv + 1u : (up ? ldh + 1u : lmd + 1u);
+          LMown = act ? lm : LMown;
+          dn_len = act ? (el ? liv + 1u : lm) : dn_len;
+          rt_len = act ? (eu ? ldh + 1u : lm) : rt_len;
         }
       }
     }
@@ -181,8 +210,6 @@ __global__ __launch_bounds__(256) void k_align_generic(const AlignArgs a, uint32
   const int W = a.W;
   const uint32_t go = a.gapopen, ge = a.gapextend, mm = a.mismatch;
   constexpr uint32_t kBigCount = 0xFFFFu;
-  const uint32_t ql = a.seqlen[a.query];
-  const uint64_t * qw = a.seqs + a.seq_off[a.query];
   // six planes of qcap columns each: H, E, A_M, A_I, L_M, L_I of the previous row
   uint32_t * pH = scratch;
   uint32_t * pE = pH + (size_t)qcap * nthreads;
@@ -193,6 +220,9 @@ __global__ __launch_bounds__(256) void k_align_generic(const AlignArgs a, uint32
   const uint32_t ntargets = a.ntargets_dev != nullptr ? min(*a.ntargets_dev, a.ntargets) : a.ntargets;
   for (uint32_t pair = tid; pair < ntargets; pair += nthreads) {
     const uint32_t target = a.targets[pair];
+    const uint32_t query = a.queries != nullptr ? a.queries[pair] : a.query;
+    const uint32_t ql = a.seqlen[query];
+    const uint64_t * qw = a.seqs + a.seq_off[query];
     const uint32_t dl = a.seqlen[target];
     const uint64_t * dw = a.seqs + a.seq_off[target];
     const int delta = (int)ql - (int)dl;
@@ -290,10 +320,12 @@ __global__ __launch_bounds__(256) void k_widen(const uint32_t * __restrict__ in,
 }  // namespace
 
 // Enqueue the alignment of `query` against d_targets[0 .. count) on the context's stream.
-// count = *d_count (device) when d_count != nullptr, bounded by max_count; all pointers are
-// device memory.  Shared by swa_search_do and the fused scan (scan.hip).
-int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_targets, const uint32_t * d_count,
-                     uint32_t max_count, uint32_t * d_diffs, uint32_t * d_scores, uint32_t * d_alnlens) {
+// count = *d_count (device) when d_count != nullptr, bounded by max_count; d_queries != nullptr
+// gives one query per pair (batched sub-seeds) instead of the single `query`; all pointers
+// are device memory.  Shared by swa_search_do and the fused scan (scan.hip).
+int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, const uint32_t * d_targets,
+                     const uint32_t * d_count, uint32_t max_count, uint32_t * d_diffs, uint32_t * d_scores,
+                     uint32_t * d_alnlens) {
   const uint64_t mm = ctx->pen_mismatch, go = ctx->pen_gapopen, ge = ctx->pen_gapextend, d = ctx->resolution;
   // 8- or 16-bit arithmetic exactly as set_bit_mode decides (src/algo.cc:96-120)
   const uint64_t diff_saturation = std::min<uint64_t>(255 / mm, 255 / (go + ge));
@@ -304,6 +336,7 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_targets, 
   AlignArgs a{};
   a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen;
   a.query = query;
+  a.queries = d_queries;
   a.ntargets = max_count;
   a.ntargets_dev = d_count;
   a.targets = d_targets;
@@ -318,7 +351,7 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_targets, 
   const uint64_t cap = uint64_t(ctx->num_cus) * 8;
   if (blocks > cap) { blocks = cap; }
   if (blocks < 1) { blocks = 1; }
-  const size_t lds = sizeof(uint64_t) * (size_t)a.maxwords * (groups + 1);
+  const size_t lds = sizeof(uint64_t) * (size_t)a.maxwords * (2 * groups);
   if (generic) {
     a.W = W64 > 0x3FFFFFFF ? 0x3FFFFFFF : (int)W64;
     const uint32_t qcap = ctx->db.longest + 1u;
@@ -328,8 +361,13 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_targets, 
     SWA_TRY(swa_reserve(ctx, ctx->d_queue, nthreads * 6ull * qcap * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_align_generic, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, a,
                        static_cast<uint32_t *>(ctx->d_queue.ptr), (uint32_t)nthreads, qcap);
-  } else if (wide) { hipLaunchKernelGGL(k_align<64>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
-  else { hipLaunchKernelGGL(k_align<32>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
+  } else if (d_alnlens != nullptr) {
+    if (wide) { hipLaunchKernelGGL((k_align<64, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_align<32, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
+  } else {
+    if (wide) { hipLaunchKernelGGL((k_align<64, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_align<32, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); }
+  }
   SWA_HIP(ctx, hipGetLastError());
   return SWA_OK;
 }
@@ -353,7 +391,7 @@ extern "C" int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listleng
   unsigned cb = (unsigned)std::min<uint64_t>((listlength + 255) / 256, uint64_t(ctx->num_cus) * 8);
   SWA_HIP(ctx, hipMemcpyAsync(d64, targets, listlength * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_narrow, dim3(cb), dim3(256), 0, ctx->stream, d64, t32, listlength);
-  SWA_TRY(swa_align_launch(ctx, (uint32_t)query_no, t32, nullptr, (uint32_t)listlength, r32,
+  SWA_TRY(swa_align_launch(ctx, (uint32_t)query_no, nullptr, t32, nullptr, (uint32_t)listlength, r32,
                            scores != nullptr ? r32 + listlength : nullptr,
                            alignlengths != nullptr ? r32 + 2 * listlength : nullptr));
   uint64_t * outs[3] = {diffs, scores, alignlengths};

@@ -74,7 +74,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_offsets_tmp, &ctx->d_nb_tmp, &ctx->d_qgrams, &ctx->d_list_a, &ctx->d_list_b,
                        &ctx->d_list_c, &ctx->d_list_d, &ctx->d_light, &ctx->d_graft, &ctx->d_bloomflex,
                        &ctx->d_fpatterns, &ctx->d_queue, &ctx->d_fcounters, &ctx->d_scan_est, &ctx->d_scan_swarmed,
-                       &ctx->d_scan_targets, &ctx->d_scan_diffs, &ctx->d_scan_hits, &ctx->d_scan_counters}) {
+                       &ctx->d_scan_targets, &ctx->d_scan_diffs, &ctx->d_scan_hits, &ctx->d_scan_counters, &ctx->d_scan_seeds}) {
     swa_release(*b);
   }
   if (ctx->ev_ready) { for (auto & e : ctx->ev) { (void)hipEventDestroy(e); } }

@@ -95,7 +95,7 @@ extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t diff
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
 
   std::vector<uint8_t> swarmed(n, 0);
-  std::vector<uint32_t> hit_ids(n), hit_diffs(n);
+  std::vector<uint32_t> hit_ids(n), hit_diffs(n), hit_sidx(n), batch_ids, batch_radii;
   std::vector<swa_dn_result::Member> queue;
   r->order.reserve(n);
   for (uint32_t seed = 0; seed < n; ++seed) {
@@ -117,22 +117,43 @@ extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t diff
     }
     size_t next = 1;                                       // queue[next..) = swarmed but not yet seeded
     while (next < queue.size()) {
-      const swa_dn_result::Member sub = queue[next];
-      ++next;
-      rc = swa_scan_step(ctx, sub.id, seed + 1, 0, sub.radius, no_cluster_breaking, hit_ids.data(), hit_diffs.data(),
-                         n, &nh);
+      // All sub-seeds of the current generation go to the GPU in one batch: their hits belong
+      // to the next generation and queue up behind them, so the batch is complete when the
+      // generation starts.  Hits are computed against the pool as of now; a target found by
+      // several sub-seeds is kept for the first one in queue order, exactly what the
+      // one-by-one loop of the reference does (src/algo.cc:505-602).
+      const uint32_t generation = queue[next].generation;
+      size_t batch_end = next;
+      while (batch_end < queue.size() && queue[batch_end].generation == generation && batch_end - next < 65535) { ++batch_end; }
+      const uint32_t nb = (uint32_t)(batch_end - next);
+      batch_ids.resize(nb);
+      batch_radii.resize(nb);
+      for (uint32_t k = 0; k < nb; ++k) { batch_ids[k] = queue[next + k].id; batch_radii[k] = queue[next + k].radius; }
+      rc = swa_scan_batch(ctx, nb, batch_ids.data(), batch_radii.data(), seed + 1, 0, no_cluster_breaking,
+                          hit_sidx.data(), hit_ids.data(), hit_diffs.data(), (uint32_t)hit_ids.size(), &nh);
+      if (rc == SWA_E_CAPACITY) {
+        hit_sidx.resize(nh); hit_ids.resize(nh); hit_diffs.resize(nh);
+        rc = swa_scan_fetch(ctx, hit_sidx.data(), hit_ids.data(), hit_diffs.data(), nh);
+      }
       if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
-      for (uint32_t k = 0; k < nh; ++k) {
-        const uint32_t id = hit_ids[k];
-        swarmed[id] = 1;
-        // keep the unseeded part of the queue ordered by generation, then id (algo.cc:205-219)
-        size_t pos = queue.size();
-        while (pos > next && queue[pos - 1].id > id && queue[pos - 1].generation > sub.generation) { --pos; }
-        const swa_dn_result::Member m{id, sub.generation + 1, sub.radius + hit_diffs[k]};
-        queue.insert(queue.begin() + (std::ptrdiff_t)pos, m);
-        sw.maxgen = std::max(sw.maxgen, m.generation);
-        sw.maxradius = std::max(sw.maxradius, m.radius);
-        r->links.push_back({sub.id, id, hit_diffs[k], swarm_no, m.generation});
+      const size_t batch_first = next;
+      uint32_t h = 0;
+      for (uint32_t b = 0; b < nb; ++b) {
+        const swa_dn_result::Member sub = queue[batch_first + b];   // members of this generation never move
+        ++next;
+        for (; h < nh && hit_sidx[h] == b; ++h) {
+          const uint32_t id = hit_ids[h];
+          if (swarmed[id]) { continue; }                   // an earlier sub-seed of the batch took it
+          swarmed[id] = 1;
+          // keep the unseeded part of the queue ordered by generation, then id (algo.cc:205-219)
+          size_t pos = queue.size();
+          while (pos > next && queue[pos - 1].id > id && queue[pos - 1].generation > sub.generation) { --pos; }
+          const swa_dn_result::Member m{id, sub.generation + 1, sub.radius + hit_diffs[h]};
+          queue.insert(queue.begin() + (std::ptrdiff_t)pos, m);
+          sw.maxgen = std::max(sw.maxgen, m.generation);
+          sw.maxradius = std::max(sw.maxradius, m.radius);
+          r->links.push_back({sub.id, id, hit_diffs[h], swarm_no, m.generation});
+        }
       }
     }
     sw.link_end = (uint32_t)r->links.size();

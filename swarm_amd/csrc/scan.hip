@@ -1,4 +1,4 @@
-// scan.hip — the fused d >= 2 step: one (sub)seed against the whole unswarmed pool, on the GPU.
+// scan.hip — the fused d >= 2 step: seeds against the whole unswarmed pool, on the GPU.
 //
 // The reference's greedy loop (src/algo.cc:384-676) builds, for every seed and sub-seed, a
 // candidate list on the host (abundance rule + triangle-inequality prune
@@ -6,48 +6,68 @@
 // `qdiff <= d` on the host, calls search_do, and filters `diff <= d` on the host.  Done through
 // the per-call seams B3/B4 that costs four host<->device transfers per step.  Here the pool
 // state lives in HBM (est[] = q-gram estimate against the current swarm's initial seed,
-// swarmed[]) and one step is three kernels and ONE small read-back:
+// swarmed[]) and one launch sequence handles a whole BATCH of sub-seeds:
 //
-//   k_scan_filter   8 lanes per pool amplicon: prune -> 128-byte signature gather -> popcount
-//                   bound -> (first generation: store est) -> compact survivors
-//   k_align<G>      the B4 kernel over the compacted targets (count read on the device)
-//   k_scan_collect  diff <= d -> (id, diff) hit list, swarmed[id] = 1
+//   k_scan_filter   grid.y = seed; 8 lanes per pool amplicon: prune -> 128-byte signature
+//                   gather -> popcount bound -> (first generation: store est) -> compact
+//                   (seed index, target) pairs
+//   k_align<G>      the B4 kernel over the compacted pairs (count read on the device)
+//   k_scan_collect  diff <= d -> (seed index, id, diff) hit list, swarmed[id] = 1
 //
-// The unswarmed pool is always in ascending amplicon-id order in the reference (rotations in
-// move_target_to_first_unswarmed_position keep the relative order, src/algo.cc:222-245), so
-// "pool order" = id order and the host only needs the hits sorted by id.
+// Why batching is exact: all sub-seeds of one generation are known when the generation
+// starts (hits they produce belong to the next generation and queue up behind them,
+// src/algo.cc:205-219); whether a pool amplicon is a hit of a sub-seed does not depend on the
+// pool, only on the pair; so the sequential result is "the batch result minus targets an
+// earlier sub-seed of the batch already took", which the host resolves in queue order.  The
+// union of all hits is exactly the set that leaves the pool.
+//
+// The unswarmed pool is always in ascending amplicon-id order in the reference (the rotations
+// of move_target_to_first_unswarmed_position keep the relative order, src/algo.cc:222-245), so
+// "pool order" = id order and the host only needs the hits sorted by (seed index, id).
 #include "swa_internal.h"
 
 #include <algorithm>
 
-int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_targets, const uint32_t * d_count,
-                     uint32_t max_count, uint32_t * d_diffs, uint32_t * d_scores, uint32_t * d_alnlens);
+int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, const uint32_t * d_targets,
+                     const uint32_t * d_count, uint32_t max_count, uint32_t * d_diffs, uint32_t * d_scores,
+                     uint32_t * d_alnlens);
+
+extern "C" int swa_scan_fetch(swa_ctx * ctx, uint32_t * hit_seedidx, uint32_t * hit_ids, uint32_t * hit_diffs,
+                              uint32_t cap);
 
 namespace {
 
-constexpr uint32_t kInlineHits = 1022;   // hits returned with the first read-back
+constexpr uint32_t kInlineHits = 680;   // hit triples returned with the first read-back (8 KB)
 
 struct ScanArgs {
   const ulonglong2 * sigs;
   const uint64_t * abundance;
   uint32_t * est;
   uint8_t * swarmed;
-  uint32_t n, lo, seed;
-  uint32_t first_generation, limit /* radius + d */, d, ncb;
-  uint32_t * targets;
-  uint32_t * counters;     // [0] targets [1] hits [2..3] unused
-  unsigned long long * totals;   // [0] q-gram comparisons [1] aligned pairs [2] accepted
+  uint32_t n, lo, nseeds;
+  const uint32_t * seeds;       // [nseeds] amplicon ids
+  const uint32_t * limits;      // [nseeds] radius + d
+  uint32_t first_generation, d, ncb;
+  uint32_t * t_query;           // compacted pairs: query amplicon id
+  uint32_t * t_target;          //                  target amplicon id
+  uint32_t * t_seedidx;         //                  index of the seed inside the batch
+  uint32_t cap;                 // capacity of the pair arrays
+  uint32_t * counters;          // [0] pairs [1] hits [2] pair overflow flag
+  unsigned long long * totals;  // [0] q-gram comparisons [1] aligned pairs
 };
 
 __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
+  const uint32_t sidx = blockIdx.y;
+  const uint32_t seed = a.seeds[sidx];
+  const uint32_t limit = a.limits[sidx];
   const uint32_t sub = threadIdx.x & 7u;
-  const ulonglong2 mine = a.sigs[(uint64_t)a.seed * 8u + sub];
-  const uint64_t seed_ab = a.abundance[a.seed];
+  const ulonglong2 mine = a.sigs[(uint64_t)seed * 8u + sub];
+  const uint64_t seed_ab = a.abundance[seed];
   const uint32_t groups = gridDim.x * (blockDim.x >> 3);
   unsigned long long compared = 0;
   for (uint32_t i = a.lo + blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); i < a.n; i += groups) {
-    if (i == a.seed || a.swarmed[i] != 0) { continue; }
-    if (a.first_generation == 0u && a.est[i] > a.limit) { continue; }          // algo.cc:521-522
+    if (i == seed || a.swarmed[i] != 0) { continue; }
+    if (a.first_generation == 0u && a.est[i] > limit) { continue; }             // algo.cc:521-522
     if (a.ncb == 0u && a.abundance[i] > seed_ab) { continue; }                  // algo.cc:427-428, 523-525
     const ulonglong2 other = a.sigs[(uint64_t)i * 8u + sub];
     uint32_t pop = (uint32_t)__popcll(mine.x ^ other.x) + (uint32_t)__popcll(mine.y ^ other.y);
@@ -58,26 +78,37 @@ __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
       const uint32_t qd = (pop + 9u) / 10u;
       ++compared;
       if (a.first_generation != 0u) { a.est[i] = qd; }                          // algo.cc:442
-      if (qd <= a.d) { a.targets[atomicAdd(&a.counters[0], 1u)] = i; }
+      if (qd <= a.d) {
+        const uint32_t at = atomicAdd(&a.counters[0], 1u);
+        if (at < a.cap) { a.t_query[at] = seed; a.t_target[at] = i; a.t_seedidx[at] = sidx; }
+        else { a.counters[2] = 1u; }
+      }
     }
   }
   if (compared != 0ull) { atomicAdd(&a.totals[0], compared); }
 }
 
-__global__ __launch_bounds__(256) void k_scan_collect(const uint32_t * __restrict__ targets,
+__global__ __launch_bounds__(256) void k_scan_collect(const uint32_t * __restrict__ t_target,
+                                                      const uint32_t * __restrict__ t_seedidx,
                                                       const uint32_t * __restrict__ diffs, uint32_t * counters,
-                                                      uint32_t d, uint8_t * swarmed, uint32_t * __restrict__ hits,
-                                                      unsigned long long * totals) {
-  const uint32_t nt = counters[0];
+                                                      uint32_t cap, uint32_t d, uint8_t * swarmed,
+                                                      uint32_t * __restrict__ hits, unsigned long long * totals) {
+  if (counters[2] != 0u) { return; }            // pair overflow: the host grows the buffers and redoes the batch
+  const uint32_t nt = counters[0] < cap ? counters[0] : cap;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
     if (diffs[t] <= d) {
       const uint32_t at = atomicAdd(&counters[1], 1u);
-      hits[2u * at] = targets[t];
-      hits[2u * at + 1u] = diffs[t];
-      swarmed[targets[t]] = 1;
+      hits[3u * at] = t_seedidx[t];
+      hits[3u * at + 1u] = t_target[t];
+      hits[3u * at + 2u] = diffs[t];
+      swarmed[t_target[t]] = 1;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&totals[1], (unsigned long long)nt); }
+}
+
+__global__ void k_mark(uint8_t * swarmed, const uint32_t * ids, uint32_t count) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) { swarmed[ids[i]] = 1; }
 }
 
 }  // namespace
@@ -91,9 +122,6 @@ extern "C" int swa_scan_begin(swa_ctx * ctx) {
   const uint64_t n = ctx->db.n;
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_est, n * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_swarmed, n));
-  SWA_TRY(swa_reserve(ctx, ctx->d_scan_targets, n * sizeof(uint32_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_scan_diffs, n * sizeof(uint32_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_scan_hits, (2 * n + 2 * kInlineHits + 8) * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_counters, 64));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_scan_est.ptr, 0, n * sizeof(uint32_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_scan_swarmed.ptr, 0, n, ctx->stream));
@@ -103,77 +131,145 @@ extern "C" int swa_scan_begin(swa_ctx * ctx) {
   return SWA_OK;
 }
 
+// One batch: every seeds[k] (with radius radii[k]) against the unswarmed pool.
+// hit_* receive triples sorted by (seed index, target id); *nhits = number of triples.
+extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * seeds, const uint32_t * radii,
+                              uint32_t lowest_unswarmed, int first_generation, int no_cluster_breaking,
+                              uint32_t * hit_seedidx, uint32_t * hit_ids, uint32_t * hit_diffs, uint32_t cap,
+                              uint32_t * nhits) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->scan_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_scan_batch: call swa_scan_begin first"); }
+  if (nhits == nullptr || seeds == nullptr || radii == nullptr || nseeds == 0 || nseeds > 65535 ||
+      (first_generation != 0 && nseeds != 1) ||
+      (cap != 0 && (hit_ids == nullptr || hit_diffs == nullptr || hit_seedidx == nullptr))) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_scan_batch: bad argument");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  const uint32_t d = (uint32_t)ctx->resolution;
+  for (uint32_t k = 0; k < nseeds; ++k) {
+    if (seeds[k] >= n) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_scan_batch: seed out of range"); }
+  }
+  auto * counters = static_cast<uint32_t *>(ctx->d_scan_counters.ptr);          // u32[4] then u64 totals[4]
+  auto * totals = reinterpret_cast<unsigned long long *>(counters + 4);
+
+  // seeds + limits -> device (one small upload)
+  ctx->scan_host.resize(2 * (size_t)nseeds);
+  for (uint32_t k = 0; k < nseeds; ++k) { ctx->scan_host[k] = seeds[k]; ctx->scan_host[nseeds + k] = radii[k] + d; }
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_seeds, 2 * (size_t)nseeds * sizeof(uint32_t)));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_scan_seeds.ptr, ctx->scan_host.data(), 2 * (size_t)nseeds * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t lo = lowest_unswarmed < n ? lowest_unswarmed : n;
+  const uint32_t span = n - lo;
+  // pair capacity: a first guess that is grown (and the batch redone) if it ever overflows
+  uint64_t pair_cap = ctx->scan_pair_cap;
+  if (pair_cap == 0) { pair_cap = std::max<uint64_t>(1u << 16, (uint64_t)n); }
+  uint32_t got = 0;
+  ++ctx->scan_launches;
+  for (;;) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_scan_targets, 3 * pair_cap * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_scan_diffs, pair_cap * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_scan_hits, (3 * pair_cap + 8) * sizeof(uint32_t)));
+    ctx->scan_pair_cap = pair_cap;
+    ScanArgs a{};
+    a.sigs = static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr);
+    a.abundance = ctx->db.abundance;
+    a.est = static_cast<uint32_t *>(ctx->d_scan_est.ptr);
+    a.swarmed = static_cast<uint8_t *>(ctx->d_scan_swarmed.ptr);
+    a.n = n; a.lo = lo; a.nseeds = nseeds;
+    a.seeds = static_cast<const uint32_t *>(ctx->d_scan_seeds.ptr);
+    a.limits = a.seeds + nseeds;
+    a.first_generation = first_generation != 0 ? 1u : 0u;
+    a.d = d;
+    a.ncb = no_cluster_breaking != 0 ? 1u : 0u;
+    a.t_query = static_cast<uint32_t *>(ctx->d_scan_targets.ptr);
+    a.t_target = a.t_query + pair_cap;
+    a.t_seedidx = a.t_target + pair_cap;
+    a.cap = (uint32_t)std::min<uint64_t>(pair_cap, 0xFFFFFFFFull);
+    a.counters = counters;
+    a.totals = totals;
+    auto * hits = static_cast<uint32_t *>(ctx->d_scan_hits.ptr);
+    SWA_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+    if (a.first_generation != 0u) {                    // the initial seed joins its own swarm
+      hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, ctx->stream, a.swarmed, a.seeds, 1u);
+    }
+    if (span > 0) {
+      uint64_t blocks = ((uint64_t)span + 31) / 32;
+      const uint64_t gcap = std::max<uint64_t>(1, uint64_t(ctx->num_cus) * 8 / nseeds);
+      if (blocks > gcap) { blocks = gcap; }
+      hipLaunchKernelGGL(k_scan_filter, dim3((unsigned)blocks, nseeds), dim3(256), 0, ctx->stream, a);
+      SWA_HIP(ctx, hipGetLastError());
+      const uint64_t max_pairs = std::min<uint64_t>((uint64_t)span * nseeds, a.cap);
+      SWA_TRY(swa_align_launch(ctx, 0, a.t_query, a.t_target, counters, (uint32_t)max_pairs,
+                               static_cast<uint32_t *>(ctx->d_scan_diffs.ptr), nullptr, nullptr));
+      hipLaunchKernelGGL(k_scan_collect, dim3(64), dim3(256), 0, ctx->stream, a.t_target, a.t_seedidx,
+                         static_cast<const uint32_t *>(ctx->d_scan_diffs.ptr), counters, a.cap, d, a.swarmed, hits + 4,
+                         totals);
+      SWA_HIP(ctx, hipGetLastError());
+    }
+    // one read-back: [pairs, hits, overflow, 0] + the first kInlineHits triples
+    SWA_HIP(ctx, hipMemcpyAsync(hits, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->scan_host.resize(4 + 3 * (size_t)kInlineHits);
+    SWA_HIP(ctx, hipMemcpyAsync(ctx->scan_host.data(), hits, ctx->scan_host.size() * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scan_host[2] != 0u) {
+      // more (seed, target) pairs than the buffers hold.  Nothing irreversible happened (est
+      // stores are idempotent, k_scan_collect marks nothing when the flag is set), so grow and
+      // run the batch again.
+      pair_cap = std::max<uint64_t>(2 * pair_cap, (uint64_t)ctx->scan_host[0] + 1024);
+      continue;
+    }
+    got = ctx->scan_host[1];
+    if (got > kInlineHits) {
+      ctx->scan_host.resize(4 + 3 * (size_t)got);
+      SWA_HIP(ctx, hipMemcpyAsync(ctx->scan_host.data() + 4, hits + 4, 3 * (size_t)got * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+      SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    break;
+  }
+  *nhits = got;
+  // queue order of the seeds, then pool (= id) order of the targets; kept in the context so
+  // that a caller whose buffers were too small can fetch the result after growing them
+  struct Hit { uint32_t sidx, id, diff; };
+  const auto * triples = reinterpret_cast<const Hit *>(ctx->scan_host.data() + 4);
+  ctx->scan_sorted.resize(got);
+  for (uint32_t k = 0; k < got; ++k) { ctx->scan_sorted[k] = ((uint64_t)triples[k].sidx << 32) | triples[k].id; }
+  std::vector<uint32_t> & perm = ctx->scan_perm;
+  perm.resize(got);
+  for (uint32_t k = 0; k < got; ++k) { perm[k] = k; }
+  std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return ctx->scan_sorted[x] < ctx->scan_sorted[y]; });
+  if (got > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_scan_batch: hit buffer too small, use swa_scan_fetch"); }
+  return swa_scan_fetch(ctx, hit_seedidx, hit_ids, hit_diffs, cap);
+}
+
+// copies the (sorted) hits of the most recent swa_scan_batch; cap must be >= its *nhits
+extern "C" int swa_scan_fetch(swa_ctx * ctx, uint32_t * hit_seedidx, uint32_t * hit_ids, uint32_t * hit_diffs,
+                              uint32_t cap) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  const uint32_t got = (uint32_t)ctx->scan_perm.size();
+  if (got > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_scan_fetch: hit buffer too small"); }
+  struct Hit { uint32_t sidx, id, diff; };
+  const auto * triples = reinterpret_cast<const Hit *>(ctx->scan_host.data() + 4);
+  for (uint32_t k = 0; k < got; ++k) {
+    const Hit & h = triples[ctx->scan_perm[k]];
+    if (hit_seedidx != nullptr) { hit_seedidx[k] = h.sidx; }
+    hit_ids[k] = h.id;
+    hit_diffs[k] = h.diff;
+  }
+  return SWA_OK;
+}
+
+// single (sub)seed convenience form
 extern "C" int swa_scan_step(swa_ctx * ctx, uint32_t seed, uint32_t lowest_unswarmed, int first_generation,
                              uint32_t radius, int no_cluster_breaking, uint32_t * hit_ids, uint32_t * hit_diffs,
                              uint32_t cap, uint32_t * nhits) {
   if (ctx == nullptr) { return SWA_E_ARG; }
-  if (!ctx->scan_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_scan_step: call swa_scan_begin first"); }
-  if (seed >= ctx->db.n || nhits == nullptr || (cap != 0 && (hit_ids == nullptr || hit_diffs == nullptr))) {
-    return swa_fail_msg(ctx, SWA_E_ARG, "swa_scan_step: bad argument");
-  }
-  SWA_HIP(ctx, hipSetDevice(ctx->device));
-  const uint32_t n = ctx->db.n;
-  auto * counters = static_cast<uint32_t *>(ctx->d_scan_counters.ptr);          // u32[4] then u64 totals[4]
-  auto * totals = reinterpret_cast<unsigned long long *>(counters + 4);
-  auto * hits = static_cast<uint32_t *>(ctx->d_scan_hits.ptr);
-  ScanArgs a{};
-  a.sigs = static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr);
-  a.abundance = ctx->db.abundance;
-  a.est = static_cast<uint32_t *>(ctx->d_scan_est.ptr);
-  a.swarmed = static_cast<uint8_t *>(ctx->d_scan_swarmed.ptr);
-  a.n = n;
-  a.lo = lowest_unswarmed < n ? lowest_unswarmed : n;
-  a.seed = seed;
-  a.first_generation = first_generation != 0 ? 1u : 0u;
-  a.limit = radius + (uint32_t)ctx->resolution;
-  a.d = (uint32_t)ctx->resolution;
-  a.ncb = no_cluster_breaking != 0 ? 1u : 0u;
-  a.targets = static_cast<uint32_t *>(ctx->d_scan_targets.ptr);
-  a.counters = counters;
-  a.totals = totals;
-  SWA_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), ctx->stream));
-  if (a.first_generation != 0u) {                      // the initial seed joins its own swarm
-    SWA_HIP(ctx, hipMemsetAsync(a.swarmed + seed, 1, 1, ctx->stream));
-  }
-  const uint32_t span = n - a.lo;
-  if (span > 0) {
-    uint64_t blocks = ((uint64_t)span + 31) / 32;
-    const uint64_t gcap = uint64_t(ctx->num_cus) * 8;
-    if (blocks > gcap) { blocks = gcap; }
-    hipLaunchKernelGGL(k_scan_filter, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-    SWA_HIP(ctx, hipGetLastError());
-    SWA_TRY(swa_align_launch(ctx, seed, a.targets, counters, span, static_cast<uint32_t *>(ctx->d_scan_diffs.ptr),
-                             nullptr, nullptr));
-    hipLaunchKernelGGL(k_scan_collect, dim3(64), dim3(256), 0, ctx->stream, a.targets,
-                       static_cast<const uint32_t *>(ctx->d_scan_diffs.ptr), counters, a.d, a.swarmed, hits + 2, totals);
-    SWA_HIP(ctx, hipGetLastError());
-  }
-  // one read-back: [target count, hit count] + the first kInlineHits (id, diff) pairs
-  SWA_HIP(ctx, hipMemcpyAsync(hits, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-  ctx->scan_host.resize(2 + 2 * kInlineHits);
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->scan_host.data(), hits, ctx->scan_host.size() * sizeof(uint32_t),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t got = ctx->scan_host[1];
-  *nhits = got;
-  if (got > kInlineHits) {
-    ctx->scan_host.resize(2 + 2 * (size_t)got);
-    SWA_HIP(ctx, hipMemcpyAsync(ctx->scan_host.data() + 2, hits + 2, 2 * (size_t)got * sizeof(uint32_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  if (got > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_scan_step: hit buffer too small"); }
-  // pool order = ascending amplicon id
-  ctx->scan_sorted.resize(got);
-  const uint32_t * pairs = ctx->scan_host.data() + 2;
-  for (uint32_t k = 0; k < got; ++k) { ctx->scan_sorted[k] = ((uint64_t)pairs[2 * k] << 32) | pairs[2 * k + 1]; }
-  std::sort(ctx->scan_sorted.begin(), ctx->scan_sorted.end());
-  for (uint32_t k = 0; k < got; ++k) {
-    hit_ids[k] = (uint32_t)(ctx->scan_sorted[k] >> 32);
-    hit_diffs[k] = (uint32_t)ctx->scan_sorted[k];
-  }
-  totals = nullptr;
-  return SWA_OK;
+  ctx->scan_idx_tmp.resize(cap > 0 ? cap : 1);
+  uint32_t * idx = ctx->scan_idx_tmp.data();   // (scan_batch does not touch scan_idx_tmp)
+  return swa_scan_batch(ctx, 1, &seed, &radius, lowest_unswarmed, first_generation, no_cluster_breaking, idx, hit_ids,
+                        hit_diffs, cap, nhits);
 }
 
 extern "C" int swa_scan_totals(swa_ctx * ctx, uint64_t * out3) {
@@ -183,6 +279,6 @@ extern "C" int swa_scan_totals(swa_ctx * ctx, uint64_t * out3) {
   uint64_t t[4] = {};
   SWA_HIP(ctx, hipMemcpyAsync(t, static_cast<uint32_t *>(ctx->d_scan_counters.ptr) + 4, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  out3[0] = t[0]; out3[1] = t[1]; out3[2] = t[2];
+  out3[0] = t[0]; out3[1] = t[1]; out3[2] = ctx->scan_launches;
   return SWA_OK;
 }

@@ -65,8 +65,11 @@ struct swa_ctx {
   // fused d >= 2 scan state (scan.hip)
   bool scan_ready = false;
   swa_dbuf d_scan_est, d_scan_swarmed, d_scan_targets, d_scan_diffs, d_scan_hits, d_scan_counters;
-  std::vector<uint32_t> scan_host;
+  swa_dbuf d_scan_seeds;
+  std::vector<uint32_t> scan_host, scan_perm, scan_idx_tmp;
   std::vector<uint64_t> scan_sorted;
+  uint64_t scan_pair_cap = 0;
+  uint64_t scan_launches = 0;
 
   // fastidious state
   swa_dbuf d_light, d_graft, d_bloomflex, d_fpatterns, d_queue, d_fcounters;
