@@ -24,6 +24,7 @@
 // All arithmetic is 64-bit integer XOR/shift/compare; results are bit-exact.
 #include "swa_internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -57,15 +58,23 @@ struct NetArgs {
   uint32_t first;
   uint32_t count;
   uint64_t * edges;             // (src << 32) | dst
-  uint64_t edge_cap;
-  unsigned long long * edge_counter;
+  uint64_t seg_cap;             // edges are appended to per-wave segments: segment w = edges[w*seg_cap ..)
+  uint32_t * seg_fill;          // [launch waves] fill of each segment (no atomics: one writer per segment)
   uint32_t * counts;            // per query amplicon (index k = amp - first)
   unsigned long long * stats;   // [0] variants [1] bloom pass [2] hash match [3] verified
+  // MODE 2 (seeds the anchored passes cannot serve): explicit (seed, position range) list
+  const struct swa_fallback * fallback;
+  const uint32_t * fallback_count;
+  const struct swa_aux * aux;
   // MODE 1 (fastidious second level)
   const swa_task * tasks;
   uint32_t * graft;
   unsigned long long * cand_counter;
 };
+
+#define SWA_ANCHOR_TYPES_ONLY
+#include "d1_anchor.inc"
+#undef SWA_ANCHOR_TYPES_ONLY
 
 // ---- sequence hashes (db.cc:761 zobrist_hash) --------------------------------------
 template <bool ZLDS>
@@ -73,7 +82,8 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
                                                  const uint64_t * __restrict__ seq_off,
                                                  const uint32_t * __restrict__ seqlen,
                                                  const uint64_t * __restrict__ zobrist, uint32_t zlen,
-                                                 uint32_t n, uint64_t * __restrict__ seqhash) {
+                                                 uint32_t n, uint64_t * __restrict__ seqhash,
+                                                 swa_aux * __restrict__ aux) {
   extern __shared__ uint64_t lds[];
   const uint64_t * zob = zobrist;
   if (ZLDS) {
@@ -84,14 +94,22 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
   for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
     const uint64_t * s = seqs + seq_off[a];
     const uint32_t len = seqlen[a];
-    uint64_t h = 0;
+    uint64_t h = 0, dall = 0, iall = 0;
     uint64_t word = 0;
+    swa_aux ax{};
     for (uint32_t p = 0; p < len; ++p) {
       if ((p & 31u) == 0u) { word = s[p >> 5]; }
-      h ^= zob[4u * p + (uint32_t)(word & 3u)];
+      if (p == kAnchor) { ax.a32 = h; ax.d32 = dall; ax.i32 = iall; }      // the three streams below position 32
+      const uint32_t c = (uint32_t)(word & 3u);
+      h ^= zob[4u * p + c];
+      if (p >= 1u) { dall ^= zob[4u * (p - 1u) + c]; }
+      iall ^= zob[4u * (p + 1u) + c];
       word >>= 2;
     }
+    if (len <= kAnchor) { ax.a32 = h; ax.d32 = dall; ax.i32 = iall; }
+    ax.h = h; ax.dall = dall; ax.iall = iall;
     seqhash[a] = h;
+    aux[a] = ax;
   }
 }
 
@@ -315,13 +333,20 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
 
   unsigned long long st_var = 0, st_pass = 0, st_match = 0, st_ver = 0;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
+  // this wave's private output segment (a single shared edge counter costs one contended
+  // returning atomic per query — measured: ~88 atomics/us on one address bound the kernel)
+  const uint32_t gwave = blockIdx.x * kWaves + wave;
+  uint32_t seg_at = (MODE == 1) ? 0u : a.seg_fill[gwave];
 
   const uint32_t nwaves = gridDim.x * kWaves;
-  for (uint32_t k = blockIdx.x * kWaves + wave; k < a.count; k += nwaves) {
+  const uint32_t nqueries = (MODE == 2) ? *a.fallback_count : a.count;
+  for (uint32_t k = blockIdx.x * kWaves + wave; k < nqueries; k += nwaves) {
     uint32_t seed, len, nw;
+    uint32_t range = 0;                                      // MODE 2: 0 all positions, 1 p >= 32, 2 p < 32
     uint64_t seed_ab = 0;
-    if (MODE == 0) {
-      seed = a.first + k;
+    if (MODE == 0 || MODE == 2) {
+      if (MODE == 2) { seed = a.fallback[k].seed; range = a.fallback[k].range; }
+      else { seed = a.first + k; }
       len = a.seqlen[seed];
       nw = (len + 31u) >> 5;
       const uint64_t * gs = a.seqs + a.seq_off[seed];
@@ -360,14 +385,12 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
       }
       if (hm != 0ull) {
         const uint32_t nh = (uint32_t)__popcll(hm);
-        if (MODE == 0) {
-          unsigned long long base = 0;
-          if (lane == 0) { base = atomicAdd(a.edge_counter, (unsigned long long)nh); }
-          base = swa_shfl_u64(base, 0);
+        if (MODE == 0 || MODE == 2) {
           if (hit) {
-            const unsigned long long at = base + (unsigned long long)__popcll(hm & lane_lt);
-            if (at < a.edge_cap) { a.edges[at] = ((uint64_t)seed << 32) | amp; }
+            const uint64_t at = (uint64_t)seg_at + (uint64_t)__popcll(hm & lane_lt);
+            if (at < a.seg_cap) { a.edges[(uint64_t)gwave * a.seg_cap + at] = ((uint64_t)seed << 32) | amp; }
           }
+          seg_at += nh;
         } else {
           if (hit) { atomicMin(&a.graft[amp], seed); }
         }
@@ -400,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
     };
 
     // 8 Bloom-word loads in flight per lane, then test + compact
-    (void)enumerate_variants(sw, len, zob, lane, [&](const Slots & s) {
+    auto probe_slots = [&](const auto & s) {
       uint64_t word[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -412,18 +435,31 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
         if (STATS) { st_var += (unsigned long long)__popcll(__ballot(s.ok[i])); }
         enqueue(pass, s.hs[i], s.code[i]);
       }
-    });
+    };
+    if (MODE == 2) {
+      const swa_aux ax = a.aux[seed];
+      const uint32_t pb = range == 1u ? kAnchor : 0u;
+      const uint32_t pe = range == 2u ? kAnchor : len + 1u;
+      enumerate_range(sw, len, zob, lane, pb, pe < len + 1u ? pe : len + 1u, ax.h, range == 1u ? ax.a32 : 0ull,
+                      range == 1u ? (ax.dall ^ ax.d32) : ax.dall, range == 1u ? (ax.iall ^ ax.i32) : ax.iall,
+                      probe_slots);
+    } else {
+      (void)enumerate_variants(sw, len, zob, lane, probe_slots);
+    }
     if (qn > 0u) {
       wave_lds_sync();
       drain(qn);
     }
     if (MODE == 0) {
       if (lane == 0) { a.counts[k] = row; }
+    } else if (MODE == 2) {
+      if (lane == 0 && row != 0u) { atomicAdd(&a.counts[seed - a.first], row); }
     } else {
       if (lane == 0 && row != 0u) { atomicAdd(a.cand_counter, (unsigned long long)row); }
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (MODE != 1 && lane == 0) { a.seg_fill[gwave] = seg_at; }
   if (STATS && lane == 0) {
     atomicAdd(&a.stats[0], st_var);
     atomicAdd(&a.stats[1], st_pass);
@@ -431,6 +467,8 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
     atomicAdd(&a.stats[3], st_ver);
   }
 }
+
+#include "d1_anchor.inc"
 
 // ---- fastidious first level (algod1.cc:495-518 mark_light_var, 398-450 check_heavy_var) ---
 struct FlexArgs {
@@ -602,16 +640,39 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t * __re
   }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_edges(const uint64_t * __restrict__ edges, uint64_t n_edges,
-                                                       uint32_t first, const uint64_t * __restrict__ offsets,
-                                                       uint32_t * cursor, uint32_t * __restrict__ neighbours,
-                                                       uint64_t cap) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += stride) {
-    const uint64_t edge = edges[e];
-    const uint32_t k = (uint32_t)(edge >> 32) - first;
-    const uint64_t at = offsets[k] + atomicAdd(&cursor[k], 1u);
-    if (at < cap) { neighbours[at] = (uint32_t)edge; }
+// total and largest fill of the per-wave edge segments -> out[0], out[1]
+__global__ __launch_bounds__(256) void k_seg_reduce(const uint32_t * __restrict__ seg_fill, uint32_t nseg,
+                                                    unsigned long long * out) {
+  __shared__ unsigned long long ssum[256];
+  __shared__ unsigned long long smax[256];
+  unsigned long long sum = 0, mx = 0;
+  for (uint32_t i = threadIdx.x; i < nseg; i += 256u) { sum += seg_fill[i]; mx = mx > seg_fill[i] ? mx : seg_fill[i]; }
+  ssum[threadIdx.x] = sum; smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + o];
+      smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + o] ? smax[threadIdx.x] : smax[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = ssum[0]; out[1] = smax[0]; }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_edges(const uint64_t * __restrict__ edges,
+                                                       const uint32_t * __restrict__ seg_fill, uint32_t nseg,
+                                                       uint64_t seg_cap, uint32_t first,
+                                                       const uint64_t * __restrict__ offsets, uint32_t * cursor,
+                                                       uint32_t * __restrict__ neighbours, uint64_t cap) {
+  for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const uint32_t fill = seg_fill[seg];
+    const uint64_t * e = edges + (uint64_t)seg * seg_cap;
+    for (uint32_t j = threadIdx.x; j < fill; j += blockDim.x) {
+      const uint64_t edge = e[j];
+      const uint32_t k = (uint32_t)(edge >> 32) - first;
+      const uint64_t at = offsets[k] + atomicAdd(&cursor[k], 1u);
+      if (at < cap) { neighbours[at] = (uint32_t)edge; }
+    }
   }
 }
 
@@ -678,6 +739,148 @@ int swa_d1_rebuild_table(swa_ctx * ctx, const uint8_t * d_is_member) {
   return SWA_OK;
 }
 
+
+// ---- the anchored index (see d1_anchor.inc) -------------------------------------------------
+static bool anchored_enabled() {
+  const char * e = getenv("SWA_D1_PLAIN");
+  return !(e != nullptr && e[0] == '1');
+}
+
+static int build_anchor_index(swa_ctx * ctx) {
+  ctx->anchor_ready = false;
+  // (the anchored kernel prefetches a seed's words into kPrefetchWords registers per lane)
+  if (!anchored_enabled() || ctx->db.longest < kMinAnchoredLen || ctx->db.longest > 64u * kPrefetchWords * 32u - 64u) {
+    return SWA_OK;
+  }
+  const uint32_t n = ctx->db.n;
+  uint64_t asize = 64;
+  while (asize < 2ull * n) { asize <<= 1; }
+  ctx->anchor_slots = asize;
+  for (int which = 0; which < 2; ++which) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_akeys[which], asize * sizeof(uint64_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_acounts[which], asize * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_acursor[which], asize * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_aoffsets[which], (asize + 1) * sizeof(uint64_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_aslot[which], uint64_t(n) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_amembers[which], uint64_t(n) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], (uint64_t(n) + 128) * sizeof(swa_item)));   // big | small halves
+  }
+  SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
+  const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
+  for (int which = 0; which < 2; ++which) {
+    auto * keys = static_cast<unsigned long long *>(ctx->d_akeys[which].ptr);
+    auto * counts = static_cast<uint32_t *>(ctx->d_acounts[which].ptr);
+    auto * cursor = static_cast<uint32_t *>(ctx->d_acursor[which].ptr);
+    auto * offsets = static_cast<uint64_t *>(ctx->d_aoffsets[which].ptr);
+    auto * slot_of = static_cast<uint32_t *>(ctx->d_aslot[which].ptr);
+    hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, keys, counts, cursor, asize);
+    AnchorBuildArgs b{};
+    b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n; b.which = which;
+    b.keys = keys; b.counts = counts; b.amask = asize - 1; b.slot_of = slot_of;
+    hipLaunchKernelGGL(k_anchor_insert, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, counts, (uint32_t)asize,
+                       static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, counts, (uint32_t)asize,
+                       static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), offsets);
+    hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, slot_of, n, offsets, cursor,
+                       static_cast<uint32_t *>(ctx->d_amembers[which].ptr));
+    hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, counts, offsets, asize,
+                       static_cast<swa_item *>(ctx->d_aitems[which].ptr), static_cast<uint32_t *>(ctx->d_acounters.ptr) + which,
+                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + (n / 2 + 64),
+                       static_cast<uint32_t *>(ctx->d_acounters.ptr) + 3 + which);
+    SWA_HIP(ctx, hipGetLastError());
+  }
+  ctx->anchor_ready = true;
+  return SWA_OK;
+}
+
+// anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
+// the plain kernel; edges / counts / edge counter as launch_network leaves them
+static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count) {
+  // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items
+  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
+  SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(acounters + 2, 0, sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(acounters + 16, 0, 16 * sizeof(uint32_t), ctx->stream));   // work counters of both passes
+  const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
+  const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
+  auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
+  swa_t0(ctx, 3);
+  for (int pass = 0; pass < 2; ++pass) {
+    AnchorArgs a{};
+    a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen; a.abundance = ctx->db.abundance;
+    a.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
+    a.zlen = ctx->zobrist_len; a.maxwords = maxwords;
+    a.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
+    a.members = static_cast<const uint32_t *>(ctx->d_amembers[pass].ptr);
+    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
+    a.item_count = acounters + pass;
+    a.pass = pass;
+    a.no_cluster_breaking = ncb;
+    a.first = first; a.count = count;
+    a.edges = static_cast<uint64_t *>(ctx->d_edges.ptr);
+    a.seg_cap = ctx->seg_cap;
+    a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
+    a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
+    const size_t common = (zlds ? 4ull * ctx->zobrist_len : 0ull) +
+                          kWaves * (2 * (size_t)(maxwords + 2u) + kRing);
+    const int grid = ctx->num_cus * 8;
+    // small groups: one wave per group
+    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr) + (ctx->db.n / 2 + 64);
+    a.item_count = acounters + 3 + pass;
+    a.sched = acounters + 16 + 8 * pass;
+    a.table_slots = 2 * kSmallGroup;
+    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup / 4));
+    if (zlds) { hipLaunchKernelGGL((k_d1_anchor<true, true>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_d1_anchor<false, true>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
+    // big groups: one workgroup per 64-seed chunk
+    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
+    a.item_count = acounters + pass;
+    a.table_slots = 2 * kGroupCap;
+    const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 8);
+    if (zlds) { hipLaunchKernelGGL((k_d1_anchor<true, false>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_d1_anchor<false, false>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    SWA_HIP(ctx, hipGetLastError());
+  }
+  // seeds (or halves of seeds) the anchored passes skipped
+  hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
+                     count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
+                     static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
+                     static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2);
+  NetArgs f{};
+  f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
+  f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
+  f.zlen = ctx->zobrist_len; f.maxwords = maxwords;
+  f.table = static_cast<const swa_slot *>(ctx->d_table.ptr);
+  f.tmask = ctx->table_size - 1;
+  f.bloom = static_cast<const uint64_t *>(ctx->d_bloom.ptr);
+  f.bmask = ctx->bloom_words - 1;
+  f.patterns = static_cast<const uint64_t *>(ctx->d_patterns.ptr);
+  f.no_cluster_breaking = ncb;
+  f.first = first; f.count = count;
+  f.edges = static_cast<uint64_t *>(ctx->d_edges.ptr);
+  f.seg_cap = ctx->seg_cap;
+  f.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
+  f.stats = stats;
+  f.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
+  f.fallback = static_cast<const swa_fallback *>(ctx->d_afallback.ptr);
+  f.fallback_count = acounters + 2;
+  f.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
+  const size_t flds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull +
+                                          kWaves * ((size_t)(maxwords + 2u) + kQueueCap + kQueueCap / 2));
+  const int fgrid = grid_for(ctx, count, kWaves, 8);
+  if (zlds) { hipLaunchKernelGGL((k_d1_probe<true, false, 2>), dim3(fgrid), dim3(kThreads), flds, ctx->stream, f); }
+  else { hipLaunchKernelGGL((k_d1_probe<false, false, 2>), dim3(fgrid), dim3(kThreads), flds, ctx->stream, f); }
+  swa_t1(ctx, 3);
+  SWA_HIP(ctx, hipGetLastError());
+  return SWA_OK;
+}
+
 extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   if (ctx == nullptr) { return SWA_E_ARG; }
   if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build: no database"); }
@@ -696,6 +899,7 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   SWA_TRY(swa_reserve(ctx, ctx->d_zobrist, zob.size() * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_patterns, pat.size() * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_seqhash, uint64_t(n) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_aux, uint64_t(n) * sizeof(swa_aux)));
   SWA_TRY(swa_reserve(ctx, ctx->d_table, ctx->table_size * sizeof(swa_slot)));
   SWA_TRY(swa_reserve(ctx, ctx->d_bloom, ctx->bloom_words * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
@@ -711,11 +915,11 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   if (zbytes <= kMaxZobristLds) {
     hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                        ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr));
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr));
   } else {
     hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                        ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr));
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr));
   }
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 0);
@@ -729,6 +933,9 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
                      static_cast<uint32_t *>(ctx->d_flags.ptr));
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 2);
+  swa_t0(ctx, 7);
+  SWA_TRY(build_anchor_index(ctx));
+  swa_t1(ctx, 7);
   uint32_t flag = 0;
   SWA_HIP(ctx, hipMemcpyAsync(&flag, ctx->d_flags.ptr, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -764,9 +971,9 @@ static int launch_network(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count
   a.no_cluster_breaking = ncb;
   a.first = first; a.count = count;
   a.edges = static_cast<uint64_t *>(ctx->d_edges.ptr);
-  a.edge_cap = ctx->d_edges.bytes / sizeof(uint64_t);
+  a.seg_cap = ctx->seg_cap;
+  a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
   a.stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
-  a.edge_counter = a.stats + 8;
   a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
@@ -802,18 +1009,29 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
   SWA_TRY(swa_reserve(ctx, ctx->d_cursor, uint64_t(count) * sizeof(uint32_t)));
   const uint32_t tiles = (count + kScanTile - 1) / kScanTile;
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
-  if (ctx->d_edges.bytes == 0) {
-    SWA_TRY(swa_reserve(ctx, ctx->d_edges, (uint64_t(count) * 4 + 1024) * sizeof(uint64_t)));
+  // hits leave the kernels through per-wave segments of the edge buffer (no shared counter)
+  const uint32_t nseg = (uint32_t)ctx->num_cus * 8u * kWaves;          // >= waves of any launch below
+  SWA_TRY(swa_reserve(ctx, ctx->d_seg_fill, uint64_t(nseg) * sizeof(uint32_t)));
+  if (ctx->seg_cap == 0) {
+    ctx->seg_cap = 512;
+    while (ctx->seg_cap < 8ull * count / nseg) { ctx->seg_cap <<= 1; }
   }
   uint64_t n_edges = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    SWA_TRY(launch_network(ctx, no_cluster_breaking, first, count, stats));
-    SWA_HIP(ctx, hipMemcpyAsync(&n_edges, static_cast<uint64_t *>(ctx->d_stats.ptr) + 8, sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
+    SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, uint64_t(nseg) * sizeof(uint32_t), ctx->stream));
+    if (ctx->anchor_ready && !stats) { SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count)); }
+    else { SWA_TRY(launch_network(ctx, no_cluster_breaking, first, count, stats)); }
+    hipLaunchKernelGGL(k_seg_reduce, dim3(1), dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
+                       nseg, static_cast<unsigned long long *>(ctx->d_stats.ptr) + 8);
+    uint64_t got[2] = {0, 0};
+    SWA_HIP(ctx, hipMemcpyAsync(got, static_cast<uint64_t *>(ctx->d_stats.ptr) + 8, sizeof(got), hipMemcpyDeviceToHost,
+                                ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (n_edges * sizeof(uint64_t) <= ctx->d_edges.bytes) { break; }
-    // edge list did not fit: grow to the exact need and run again (rare: > 4 hits / amplicon)
-    SWA_TRY(swa_reserve(ctx, ctx->d_edges, n_edges * sizeof(uint64_t)));
+    n_edges = got[0];
+    if (got[1] <= ctx->seg_cap) { break; }
+    // one wave found more hits than its segment holds: grow the segments and run again (rare)
+    while (ctx->seg_cap < got[1]) { ctx->seg_cap <<= 1; }
   }
   *total = n_edges;
   // CSR: offsets are always complete; neighbours only if they fit
@@ -832,9 +1050,9 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
   }
   if (n_edges > 0) {
     SWA_HIP(ctx, hipMemsetAsync(ctx->d_cursor.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_scatter_edges, dim3(grid_for(ctx, n_edges, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint64_t *>(ctx->d_edges.ptr), n_edges, first, d_offsets,
-                       static_cast<uint32_t *>(ctx->d_cursor.ptr), d_neighbours, cap);
+    hipLaunchKernelGGL(k_scatter_edges, dim3(std::min<uint32_t>(nseg, (uint32_t)ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint64_t *>(ctx->d_edges.ptr), static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
+                       nseg, ctx->seg_cap, first, d_offsets, static_cast<uint32_t *>(ctx->d_cursor.ptr), d_neighbours, cap);
     hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, d_offsets, count,
                        d_neighbours, cap);
     hipLaunchKernelGGL(k_sort_long_rows, dim3(grid_for(ctx, count, 1, 16)), dim3(64), 0, ctx->stream, d_offsets,

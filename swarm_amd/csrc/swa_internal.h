@@ -55,6 +55,13 @@ struct swa_ctx {
   swa_dbuf d_stats;              // u64[8] probe statistics + [8] edge counter
   swa_dbuf d_edges;              // u64 edge list (src << 32 | dst)
   swa_dbuf d_counts, d_cursor, d_scan_tmp, d_offsets_tmp, d_nb_tmp;
+  // anchored d=1 index (d1_anchor.inc): [0] prefix groups, [1] suffix groups
+  bool anchor_ready = false;
+  uint64_t anchor_slots = 0;
+  swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_acursor[2], d_aoffsets[2], d_aslot[2], d_amembers[2], d_aitems[2];
+  swa_dbuf d_acounters, d_afallback;
+  swa_dbuf d_seg_fill;           // u32 fill of every per-wave edge segment
+  uint64_t seg_cap = 0;          // entries per segment
 
   // q-gram / alignment state
   bool qgram_ready = false;
