@@ -81,8 +81,9 @@ int  swa_ctx_synchronize(swa_ctx * ctx);
 
 /* Per-kernel timing with HIP events on the context's stream (off by default).
    swa_timing_read: ms[0] seqhash, [1] table+Bloom build, [2] duplicate check,
-   [3] d1 network kernel, [4] CSR assembly, [5] fastidious light pass, [6] fastidious
-   heavy pass, [7] reserved — durations of the most recent launches. */
+   [3] d1 network kernels (anchored passes + fallback, or the plain kernel), [4] CSR assembly,
+   [5] fastidious light pass, [6] fastidious heavy pass, [7] anchored-index build — durations
+   of the most recent launches. */
 int  swa_timing_enable(swa_ctx * ctx, int on);
 int  swa_timing_read(swa_ctx * ctx, float * ms8);
 

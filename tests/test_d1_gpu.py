@@ -115,3 +115,66 @@ def test_full_size_1m_properties(gpu_ctx, tmp_path):
         woff, wnb, _ = _oracle_sorted_rows(db, False, int(first), 2000)
         lo, hi = int(off2[first]), int(off2[first + 2000])
         assert np.array_equal(nb2[lo:hi], wnb)
+
+
+def _check_vs_oracle(ctx, db, ncb=False):
+    _upload(ctx, db)
+    assert ctx.d1_index_build() is False
+    off, nb = ctx.d1_network(ncb)
+    woff, wnb, _ = _oracle_sorted_rows(db, ncb)
+    assert np.array_equal(off, woff)
+    assert np.array_equal(nb, wnb)
+    return off, nb
+
+
+def test_giant_anchor_groups_fall_back(gpu_ctx):
+    """> 2048 amplicons sharing the same first AND last 32 nt: the anchored passes hand those
+    seeds (per position range) to the plain kernel; the result must not change."""
+    rng = np.random.default_rng(99)
+    head = "".join(rng.choice(list("ACGT"), size=40))
+    tail = "".join(rng.choice(list("ACGT"), size=40))
+    mids = set()
+    while len(mids) < 2600:
+        mids.add("".join(rng.choice(list("ACGT"), size=int(rng.integers(5, 8)))))
+    seqs = [head + m + tail for m in sorted(mids)]
+    # plus a few ordinary clusters so that small and big groups coexist
+    for k in range(30):
+        base = "".join(rng.choice(list("ACGT"), size=120))
+        seqs.append(base)
+        for j in range(100):
+            p = int(rng.integers(0, 120))
+            seqs.append(base[:p] + "ACGT"[(("ACGT".index(base[p])) + 1 + j % 3) % 4] + base[p + 1:])
+    seqs = sorted(set(seqs))
+    db = S.build_db([(f"s{i}_{1 + (i * 13) % 40}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    off, nb = _check_vs_oracle(gpu_ctx, db)
+    assert len(nb) > 1000
+
+
+def test_short_and_long_sequences_mix(gpu_ctx):
+    """lengths around the anchoring thresholds (32, 64/65) and far above"""
+    rng = np.random.default_rng(7)
+    seqs = set()
+    for L in (20, 31, 32, 33, 40, 63, 64, 65, 66, 70, 96, 97, 128, 129, 200):
+        for k in range(6):
+            base = "".join(rng.choice(list("ACGT"), size=L))
+            seqs.add(base)
+            for j in range(25):
+                u = rng.random()
+                p = int(rng.integers(0, L))
+                if u < 0.4:
+                    seqs.add(base[:p] + "ACGT"[int(rng.integers(0, 4))] + base[p + 1:])
+                elif u < 0.7:
+                    seqs.add(base[:p] + base[p + 1:])
+                else:
+                    seqs.add(base[:p] + "ACGT"[int(rng.integers(0, 4))] + base[p:])
+    seqs = sorted(seqs)
+    db = S.build_db([(f"s{i}_{1 + (i * 7) % 9}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    _check_vs_oracle(gpu_ctx, db)
+    _check_vs_oracle(gpu_ctx, db, ncb=True)
+
+
+def test_very_long_sequences_use_plain_kernel(gpu_ctx, tmp_path):
+    fa = tmp_path / "long.fa"
+    S.gen_fasta(fa, 120, 5000, 31)
+    db = S.db_from_fasta(fa)
+    _check_vs_oracle(gpu_ctx, db)
