@@ -332,6 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
   const uint64_t * zob = ZLDS ? zob_lds : a.zobrist;
 
   unsigned long long st_var = 0, st_pass = 0, st_match = 0, st_ver = 0;
+  unsigned long long cand_total = 0;                         // MODE 1: graft candidates found by this wave
   const uint64_t lane_lt = (1ull << lane) - 1ull;
   // this wave's private output segment (a single shared edge counter costs one contended
   // returning atomic per query — measured: ~88 atomics/us on one address bound the kernel)
@@ -455,11 +456,12 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
     } else if (MODE == 2) {
       if (lane == 0 && row != 0u) { atomicAdd(&a.counts[seed - a.first], row); }
     } else {
-      if (lane == 0 && row != 0u) { atomicAdd(a.cand_counter, (unsigned long long)row); }
+      cand_total += row;
     }
     __builtin_amdgcn_wave_barrier();
   }
   if (MODE != 1 && lane == 0) { a.seg_fill[gwave] = seg_at; }
+  if (MODE == 1 && lane == 0 && cand_total != 0ull) { atomicAdd(a.cand_counter, cand_total); }
   if (STATS && lane == 0) {
     atomicAdd(&a.stats[0], st_var);
     atomicAdd(&a.stats[1], st_pass);
@@ -512,6 +514,12 @@ __global__ __launch_bounds__(kThreads) void k_d1_flex(const FlexArgs a) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   uint64_t * sw = wave_base + (size_t)wave * seed_words;
+  // PASS 1 stages its surviving tasks in LDS and reserves space in the global task list in
+  // bulk: one returning atomic per ~200 tasks instead of one per ballot (a single address
+  // sustains only ~88 atomics/us, which bound this kernel)
+  constexpr uint32_t kStage = 256;
+  swa_task * stage = reinterpret_cast<swa_task *>(wave_base + (size_t)kWaves * seed_words) + (size_t)wave * kStage;
+  uint32_t nstage = 0;
   if (ZLDS) {
     for (uint32_t i = threadIdx.x; i < 4u * a.zlen; i += kThreads) { zob_lds[i] = a.zobrist[i]; }
     __syncthreads();
@@ -519,6 +527,17 @@ __global__ __launch_bounds__(kThreads) void k_d1_flex(const FlexArgs a) {
   const uint64_t * zob = ZLDS ? zob_lds : a.zobrist;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
   unsigned long long nvar = 0;
+  auto flush = [&]() {
+    wave_lds_sync();
+    unsigned long long base = 0;
+    if (lane == 0) { base = atomicAdd(a.task_counter, (unsigned long long)nstage); }
+    base = swa_shfl_u64(base, 0);
+    for (uint32_t i = lane; i < nstage; i += 64u) {
+      if (base + i < a.task_cap) { a.tasks[base + i] = stage[i]; }
+    }
+    nstage = 0;
+    wave_lds_sync();
+  };
   const uint32_t nwaves = gridDim.x * kWaves;
   for (uint32_t k = blockIdx.x * kWaves + wave; k < a.count; k += nwaves) {
     const uint32_t amp = a.list[k];
@@ -548,23 +567,20 @@ __global__ __launch_bounds__(kThreads) void k_d1_flex(const FlexArgs a) {
           nvar += (unsigned long long)__popcll(__ballot(s.ok[i]));
           const uint64_t m = __ballot(pass);
           if (m != 0ull) {
-            unsigned long long base = 0;
-            if (lane == 0) { base = atomicAdd(a.task_counter, (unsigned long long)__popcll(m)); }
-            base = swa_shfl_u64(base, 0);
             if (pass) {
-              const unsigned long long at = base + (unsigned long long)__popcll(m & lane_lt);
-              if (at < a.task_cap) {
-                swa_task t;
-                t.hash = s.hs[i]; t.heavy = amp; t.code = s.code[i];
-                a.tasks[at] = t;
-              }
+              swa_task t;
+              t.hash = s.hs[i]; t.heavy = amp; t.code = s.code[i];
+              stage[nstage + (uint32_t)__popcll(m & lane_lt)] = t;
             }
+            nstage += (uint32_t)__popcll(m);
+            if (nstage > kStage - 64u) { flush(); }
           }
         }
       }
     });
     __builtin_amdgcn_wave_barrier();
   }
+  if (PASS == 1 && nstage != 0u) { flush(); }
   if (lane == 0 && nvar != 0ull) { atomicAdd(a.variant_counter, nvar); }
 }
 
@@ -1177,7 +1193,8 @@ extern "C" int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64
   f.task_counter = fc + 3;
   f.task_cap = task_cap;
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
-  const size_t flex_lds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + kWaves * (size_t)(f.maxwords + 2u));
+  const size_t flex_lds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + kWaves * (size_t)(f.maxwords + 2u)) +
+                          kWaves * 256 * sizeof(swa_task);
 
   // pass A
   swa_t0(ctx, 5);
