@@ -8,6 +8,7 @@
 // is a range appended to its heavy swarm's piece list.
 #include "hostdb.h"
 #include "nw_host.h"
+#include "out.h"
 
 #include <algorithm>
 #include <cinttypes>
@@ -36,52 +37,6 @@ struct swa_d1_result {
 };
 
 namespace {
-
-inline const char * hdr(const swa_hostdb * db, uint32_t i) { return db->headers.data() + db->hdr_off[i]; }
-inline uint32_t hdrlen(const swa_hostdb * db, uint32_t i) { return (uint32_t)(db->hdr_off[i + 1] - db->hdr_off[i] - 1); }
-
-// fprint_id (src/db.cc:946-968)
-void print_id(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch, int64_t append_abundance) {
-  if (append_abundance != 0 && db->ab_start[i] == db->ab_end[i]) {
-    if (usearch) { std::fprintf(fp, "%.*s;size=%" PRIu64 ";", (int)hdrlen(db, i), hdr(db, i), db->abundance[i]); }
-    else { std::fprintf(fp, "%.*s_%" PRIu64, (int)hdrlen(db, i), hdr(db, i), db->abundance[i]); }
-  } else {
-    std::fwrite(hdr(db, i), 1, hdrlen(db, i), fp);
-  }
-}
-
-// fprint_id_noabundance (src/db.cc:971-999)
-void print_id_noabundance(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch) {
-  const int s = db->ab_start[i];
-  const int e = db->ab_end[i];
-  const int len = (int)hdrlen(db, i);
-  if (s < e) {
-    std::fprintf(fp, "%.*s", s, hdr(db, i));
-    if (usearch) {
-      if (s > 0 && e < len) { std::fputc(';', fp); }
-      std::fprintf(fp, "%.*s", len - e, hdr(db, i) + e);
-    }
-  } else {
-    std::fwrite(hdr(db, i), 1, (size_t)len, fp);
-  }
-}
-
-// fprint_id_with_new_abundance (src/db.cc:1002-1026)
-void print_id_new_abundance(FILE * fp, const swa_hostdb * db, uint32_t i, uint64_t abundance, bool usearch) {
-  if (usearch) {
-    std::fprintf(fp, "%.*s%ssize=%" PRIu64 ";%.*s", db->ab_start[i], hdr(db, i), db->ab_start[i] > 0 ? ";" : "",
-                 abundance, (int)hdrlen(db, i) - db->ab_end[i], hdr(db, i) + db->ab_end[i]);
-  } else {
-    std::fprintf(fp, "%.*s_%" PRIu64, db->ab_start[i], hdr(db, i), abundance);
-  }
-}
-
-FILE * open_out(const char * path) {
-  if (path == nullptr) { return nullptr; }
-  if (std::strcmp(path, "-") == 0) { return stdout; }
-  return std::fopen(path, "w");
-}
-void close_out(FILE * fp) { if (fp != nullptr && fp != stdout) { std::fclose(fp); } else if (fp == stdout) { std::fflush(fp); } }
 
 template <typename F>
 void for_each_member(const swa_d1_result * r, const swa_d1_result::Swarm & s, F && f) {
@@ -221,43 +176,42 @@ extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand)
 // -o / -r  (src/algod1.cc:790-846)
 extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * db, const char * path, int mothur,
                                    int usearch, int64_t append_abundance, int64_t differences) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
-  if (mothur) { std::fprintf(fp, "swarm_%" PRId64 "\t%" PRIu64, differences, r->swarmcount_adjusted); }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
+  if (mothur) { o.str("swarm_"); o.u64((uint64_t)differences); o.put('\t'); o.u64(r->swarmcount_adjusted); }
   for (const auto & s : r->swarms) {
     if (s.attached) { continue; }
     bool first = true;
     for_each_member(r, s, [&](uint32_t a) {
-      if (mothur) { std::fputc(first ? '\t' : ',', fp); }
-      else if (!first) { std::fputc(' ', fp); }
+      if (mothur) { o.put(first ? '\t' : ','); }
+      else if (!first) { o.put(' '); }
       first = false;
-      print_id(fp, db, a, usearch != 0, append_abundance);
+      swa_out::id(o, db, a, usearch != 0, append_abundance);
     });
-    if (!mothur) { std::fputc('\n', fp); }
+    if (!mothur) { o.put('\n'); }
   }
-  if (mothur) { std::fputc('\n', fp); }
-  close_out(fp);
+  if (mothur) { o.put('\n'); }
   return SWA_OK;
 }
 
 // -s  (src/algod1.cc:1040-1062): maxgen is printed twice for d = 1
 extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   for (const auto & s : r->swarms) {
     if (s.attached) { continue; }
-    std::fprintf(fp, "%u\t%" PRIu64 "\t", s.size, s.mass);
-    print_id_noabundance(fp, db, s.seed, usearch != 0);
-    std::fprintf(fp, "\t%" PRIu64 "\t%u\t%u\t%u\n", db->abundance[s.seed], s.singletons, s.maxgen, s.maxgen);
+    o.u64(s.size); o.put('\t'); o.u64(s.mass); o.put('\t');
+    swa_out::id_noabundance(o, db, s.seed, usearch != 0);
+    o.put('\t'); o.u64(db->abundance[s.seed]); o.put('\t'); o.u64(s.singletons);
+    o.put('\t'); o.u64(s.maxgen); o.put('\t'); o.u64(s.maxgen); o.put('\n');
   }
-  close_out(fp);
   return SWA_OK;
 }
 
 // -i  (src/algod1.cc:985-1037)
 extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   uint32_t cluster_no = 0;
   for (const auto & s : r->swarms) {
     if (s.attached) { continue; }
@@ -265,90 +219,82 @@ extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb 
       if (a == s.seed) { return; }
       const uint32_t gp = r->graft_cand[a];
       if (gp != SWA_NO_AMPLICON) {
-        print_id_noabundance(fp, db, gp, usearch != 0);
-        std::fputc('\t', fp);
-        print_id_noabundance(fp, db, a, usearch != 0);
-        std::fprintf(fp, "\t%d\t%u\t%u\n", 2, cluster_no + 1, r->generation[gp] + 1);
+        swa_out::id_noabundance(o, db, gp, usearch != 0);
+        o.put('\t');
+        swa_out::id_noabundance(o, db, a, usearch != 0);
+        o.put('\t'); o.u64(2); o.put('\t'); o.u64(cluster_no + 1); o.put('\t'); o.u64(r->generation[gp] + 1); o.put('\n');
       }
       const uint32_t p = r->parent[a];
       if (p != SWA_NO_AMPLICON) {
-        print_id_noabundance(fp, db, p, usearch != 0);
-        std::fputc('\t', fp);
-        print_id_noabundance(fp, db, a, usearch != 0);
-        std::fprintf(fp, "\t%u\t%u\t%u\n", 1u, cluster_no + 1, r->generation[a]);
+        swa_out::id_noabundance(o, db, p, usearch != 0);
+        o.put('\t');
+        swa_out::id_noabundance(o, db, a, usearch != 0);
+        o.put('\t'); o.u64(1); o.put('\t'); o.u64(cluster_no + 1); o.put('\t'); o.u64(r->generation[a]); o.put('\n');
       }
     });
     ++cluster_no;
   }
-  close_out(fp);
   return SWA_OK;
 }
 
 // -w  (src/algod1.cc:935-982 + db_fprintseq src/db.cc:925-943)
 extern "C" int swa_d1_write_seeds(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   std::vector<uint32_t> idx(r->swarms.size());
   std::iota(idx.begin(), idx.end(), 0u);
   std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
     const auto & a = r->swarms[x];
     const auto & b = r->swarms[y];
     if (a.mass != b.mass) { return a.mass > b.mass; }
-    return std::strcmp(hdr(db, a.seed), hdr(db, b.seed)) < 0;
+    return std::strcmp(swa_out::hdr(db, a.seed), swa_out::hdr(db, b.seed)) < 0;
   });
   std::string line;
   for (uint32_t k : idx) {
     const auto & s = r->swarms[k];
     if (s.attached) { continue; }
-    std::fputc('>', fp);
-    print_id_new_abundance(fp, db, s.seed, s.mass, usearch != 0);
-    std::fputc('\n', fp);
-    const uint64_t * w = db->seqs.data() + db->seq_off[s.seed];
-    const uint32_t len = db->seqlen[s.seed];
-    line.resize(len);
-    for (uint32_t p = 0; p < len; ++p) { line[p] = "ACGT"[(w[p >> 5] >> ((p & 31u) << 1)) & 3u]; }
-    std::fwrite(line.data(), 1, len, fp);
-    std::fputc('\n', fp);
+    o.put('>');
+    swa_out::id_new_abundance(o, db, s.seed, s.mass, usearch != 0);
+    o.put('\n');
+    swa_out::sequence(o, db, s.seed, line);
   }
-  close_out(fp);
   return SWA_OK;
 }
 
 // -j  (src/algod1.cc:755-788): rows ascending by target id (the C ABI already sorts them)
 extern "C" int swa_d1_write_network(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
                                     const char * path, int usearch, int64_t append_abundance) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   std::vector<uint32_t> row;
   for (uint32_t i = 0; i < db->n; ++i) {
     row.assign(neighbours + offsets[i], neighbours + offsets[i + 1]);
     std::sort(row.begin(), row.end());
     for (uint32_t j : row) {
-      print_id(fp, db, i, usearch != 0, append_abundance);
-      std::fputc('\t', fp);
-      print_id(fp, db, j, usearch != 0, append_abundance);
-      std::fputc('\n', fp);
+      swa_out::id(o, db, i, usearch != 0, append_abundance);
+      o.put('\t');
+      swa_out::id(o, db, j, usearch != 0, append_abundance);
+      o.put('\n');
     }
   }
-  close_out(fp);
   return SWA_OK;
 }
 
 // -u  (src/algod1.cc:849-932): members in swarm order, each aligned against the seed
 extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch,
                                    int64_t append_abundance, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   swa_nw_scratch scratch;
   uint32_t cluster_no = 0;
   for (const auto & s : r->swarms) {
     if (s.attached) { continue; }
-    std::fprintf(fp, "C\t%u\t%u\t*\t*\t*\t*\t*\t", cluster_no, s.size);
-    print_id(fp, db, s.seed, usearch != 0, append_abundance);
-    std::fprintf(fp, "\t*\n");
-    std::fprintf(fp, "S\t%u\t%u\t*\t*\t*\t*\t*\t", cluster_no, db->seqlen[s.seed]);
-    print_id(fp, db, s.seed, usearch != 0, append_abundance);
-    std::fprintf(fp, "\t*\n");
+    o.str("C\t"); o.u64(cluster_no); o.put('\t'); o.u64(s.size); o.str("\t*\t*\t*\t*\t*\t");
+    swa_out::id(o, db, s.seed, usearch != 0, append_abundance);
+    o.str("\t*\n");
+    o.str("S\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[s.seed]); o.str("\t*\t*\t*\t*\t*\t");
+    swa_out::id(o, db, s.seed, usearch != 0, append_abundance);
+    o.str("\t*\n");
     for_each_member(r, s, [&](uint32_t a) {
       if (a == s.seed) { return; }
       const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[a], db->seqlen[a],
@@ -356,16 +302,17 @@ extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * d
                                            gapextend, scratch);
       const double columns = (double)scratch.ops.size();
       const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
-      const std::string cigar = swa_cigar(scratch.ops);
-      std::fprintf(fp, "H\t%u\t%u\t%.1f\t+\t0\t0\t%s\t", cluster_no, db->seqlen[a], percentid,
-                   nwdiff > 0 ? cigar.c_str() : "=");
-      print_id(fp, db, a, usearch != 0, append_abundance);
-      std::fputc('\t', fp);
-      print_id(fp, db, s.seed, usearch != 0, append_abundance);
-      std::fputc('\n', fp);
+      o.str("H\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[a]); o.put('\t'); o.fixed1(percentid);
+      o.str("\t+\t0\t0\t");
+      if (nwdiff > 0) { const std::string cigar = swa_cigar(scratch.ops); o.write(cigar.data(), cigar.size()); }
+      else { o.put('='); }
+      o.put('\t');
+      swa_out::id(o, db, a, usearch != 0, append_abundance);
+      o.put('\t');
+      swa_out::id(o, db, s.seed, usearch != 0, append_abundance);
+      o.put('\n');
     });
     ++cluster_no;
   }
-  close_out(fp);
   return SWA_OK;
 }

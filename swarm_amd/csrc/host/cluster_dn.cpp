@@ -9,6 +9,7 @@
 // is a small queue on the host.  Outputs are byte-identical (-o -r -s -i -w -u).
 #include "hostdb.h"
 #include "nw_host.h"
+#include "out.h"
 
 #include <algorithm>
 #include <cinttypes>
@@ -34,51 +35,6 @@ struct swa_dn_result {
   uint64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13;
   std::string error;
 };
-
-namespace {
-
-inline const char * hdr(const swa_hostdb * db, uint32_t i) { return db->headers.data() + db->hdr_off[i]; }
-inline int hdrlen(const swa_hostdb * db, uint32_t i) { return (int)(db->hdr_off[i + 1] - db->hdr_off[i] - 1); }
-
-void print_id(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch, int64_t append_abundance) {
-  if (append_abundance != 0 && db->ab_start[i] == db->ab_end[i]) {
-    if (usearch) { std::fprintf(fp, "%.*s;size=%" PRIu64 ";", hdrlen(db, i), hdr(db, i), db->abundance[i]); }
-    else { std::fprintf(fp, "%.*s_%" PRIu64, hdrlen(db, i), hdr(db, i), db->abundance[i]); }
-  } else {
-    std::fwrite(hdr(db, i), 1, (size_t)hdrlen(db, i), fp);
-  }
-}
-
-void print_id_noabundance(FILE * fp, const swa_hostdb * db, uint32_t i, bool usearch) {
-  const int s = db->ab_start[i], e = db->ab_end[i], len = hdrlen(db, i);
-  if (s < e) {
-    std::fprintf(fp, "%.*s", s, hdr(db, i));
-    if (usearch) {
-      if (s > 0 && e < len) { std::fputc(';', fp); }
-      std::fprintf(fp, "%.*s", len - e, hdr(db, i) + e);
-    }
-  } else {
-    std::fwrite(hdr(db, i), 1, (size_t)len, fp);
-  }
-}
-
-void print_id_new_abundance(FILE * fp, const swa_hostdb * db, uint32_t i, uint64_t abundance, bool usearch) {
-  if (usearch) {
-    std::fprintf(fp, "%.*s%ssize=%" PRIu64 ";%.*s", db->ab_start[i], hdr(db, i), db->ab_start[i] > 0 ? ";" : "",
-                 abundance, hdrlen(db, i) - db->ab_end[i], hdr(db, i) + db->ab_end[i]);
-  } else {
-    std::fprintf(fp, "%.*s_%" PRIu64, db->ab_start[i], hdr(db, i), abundance);
-  }
-}
-
-FILE * open_out(const char * path) {
-  if (path == nullptr) { return nullptr; }
-  if (std::strcmp(path, "-") == 0) { return stdout; }
-  return std::fopen(path, "w");
-}
-void close_out(FILE * fp) { if (fp == stdout) { std::fflush(fp); } else if (fp != nullptr) { std::fclose(fp); } }
-
-}  // namespace
 
 extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
                               uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out) {
@@ -184,51 +140,48 @@ extern "C" void swa_dn_result_summary(const swa_dn_result * r, uint64_t * out3) 
 // -o / -r  (src/algo.cc:258-325)
 extern "C" int swa_dn_write_swarms(const swa_dn_result * r, const swa_hostdb * db, const char * path, int mothur,
                                    int usearch, int64_t append_abundance) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   if (!r->order.empty()) {
-    if (mothur) { std::fprintf(fp, "swarm_%" PRId64 "\t%zu\t", r->differences, r->swarms.size()); }
+    if (mothur) { o.str("swarm_"); o.u64((uint64_t)r->differences); o.put('\t'); o.u64(r->swarms.size()); o.put('\t'); }
     bool first_swarm = true;
     for (const auto & s : r->swarms) {
-      if (!first_swarm) { std::fputc(mothur ? '\t' : '\n', fp); }
+      if (!first_swarm) { o.put(mothur ? '\t' : '\n'); }
       first_swarm = false;
       for (uint32_t k = s.begin; k < s.end; ++k) {
-        if (k != s.begin) { std::fputc(mothur ? ',' : ' ', fp); }
-        print_id(fp, db, r->order[k].id, usearch != 0, append_abundance);
+        if (k != s.begin) { o.put(mothur ? ',' : ' '); }
+        swa_out::id(o, db, r->order[k].id, usearch != 0, append_abundance);
       }
     }
-    std::fputc('\n', fp);
+    o.put('\n');
   }
-  close_out(fp);
   return SWA_OK;
 }
 
 // -s  (src/algo.cc:662-674)
 extern "C" int swa_dn_write_stats(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   for (const auto & s : r->swarms) {
     const uint32_t seed = r->order[s.begin].id;
-    std::fprintf(fp, "%" PRIu64 "\t%" PRIu64 "\t", (uint64_t)(s.end - s.begin), s.mass);
-    print_id_noabundance(fp, db, seed, usearch != 0);
-    std::fprintf(fp, "\t%" PRIu64 "\t%" PRIu64 "\t%" PRIu64 "\t%" PRIu64 "\n", db->abundance[seed],
-                 (uint64_t)s.singletons, (uint64_t)s.maxgen, (uint64_t)s.maxradius);
+    o.u64(s.end - s.begin); o.put('\t'); o.u64(s.mass); o.put('\t');
+    swa_out::id_noabundance(o, db, seed, usearch != 0);
+    o.put('\t'); o.u64(db->abundance[seed]); o.put('\t'); o.u64(s.singletons); o.put('\t'); o.u64(s.maxgen);
+    o.put('\t'); o.u64(s.maxradius); o.put('\n');
   }
-  close_out(fp);
   return SWA_OK;
 }
 
 // -i  (src/algo.cc:473-488, 573-589): one line per accepted pair, in acceptance order
 extern "C" int swa_dn_write_structure(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   for (const auto & l : r->links) {
-    print_id_noabundance(fp, db, l.parent, usearch != 0);
-    std::fputc('\t', fp);
-    print_id_noabundance(fp, db, l.child, usearch != 0);
-    std::fprintf(fp, "\t%u\t%u\t%u\n", l.diff, l.swarm, l.generation);
+    swa_out::id_noabundance(o, db, l.parent, usearch != 0);
+    o.put('\t');
+    swa_out::id_noabundance(o, db, l.child, usearch != 0);
+    o.put('\t'); o.u64(l.diff); o.put('\t'); o.u64(l.swarm); o.put('\t'); o.u64(l.generation); o.put('\n');
   }
-  close_out(fp);
   return SWA_OK;
 }
 
@@ -236,29 +189,23 @@ extern "C" int swa_dn_write_structure(const swa_dn_result * r, const swa_hostdb 
 // comparator is `std::strcmp(lhs, rhs) == -1` (not `< 0`), which is libc-dependent and not a
 // strict weak order — reproduced as is, on the same libc/libstdc++, for byte-identical output.
 extern "C" int swa_dn_write_seeds(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   struct Seed { uint64_t mass; uint32_t seed; };
   std::vector<Seed> seeds;
   for (const auto & s : r->swarms) { seeds.push_back({s.mass, r->order[s.begin].id}); }
   std::sort(seeds.begin(), seeds.end(), [&](const Seed & a, const Seed & b) {
     if (a.mass > b.mass) { return true; }
     if (a.mass < b.mass) { return false; }
-    return std::strcmp(hdr(db, a.seed), hdr(db, b.seed)) == -1;
+    return std::strcmp(swa_out::hdr(db, a.seed), swa_out::hdr(db, b.seed)) == -1;
   });
   std::string line;
   for (const auto & s : seeds) {
-    std::fputc('>', fp);
-    print_id_new_abundance(fp, db, s.seed, s.mass, usearch != 0);
-    std::fputc('\n', fp);
-    const uint64_t * w = db->seqs.data() + db->seq_off[s.seed];
-    const uint32_t len = db->seqlen[s.seed];
-    line.resize(len);
-    for (uint32_t p = 0; p < len; ++p) { line[p] = "ACGT"[(w[p >> 5] >> ((p & 31u) << 1)) & 3u]; }
-    std::fwrite(line.data(), 1, len, fp);
-    std::fputc('\n', fp);
+    o.put('>');
+    swa_out::id_new_abundance(o, db, s.seed, s.mass, usearch != 0);
+    o.put('\n');
+    swa_out::sequence(o, db, s.seed, line);
   }
-  close_out(fp);
   return SWA_OK;
 }
 
@@ -266,18 +213,18 @@ extern "C" int swa_dn_write_seeds(const swa_dn_result * r, const swa_hostdb * db
 // hits[] array), aligned against its swarm's seed with the scalar aligner
 extern "C" int swa_dn_write_uclust(const swa_dn_result * r, const swa_hostdb * db, const char * path, int usearch,
                                    int64_t append_abundance) {
-  FILE * fp = open_out(path);
-  if (fp == nullptr) { return SWA_E_ARG; }
+  BufOut o(path);
+  if (!o.ok()) { return SWA_E_ARG; }
   swa_nw_scratch scratch;
   uint32_t cluster_no = 0;
   for (const auto & s : r->swarms) {
     const uint32_t seed = r->order[s.begin].id;
-    std::fprintf(fp, "C\t%u\t%" PRIu64 "\t*\t*\t*\t*\t*\t", cluster_no, (uint64_t)(s.end - s.begin));
-    print_id(fp, db, seed, usearch != 0, append_abundance);
-    std::fprintf(fp, "\t*\n");
-    std::fprintf(fp, "S\t%u\t%u\t*\t*\t*\t*\t*\t", cluster_no, db->seqlen[seed]);
-    print_id(fp, db, seed, usearch != 0, append_abundance);
-    std::fprintf(fp, "\t*\n");
+    o.str("C\t"); o.u64(cluster_no); o.put('\t'); o.u64(s.end - s.begin); o.str("\t*\t*\t*\t*\t*\t");
+    swa_out::id(o, db, seed, usearch != 0, append_abundance);
+    o.str("\t*\n");
+    o.str("S\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[seed]); o.str("\t*\t*\t*\t*\t*\t");
+    swa_out::id(o, db, seed, usearch != 0, append_abundance);
+    o.str("\t*\n");
     for (uint32_t k = s.link_begin; k < s.link_end; ++k) {
       const uint32_t hit = r->links[k].child;
       const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[hit], db->seqlen[hit],
@@ -285,16 +232,17 @@ extern "C" int swa_dn_write_uclust(const swa_dn_result * r, const swa_hostdb * d
                                            r->pen_gapopen, r->pen_gapextend, scratch);
       const double columns = (double)scratch.ops.size();
       const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
-      const std::string cigar = swa_cigar(scratch.ops);
-      std::fprintf(fp, "H\t%u\t%u\t%.1f\t+\t0\t0\t%s\t", cluster_no, db->seqlen[hit], percentid,
-                   nwdiff > 0 ? cigar.c_str() : "=");
-      print_id(fp, db, hit, usearch != 0, append_abundance);
-      std::fputc('\t', fp);
-      print_id(fp, db, seed, usearch != 0, append_abundance);
-      std::fputc('\n', fp);
+      o.str("H\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[hit]); o.put('\t'); o.fixed1(percentid);
+      o.str("\t+\t0\t0\t");
+      if (nwdiff > 0) { const std::string cigar = swa_cigar(scratch.ops); o.write(cigar.data(), cigar.size()); }
+      else { o.put('='); }
+      o.put('\t');
+      swa_out::id(o, db, hit, usearch != 0, append_abundance);
+      o.put('\t');
+      swa_out::id(o, db, seed, usearch != 0, append_abundance);
+      o.put('\n');
     }
     ++cluster_no;
   }
-  close_out(fp);
   return SWA_OK;
 }

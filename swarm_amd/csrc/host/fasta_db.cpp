@@ -2,52 +2,117 @@
 // reference's db order.  Behavioural mirror of db_read (src/db.cc:432-803): same
 // accepted alphabet, same header / abundance rules, same error texts, same sort
 // (abundance descending, then header bytes ascending, src/db.cc:388-413) — with a
-// different shape: the whole input is scanned once from memory into SoA arrays whose
-// sequence words are 8-byte aligned and contiguous in SORTED order (what the GPU
-// wants to stream), instead of the reference's interleaved header/sequence blob.
+// different shape: the input is memory-mapped, cut at record boundaries and parsed by
+// all host cores in parallel into per-thread SoA pieces; abundance parsing and the
+// identifier-uniqueness check run in the same parallel pass (lock-free open addressing);
+// the sort is a parallel merge sort on (abundance, 8-byte header prefix) keys that falls
+// back to strcmp only on ties; and the result is written contiguously in SORTED order with
+// 8-byte aligned sequence words (what the GPU wants to stream), instead of the
+// reference's single-threaded getline loop over an interleaved header/sequence blob.
 #include "hostdb.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <omp.h>
+#include <parallel/algorithm>
+
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
 
 struct RawEntry {
-  uint64_t hdr_off;      // into raw header pool
+  uint64_t hdr_off;      // into the piece's header pool
+  uint64_t word_off;     // into the piece's word pool
+  uint64_t abundance;
+  uint64_t key8;         // first 8 header bytes, big endian (sort accelerator)
   uint32_t hdr_len;
-  uint32_t lineno;       // line of the '>' header
-  uint64_t word_off;     // into raw word pool
+  uint32_t lineno;       // line of the '>' header, local to the piece until fixed up
   uint32_t seqlen;
   int32_t ab_start;      // abundance annotation [start, end) inside the header
   int32_t ab_end;
-  uint64_t abundance;
+  uint32_t piece;
 };
 
-bool read_all(const char * path, std::vector<char> & buf, std::string & err) {
-  FILE * fp = nullptr;
+struct Piece {            // what one thread parsed
+  std::vector<RawEntry> entries;
+  std::vector<char> hdr_pool;
+  std::vector<uint64_t> words;
+  uint64_t lines = 0;     // newline-terminated lines consumed
+  uint64_t nucleotides = 0;
+  uint32_t longest = 0, longest_header = 0;
+  std::string error;      // first error of the piece (line numbers still local)
+  uint32_t error_line = 0;
+  int error_kind = 0;     // 0 none, 1 message carries a \x01 where the absolute line number goes, 2 final
+  uint64_t missing = 0;   // entries without abundance annotation
+  uint32_t missing_line = 0;
+  std::string missing_hdr;
+};
+
+struct Input {
+  const char * data = nullptr;
+  size_t size = 0;
+  bool mapped = false;
+  std::vector<char> owned;
+};
+
+bool load_input(const char * path, Input & in, std::string & err) {
   const bool is_stdin = (std::strcmp(path, "-") == 0);
-  fp = is_stdin ? stdin : std::fopen(path, "rb");
-  if (fp == nullptr) {
-    err = std::string("\nError: Unable to open input data file (") + path + ").\n";   // db.cc:458-461
-    return false;
+  if (!is_stdin) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) {
+      err = std::string("\nError: Unable to open input data file (") + path + ").\n";   // db.cc:458-461
+      return false;
+    }
+    struct stat st{};
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      void * p = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (p != MAP_FAILED) {
+        (void)::madvise(p, (size_t)st.st_size, MADV_WILLNEED);
+        in.data = static_cast<const char *>(p);
+        in.size = (size_t)st.st_size;
+        in.mapped = true;
+        ::close(fd);
+        return true;
+      }
+    }
+    // pipes, empty files, mmap failure: plain read
+    size_t used = 0;
+    in.owned.resize(1 << 20);
+    for (;;) {
+      if (used == in.owned.size()) { in.owned.resize(in.owned.size() * 2); }
+      const ssize_t got = ::read(fd, in.owned.data() + used, in.owned.size() - used);
+      if (got <= 0) { break; }
+      used += (size_t)got;
+    }
+    ::close(fd);
+    in.owned.resize(used);
+  } else {
+    size_t used = 0;
+    in.owned.resize(1 << 20);
+    for (;;) {
+      if (used == in.owned.size()) { in.owned.resize(in.owned.size() * 2); }
+      const size_t got = std::fread(in.owned.data() + used, 1, in.owned.size() - used, stdin);
+      if (got == 0) { break; }
+      used += got;
+    }
+    in.owned.resize(used);
   }
-  size_t used = 0;
-  buf.resize(1 << 20);
-  for (;;) {
-    if (used == buf.size()) { buf.resize(buf.size() * 2); }
-    const size_t got = std::fread(buf.data() + used, 1, buf.size() - used, fp);
-    used += got;
-    if (got == 0) { break; }
-  }
-  if (!is_stdin) { std::fclose(fp); }
-  buf.resize(used);
+  in.data = in.owned.data();
+  in.size = in.owned.size();
   return true;
 }
 
@@ -92,65 +157,47 @@ bool usearch_abundance(const char * h, uint32_t len, int32_t & start, int32_t & 
   return false;
 }
 
-inline uint64_t id_hash(const char * s, uint32_t len) {
+inline uint64_t bytes_hash(const char * s, uint32_t len) {
   uint64_t h = 0xcbf29ce484222325ull;
   for (uint32_t i = 0; i < len; ++i) { h = (h ^ (unsigned char)s[i]) * 0x100000001b3ull; }
   return h ^ (h >> 29);
 }
 
-}  // namespace
-
-extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t append_abundance, int check_dup_seqs,
-                                     swa_hostdb ** out) {
-  if (out == nullptr || path == nullptr) { return SWA_E_ARG; }
-  auto * db = new swa_hostdb();
-  *out = db;
-  std::vector<char> buf;
-  if (!read_all(path, buf, db->error)) { return SWA_E_ARG; }
-
-  int8_t map[256];
-  std::memset(map, -1, sizeof(map));
-  map['A'] = map['a'] = 0; map['C'] = map['c'] = 1; map['G'] = map['g'] = 2;
-  map['T'] = map['t'] = 3; map['U'] = map['u'] = 3;                               // db.cc:100-114
-
-  std::vector<RawEntry> raw;
-  std::vector<char> hdr_pool;
-  std::vector<uint64_t> words;
-  raw.reserve(buf.size() / 160 + 16);
-  words.reserve(buf.size() / 28 + 16);
-  hdr_pool.reserve(buf.size() / 12 + 16);
-
-  const char * p = buf.data();
-  const char * const end = p + buf.size();
+// parse records of [begin, end) — begin points at a '>' that starts a line (or at the file start)
+void parse_piece(const char * begin, const char * end, const int8_t * map, bool usearch, int64_t append_abundance,
+                 uint32_t piece_no, Piece & out) {
+  const char * p = begin;
   uint32_t lineno = 1;
   auto line_end = [&](const char * q) { const void * nl = std::memchr(q, '\n', (size_t)(end - q)); return nl ? (const char *)nl : end; };
-
+  const size_t span = (size_t)(end - begin);
+  out.entries.reserve(span / 160 + 16);
+  out.words.reserve(span / 28 + 16);
+  out.hdr_pool.reserve(span / 12 + 16);
+  auto fail = [&](const std::string & msg, uint32_t line, int kind) { out.error = msg; out.error_line = line; out.error_kind = kind; };
   while (p < end) {
-    if (*p != '>') {
-      db->error = "\nError: Illegal header line in fasta file.\n";                 // db.cc:492-494
-      return SWA_E_ARG;
-    }
+    if (*p != '>') { fail("\nError: Illegal header line in fasta file.\n", lineno, 2); break; }   // db.cc:492-494
     const char * le = line_end(p);
     const char * h = p + 1;
     uint32_t hlen = 0;
-    while (h + hlen < le && h[hlen] != ' ' && h[hlen] != '\r' && h[hlen] != 0) { ++hlen; }   // db.cc:498-499
-    if (hlen > 16777215u) {
-      db->error = "\nError: Headers longer than 16,777,215 symbols are not supported.\n";
-      return SWA_E_ARG;
-    }
+    while (h + hlen < le && h[hlen] != ' ' && h[hlen] != '\r' && h[hlen] != 0) { ++hlen; }      // db.cc:498-499
+    if (hlen > 16777215u) { fail("\nError: Headers longer than 16,777,215 symbols are not supported.\n", lineno, 2); break; }
     RawEntry e{};
-    e.hdr_off = hdr_pool.size();
+    e.piece = piece_no;
+    e.hdr_off = out.hdr_pool.size();
     e.hdr_len = hlen;
     e.lineno = lineno;
-    hdr_pool.insert(hdr_pool.end(), h, h + hlen);
-    hdr_pool.push_back('\0');
+    out.hdr_pool.insert(out.hdr_pool.end(), h, h + hlen);
+    out.hdr_pool.push_back('\0');
+    uint64_t key = 0;
+    for (uint32_t i = 0; i < 8; ++i) { key = (key << 8) | (i < hlen ? (unsigned char)h[i] : 0u); }
+    e.key8 = key;
     p = (le < end) ? le + 1 : end;
     ++lineno;
 
-    e.word_off = words.size();
+    e.word_off = out.words.size();
     uint64_t acc = 0;
-    uint32_t fill = 0;
-    uint32_t len = 0;
+    uint32_t fill = 0, len = 0;
+    bool bad = false;
     while (p < end && *p != '>') {
       le = line_end(p);
       for (const char * q = p; q < le; ++q) {
@@ -159,173 +206,346 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
         if (code >= 0) {
           acc |= (uint64_t)code << (2u * fill);
           ++len;
-          if (++fill == 32u) { words.push_back(acc); acc = 0; fill = 0; }
+          if (++fill == 32u) { out.words.push_back(acc); acc = 0; fill = 0; }
         } else if (ch == 0) {
           break;                                 // the reference's line scan stops at a NUL
         } else if (ch != '\n' && ch != '\r') {
           char msg[160];
-          if (ch >= 32 && ch <= 126) {
-            std::snprintf(msg, sizeof(msg), "\nError: Illegal character '%c' in sequence on line %u.\n", ch, lineno);
-          } else {
-            std::snprintf(msg, sizeof(msg), "\nError: Illegal character (ascii no %d) in sequence on line %u.\n", (int)ch, lineno);
-          }
-          db->error = msg;                                                          // db.cc:575-590
-          return SWA_E_ARG;
+          if (ch >= 32 && ch <= 126) { std::snprintf(msg, sizeof(msg), "\nError: Illegal character '%c' in sequence on line \x01.\n", ch); }
+          else { std::snprintf(msg, sizeof(msg), "\nError: Illegal character (ascii no %d) in sequence on line \x01.\n", (int)ch); }
+          fail(msg, lineno, 1);                                                                  // db.cc:575-590
+          bad = true;
+          break;
         }
       }
-      if (len > 67108861u) {
-        db->error = "\nError: Sequences longer than 67,108,861 symbols are not supported.\n";
-        return SWA_E_ARG;
-      }
+      if (bad) { break; }
+      if (len > 67108861u) { fail("\nError: Sequences longer than 67,108,861 symbols are not supported.\n", lineno, 2); bad = true; break; }
       p = (le < end) ? le + 1 : end;
       ++lineno;
     }
-    if (len == 0) {
-      db->error = "\nError: Empty sequence found on line " + std::to_string(lineno - 1) + ".\n";   // db.cc:608-611
-      return SWA_E_ARG;
-    }
-    if (fill > 0) { words.push_back(acc); }
+    if (bad) { break; }
+    if (len == 0) { fail("\nError: Empty sequence found on line \x01.\n", lineno - 1, 1); break; }   // db.cc:608-611
+    if (fill > 0) { out.words.push_back(acc); }
     e.seqlen = len;
-    db->nucleotides += len;
-    db->longest = std::max(db->longest, len);
-    db->longest_header = std::max(db->longest_header, hlen);
-    raw.push_back(e);
-  }
-  const uint64_t n64 = raw.size();
-  if (n64 > 0xFFFFFFFEull) { db->error = "\nError: too many sequences.\n"; return SWA_E_ARG; }
-  const uint32_t n = (uint32_t)n64;
-  db->n = n;
+    out.nucleotides += len;
+    out.longest = std::max(out.longest, len);
+    out.longest_header = std::max(out.longest_header, hlen);
 
-  // abundances, identifier uniqueness (db.cc:286-343, 680-758)
-  uint64_t missing = 0;
-  uint32_t missing_line = 0;
-  const char * missing_hdr = nullptr;
-  std::vector<uint32_t> idtab(n ? 2ull * n : 1, 0xFFFFFFFFu);
-  auto id_span = [&](const RawEntry & e, const char *& s, uint32_t & l) {
-    const char * hdr = hdr_pool.data() + e.hdr_off;
-    if (e.ab_start > 0) { s = hdr; l = (uint32_t)e.ab_start; }
-    else { s = hdr + e.ab_end; l = e.hdr_len - (uint32_t)e.ab_end; }
-  };
-  for (uint32_t i = 0; i < n; ++i) {
-    RawEntry & e = raw[i];
-    const char * hdr = hdr_pool.data() + e.hdr_off;
+    // abundance annotation (db.cc:286-343)
+    const char * hdr = out.hdr_pool.data() + e.hdr_off;
     int32_t s = 0, t = 0;
-    int64_t number = 0;
-    int64_t abundance = 0;
-    const bool found = usearch ? usearch_abundance(hdr, e.hdr_len, s, t, number) : swarm_abundance(hdr, e.hdr_len, s, t, number);
+    int64_t number = 0, abundance = 0;
+    const bool found = usearch ? usearch_abundance(hdr, hlen, s, t, number) : swarm_abundance(hdr, hlen, s, t, number);
     if (found) {
       if (number <= 0) {
-        db->error = "\nError: Illegal abundance value on line " + std::to_string(e.lineno) + ":\n" + hdr +
-                    "\nAbundance values should be positive integers.\n";
-        return SWA_E_ARG;
+        fail(std::string("\nError: Illegal abundance value on line \x01:\n") + hdr + "\nAbundance values should be positive integers.\n",
+             e.lineno, 1);
+        break;
       }
       abundance = number;
     }
     if (abundance == 0) {
-      s = (int32_t)e.hdr_len;
+      s = (int32_t)hlen;
       t = s;
       if (append_abundance != 0) { abundance = append_abundance; }
-      else {
-        if (++missing == 1) { missing_line = e.lineno; missing_hdr = hdr; }
-      }
+      else if (++out.missing == 1) { out.missing_line = e.lineno; out.missing_hdr = hdr; }
     }
     e.abundance = (uint64_t)abundance;
     e.ab_start = s;
     e.ab_end = t;
-    if (e.ab_start == 0 && e.ab_end == (int32_t)e.hdr_len) {
-      db->error = "\nError: Empty sequence identifier.\n";
+    if (e.ab_start == 0 && e.ab_end == (int32_t)hlen) {
+      fail("\nError: Empty sequence identifier.\n", e.lineno, 2);
+      break;
+    }
+    out.entries.push_back(e);
+  }
+  out.lines = lineno - 1;
+}
+
+unsigned worker_count(size_t bytes) {
+  const char * env = std::getenv("SWARM_AMD_HOST_THREADS");
+  unsigned t = env != nullptr ? (unsigned)std::atoi(env) : std::thread::hardware_concurrency();
+  if (t < 1) { t = 1; }
+  if (t > 64) { t = 64; }
+  const size_t by_size = bytes / (4u << 20) + 1;            // at least 4 MB of text per thread
+  return (unsigned)std::min<size_t>(t, by_size);
+}
+
+template <typename F>
+void run_parallel(unsigned threads, F && fn) {
+  if (threads <= 1) { fn(0u); return; }
+  std::vector<std::thread> pool;
+  pool.reserve(threads);
+  for (unsigned t = 0; t < threads; ++t) { pool.emplace_back([&fn, t] { fn(t); }); }
+  for (auto & th : pool) { th.join(); }
+}
+
+}  // namespace
+
+namespace {
+struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the phase times to stderr
+  bool on = std::getenv("SWARM_AMD_DB_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char * what) {
+    if (!on) { return; }
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[hostdb] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+}  // namespace
+
+extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t append_abundance, int check_dup_seqs,
+                                     swa_hostdb ** out) {
+  if (out == nullptr || path == nullptr) { return SWA_E_ARG; }
+  PhaseTimer timer;
+  auto * db = new swa_hostdb();
+  *out = db;
+  Input in;
+  if (!load_input(path, in, db->error)) { return SWA_E_ARG; }
+  struct Unmap { Input & i; ~Unmap() { if (i.mapped) { ::munmap(const_cast<char *>(i.data), i.size); } } } unmap{in};
+
+  int8_t map[256];
+  std::memset(map, -1, sizeof(map));
+  map['A'] = map['a'] = 0; map['C'] = map['c'] = 1; map['G'] = map['g'] = 2;
+  map['T'] = map['t'] = 3; map['U'] = map['u'] = 3;                               // db.cc:100-114
+
+  // ---- cut the text at record boundaries ("\n>") and parse the pieces in parallel
+  const unsigned threads = worker_count(in.size);
+  std::vector<size_t> cuts(threads + 1, in.size);
+  cuts[0] = 0;
+  for (unsigned t = 1; t < threads; ++t) {
+    size_t pos = in.size / threads * t;
+    if (pos < cuts[t - 1]) { pos = cuts[t - 1]; }
+    while (pos < in.size) {
+      const void * nl = std::memchr(in.data + pos, '\n', in.size - pos);
+      if (nl == nullptr) { pos = in.size; break; }
+      pos = (size_t)((const char *)nl - in.data) + 1;
+      if (pos < in.size && in.data[pos] == '>') { break; }
+    }
+    cuts[t] = pos;
+  }
+  std::vector<Piece> pieces(threads);
+  run_parallel(threads, [&](unsigned t) {
+    if (cuts[t] < cuts[t + 1]) {
+      parse_piece(in.data + cuts[t], in.data + cuts[t + 1], map, usearch != 0, append_abundance, t, pieces[t]);
+    }
+  });
+
+  timer.lap("map + parallel parse");
+  // ---- first error in file order, with absolute line numbers
+  uint64_t lines_before = 0;
+  for (unsigned t = 0; t < threads; ++t) {
+    Piece & pc = pieces[t];
+    if (pc.error_kind != 0) {
+      if (pc.error_kind == 1) {                     // the first \x01 stands for the absolute line number
+        const size_t at = pc.error.find('\x01');
+        db->error = pc.error;
+        if (at != std::string::npos) { db->error.replace(at, 1, std::to_string(pc.error_line + lines_before)); }
+      } else {
+        db->error = pc.error;
+      }
       return SWA_E_ARG;
     }
-    const char * ids; uint32_t idl;
-    id_span(e, ids, idl);
-    uint64_t slot = id_hash(ids, idl) % idtab.size();
-    while (idtab[slot] != 0xFFFFFFFFu) {
-      const char * os; uint32_t ol;
-      id_span(raw[idtab[slot]], os, ol);
-      if (ol == idl && std::memcmp(os, ids, idl) == 0) {
-        db->error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
-        return SWA_E_ARG;
-      }
-      slot = (slot + 1) % idtab.size();
-    }
-    idtab[slot] = i;
+    for (auto & e : pc.entries) { e.lineno += (uint32_t)lines_before; }
+    if (pc.missing != 0) { pc.missing_line += (uint32_t)lines_before; }
+    lines_before += pc.lines;
   }
-  idtab.clear(); idtab.shrink_to_fit();
 
+  // ---- global view of the entries
+  std::vector<uint64_t> piece_first(threads + 1, 0);
+  for (unsigned t = 0; t < threads; ++t) { piece_first[t + 1] = piece_first[t] + pieces[t].entries.size(); }
+  const uint64_t n64 = piece_first[threads];
+  if (n64 > 0xFFFFFFFEull) { db->error = "\nError: too many sequences.\n"; return SWA_E_ARG; }
+  const uint32_t n = (uint32_t)n64;
+  db->n = n;
+  std::vector<const RawEntry *> ent(n);
+  run_parallel(threads, [&](unsigned t) {
+    uint64_t k = piece_first[t];
+    for (const auto & e : pieces[t].entries) { ent[k++] = &e; }
+  });
+  auto hdr_of = [&](const RawEntry * e) { return pieces[e->piece].hdr_pool.data() + e->hdr_off; };
+  auto words_of = [&](const RawEntry * e) { return pieces[e->piece].words.data() + e->word_off; };
+  for (const auto & pc : pieces) {
+    db->nucleotides += pc.nucleotides;
+    db->longest = std::max(db->longest, pc.longest);
+    db->longest_header = std::max(db->longest_header, pc.longest_header);
+  }
+
+  timer.lap("entry index");
+  // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
+  {
+    const uint64_t tsize = n ? 2ull * n : 1;
+    std::vector<std::atomic<uint32_t>> idtab(tsize);
+    run_parallel(threads, [&](unsigned t) {
+      for (uint64_t i = tsize * t / threads; i < tsize * (t + 1) / threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
+    });
+    auto id_span = [&](const RawEntry * e, const char *& s, uint32_t & l) {
+      const char * hdr = hdr_of(e);
+      if (e->ab_start > 0) { s = hdr; l = (uint32_t)e->ab_start; }
+      else { s = hdr + e->ab_end; l = e->hdr_len - (uint32_t)e->ab_end; }
+    };
+    std::atomic<uint32_t> dup_entry{0xFFFFFFFFu};
+    run_parallel(threads, [&](unsigned t) {
+      for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads; ++i) {
+        const char * ids; uint32_t idl;
+        id_span(ent[i], ids, idl);
+        uint64_t slot = bytes_hash(ids, idl) % tsize;
+        for (;;) {
+          uint32_t cur = idtab[slot].load(std::memory_order_acquire);
+          if (cur == 0xFFFFFFFFu) {
+            if (idtab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
+          }
+          const char * os; uint32_t ol;
+          id_span(ent[cur], os, ol);
+          if (ol == idl && std::memcmp(os, ids, idl) == 0) {
+            // report the LATER of the two, like the sequential scan of the reference does
+            uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
+            uint32_t seen = dup_entry.load();
+            while (later < seen && !dup_entry.compare_exchange_weak(seen, later)) { }
+            break;
+          }
+          slot = (slot + 1) % tsize;
+        }
+      }
+    });
+    if (dup_entry.load() != 0xFFFFFFFFu) {
+      const char * ids; uint32_t idl;
+      id_span(ent[dup_entry.load()], ids, idl);
+      db->error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
+      return SWA_E_ARG;
+    }
+  }
+
+  timer.lap("identifier uniqueness");
   // duplicated sequences are checked here only for d > 1 (db.cc:763-790); d = 1 finds
   // them while building the amplicon table (algod1.cc:1131-1150 / swa_d1_index_build)
   if (check_dup_seqs && n > 1) {
-    std::vector<uint32_t> tab(2ull * n, 0xFFFFFFFFu);
-    for (uint32_t i = 0; i < n; ++i) {
-      const RawEntry & e = raw[i];
-      const uint32_t nw = (e.seqlen + 31u) >> 5;
-      uint64_t hsh = e.seqlen * 0x9E3779B97F4A7C15ull;
-      for (uint32_t w = 0; w < nw; ++w) { hsh = (hsh ^ words[e.word_off + w]) * 0xff51afd7ed558ccdull; hsh ^= hsh >> 32; }
-      uint64_t slot = hsh % tab.size();
-      while (tab[slot] != 0xFFFFFFFFu) {
-        const RawEntry & o = raw[tab[slot]];
-        if (o.seqlen == e.seqlen && std::memcmp(&words[o.word_off], &words[e.word_off], nw * 8ull) == 0) {
-          db->error = "\nError: some fasta entries have identical sequences.\n"
-                      "Swarm expects dereplicated fasta files.\n"
-                      "Such files can be produced with swarm or vsearch:\n"
-                      " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
-                      "or\n"
-                      " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
-          return SWA_E_DUPLICATES;
+    const uint64_t tsize = 2ull * n;
+    std::vector<std::atomic<uint32_t>> tab(tsize);
+    for (auto & a : tab) { a.store(0xFFFFFFFFu, std::memory_order_relaxed); }
+    std::atomic<bool> dup{false};
+    run_parallel(threads, [&](unsigned t) {
+      for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads && !dup.load(std::memory_order_relaxed); ++i) {
+        const RawEntry * e = ent[i];
+        const uint64_t * w = words_of(e);
+        const uint32_t nw = (e->seqlen + 31u) >> 5;
+        uint64_t hsh = e->seqlen * 0x9E3779B97F4A7C15ull;
+        for (uint32_t k = 0; k < nw; ++k) { hsh = (hsh ^ w[k]) * 0xff51afd7ed558ccdull; hsh ^= hsh >> 32; }
+        uint64_t slot = hsh % tsize;
+        for (;;) {
+          uint32_t cur = tab[slot].load(std::memory_order_acquire);
+          if (cur == 0xFFFFFFFFu) {
+            if (tab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
+          }
+          const RawEntry * o = ent[cur];
+          if (o->seqlen == e->seqlen && std::memcmp(words_of(o), w, nw * 8ull) == 0) { dup.store(true); break; }
+          slot = (slot + 1) % tsize;
         }
-        slot = (slot + 1) % tab.size();
       }
-      tab[slot] = i;
+    });
+    if (dup.load()) {
+      db->error = "\nError: some fasta entries have identical sequences.\n"
+                  "Swarm expects dereplicated fasta files.\n"
+                  "Such files can be produced with swarm or vsearch:\n"
+                  " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
+                  "or\n"
+                  " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
+      return SWA_E_DUPLICATES;
     }
   }
-  if (missing != 0) {                                                                // db.cc:369-385
-    db->error = "\nError: Abundance annotations not found for " + std::to_string(missing) +
-                " sequences, starting on line " + std::to_string(missing_line) + ".\n>" + missing_hdr + "\n" +
-                "Fasta headers must end with abundance annotations (_INT or ;size=INT).\n"
-                "The -z option must be used if the abundance annotation is in the latter format.\n"
-                "Abundance annotations can be produced by dereplicating the sequences.\n"
-                "The header is defined as the string comprised between the \">\" symbol\n"
-                "and the first space or the end of the line, whichever comes first.\n";
-    return SWA_E_ARG;
+
+  {                                                                                  // db.cc:369-385
+    uint64_t missing = 0;
+    uint32_t missing_line = 0;
+    std::string missing_hdr;
+    for (const auto & pc : pieces) {
+      if (pc.missing != 0 && missing == 0) { missing_line = pc.missing_line; missing_hdr = pc.missing_hdr; }
+      missing += pc.missing;
+    }
+    if (missing != 0) {
+      db->error = "\nError: Abundance annotations not found for " + std::to_string(missing) +
+                  " sequences, starting on line " + std::to_string(missing_line) + ".\n>" + missing_hdr + "\n" +
+                  "Fasta headers must end with abundance annotations (_INT or ;size=INT).\n"
+                  "The -z option must be used if the abundance annotation is in the latter format.\n"
+                  "Abundance annotations can be produced by dereplicating the sequences.\n"
+                  "The header is defined as the string comprised between the \">\" symbol\n"
+                  "and the first space or the end of the line, whichever comes first.\n";
+      return SWA_E_ARG;
+    }
   }
 
-  // db order: abundance descending, then header (strcmp) ascending — db.cc:388-413
+  timer.lap("duplicate / missing checks");
+  // ---- db order: abundance descending, then header (strcmp) ascending — db.cc:388-413.
+  // Parallel merge sort; the 8-byte big-endian header prefix decides most ties without
+  // touching the header text (equal prefixes fall through to strcmp: same order).
   std::vector<uint32_t> order(n);
   std::iota(order.begin(), order.end(), 0u);
   auto less = [&](uint32_t a, uint32_t b) {
-    const RawEntry & x = raw[a];
-    const RawEntry & y = raw[b];
-    if (x.abundance != y.abundance) { return x.abundance > y.abundance; }
-    return std::strcmp(hdr_pool.data() + x.hdr_off, hdr_pool.data() + y.hdr_off) < 0;
+    const RawEntry * x = ent[a];
+    const RawEntry * y = ent[b];
+    if (x->abundance != y->abundance) { return x->abundance > y->abundance; }
+    if (x->key8 != y->key8) { return x->key8 < y->key8; }
+    return std::strcmp(hdr_of(x), hdr_of(y)) < 0;
   };
-  if (!std::is_sorted(order.begin(), order.end(), less)) { std::sort(order.begin(), order.end(), less); }
-
+  if (!std::is_sorted(order.begin(), order.end(), less)) {
+    // libstdc++ parallel mode: multiway merge sort over the host cores (OpenMP); the order is a
+    // strict total order (identifiers are unique), so the result equals std::sort's
+    omp_set_num_threads((int)threads);
+    __gnu_parallel::sort(order.begin(), order.end(), less);
+  }
+  timer.lap("sort");
+  // ---- contiguous SoA in sorted order (offsets by prefix sum, copies in parallel)
   db->seq_off.resize((size_t)n + 1);
   db->seqlen.resize(n);
   db->abundance.resize(n);
   db->hdr_off.resize((size_t)n + 1);
   db->ab_start.resize(n);
   db->ab_end.resize(n);
-  db->seqs.resize(words.size() + 1);
-  db->headers.resize(hdr_pool.size() + 1);
   uint64_t woff = 0, hoff = 0;
-  for (uint32_t k = 0; k < n; ++k) {
-    const RawEntry & e = raw[order[k]];
-    const uint32_t nw = (e.seqlen + 31u) >> 5;
-    db->seq_off[k] = woff;
-    std::memcpy(&db->seqs[woff], &words[e.word_off], nw * 8ull);
-    woff += nw;
-    db->seqlen[k] = e.seqlen;
-    db->abundance[k] = e.abundance;
-    db->hdr_off[k] = hoff;
-    std::memcpy(&db->headers[hoff], hdr_pool.data() + e.hdr_off, (size_t)e.hdr_len + 1);
-    hoff += (uint64_t)e.hdr_len + 1;
-    db->ab_start[k] = e.ab_start;
-    db->ab_end[k] = e.ab_end;
+  {
+    // offsets by a two-level prefix sum: per-thread block totals, then each thread fills its block
+    std::vector<uint64_t> wsum(threads + 1, 0), hsum(threads + 1, 0);
+    run_parallel(threads, [&](unsigned t) {
+      uint64_t w = 0, h = 0;
+      for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
+        const RawEntry * e = ent[order[k]];
+        w += (e->seqlen + 31u) >> 5;
+        h += (uint64_t)e->hdr_len + 1;
+      }
+      wsum[t + 1] = w; hsum[t + 1] = h;
+    });
+    for (unsigned t = 0; t < threads; ++t) { wsum[t + 1] += wsum[t]; hsum[t + 1] += hsum[t]; }
+    run_parallel(threads, [&](unsigned t) {
+      uint64_t w = wsum[t], h = hsum[t];
+      for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
+        const RawEntry * e = ent[order[k]];
+        db->seq_off[k] = w;
+        db->hdr_off[k] = h;
+        w += (e->seqlen + 31u) >> 5;
+        h += (uint64_t)e->hdr_len + 1;
+      }
+    });
+    woff = wsum[threads];
+    hoff = hsum[threads];
   }
   db->seq_off[n] = woff;
   db->hdr_off[n] = hoff;
+  db->seqs.resize(woff + 1);
+  db->headers.resize(hoff + 1);
+  run_parallel(threads, [&](unsigned t) {
+    for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
+      const RawEntry * e = ent[order[k]];
+      std::memcpy(&db->seqs[db->seq_off[k]], words_of(e), ((e->seqlen + 31u) >> 5) * 8ull);
+      std::memcpy(&db->headers[db->hdr_off[k]], hdr_of(e), (size_t)e->hdr_len + 1);
+      db->seqlen[k] = e->seqlen;
+      db->abundance[k] = e->abundance;
+      db->ab_start[k] = e->ab_start;
+      db->ab_end[k] = e->ab_end;
+    }
+  });
   db->seqs[woff] = 0;
+  timer.lap("gather into db order");
   return SWA_OK;
 }
 
