@@ -106,6 +106,9 @@ def main() -> None:
     ap.add_argument("--length", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="development aid: run rank 0's share of an N-GPU job on this one GPU (no collectives); "
+                         "the JSON line is marked simulated and is not a result")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +126,8 @@ def main() -> None:
 
     from swarm_amd import Context, HostDb, sharding
 
-    n_total = args.per_gpu * world
+    sim_world = args.simulate_world if world == 1 and args.simulate_world > 1 else 0
+    n_total = args.per_gpu * (sim_world or world)
     fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n_total}x{args.length}_s{args.seed}.fa"
     if local_rank == 0 and not fasta.exists():
         tmp = fasta.with_suffix(f".tmp{os.getpid()}")
@@ -148,7 +152,7 @@ def main() -> None:
     ctx.attach_db(t_seqs, t_off, t_len, t_ab, hdb.longest)
     ctx.timing_enable(True)
 
-    parts = sharding.partition_even(n_total, world)
+    parts = sharding.partition_even(n_total, sim_world or world)
     first, count = parts[rank]
     cap = 8 * count
     d_offsets = torch.zeros(count + 1, dtype=torch.int64, device=dev)
@@ -230,7 +234,9 @@ def main() -> None:
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_kernel_ms": k_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if sim_world:
+            out["simulated"] = f"rank 0 of {sim_world}, no collectives: value counts all {n_total} amplicons as if every rank finished in this time"
+        if world == 1 and not sim_world and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fasta, n_total, args.length, args.seed)
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -803,10 +803,6 @@ static int build_anchor_index(swa_ctx * ctx) {
                        static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), offsets);
     hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, slot_of, n, offsets, cursor,
                        static_cast<uint32_t *>(ctx->d_amembers[which].ptr));
-    hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, counts, offsets, asize,
-                       static_cast<swa_item *>(ctx->d_aitems[which].ptr), static_cast<uint32_t *>(ctx->d_acounters.ptr) + which,
-                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + (n / 2 + 64),
-                       static_cast<uint32_t *>(ctx->d_acounters.ptr) + 3 + which);
     SWA_HIP(ctx, hipGetLastError());
   }
   ctx->anchor_ready = true;
@@ -821,12 +817,35 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
-  SWA_HIP(ctx, hipMemsetAsync(acounters + 2, 0, sizeof(uint32_t), ctx->stream));
-  SWA_HIP(ctx, hipMemsetAsync(acounters + 16, 0, 16 * sizeof(uint32_t), ctx->stream));   // work counters of both passes
+  // item counts [0,1] big / [3,4] small, fallback count [2], work counters of both passes [16..32)
+  SWA_HIP(ctx, hipMemsetAsync(acounters, 0, 32 * sizeof(uint32_t), ctx->stream));
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
   auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
   swa_t0(ctx, 3);
+  // work items of this call: only groups that own a seed of [first, first+count) (all of them
+  // when the whole database is queried)
+  const uint64_t asize = ctx->anchor_slots;
+  const bool whole = first == 0 && count == ctx->db.n;
+  uint8_t * wanted[2] = {nullptr, nullptr};
+  if (!whole) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_awanted, 2 * asize));
+    SWA_HIP(ctx, hipMemsetAsync(ctx->d_awanted.ptr, 0, 2 * asize, ctx->stream));
+    wanted[0] = static_cast<uint8_t *>(ctx->d_awanted.ptr);
+    wanted[1] = wanted[0] + asize;
+    hipLaunchKernelGGL(k_anchor_flag, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first, count,
+                       static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_aslot[1].ptr),
+                       wanted[0], wanted[1]);
+  }
+  for (int which = 0; which < 2; ++which) {
+    hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
+                       static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
+                       static_cast<swa_item *>(ctx->d_aitems[which].ptr), acounters + which,
+                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + (ctx->db.n / 2 + 64), acounters + 3 + which,
+                       wanted[which]);
+  }
+  SWA_HIP(ctx, hipGetLastError());
   for (int pass = 0; pass < 2; ++pass) {
     AnchorArgs a{};
     a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen; a.abundance = ctx->db.abundance;
