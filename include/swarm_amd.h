@@ -129,6 +129,21 @@ uint64_t swa_d1_table_size(const swa_ctx * ctx);
    (src/algod1.cc:1394-1396, 1436-1438, 1469-1470). */
 int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
                       uint32_t * graft_cand, uint64_t * counters);
+/* Multi-GPU form: the light side (Bloom + light table, src/algod1.cc:453-489) is built whole
+   on this GPU, the heavy side (check_heavy_thread, src/algod1.cc:492-552) covers only slice
+   `shard` of `nshards` of the heavy amplicons.  Combining the shards: graft_cand = element-wise
+   minimum (the reference keeps the smallest heavy id, src/algod1.cc:244-258), counters[1] and
+   counters[2] add up, counters[0], [3], [4] are identical on every shard. */
+int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
+                            uint32_t shard, uint32_t nshards, uint32_t * graft_cand, uint64_t * counters);
+
+/* ---- d = 0: dereplication -------------------------------
+   Replaces the bucket search of dereplicating() (src/derep.cc:276-354: Zobrist hash, open
+   addressing, exact sequence comparison on a hash match).  first_identical[i] = the smallest
+   amplicon index whose sequence is identical to amplicon i's (== i for the first occurrence);
+   caller allocates u32[n].  Independent of swa_d1_index_build, and invalidates a d = 1 index
+   built on the same context. */
+int swa_derep(swa_ctx * ctx, uint32_t * first_identical);
 
 /* ---- B3: q-gram prefilter -------------------------------------------------------- */
 /* 1024-bit 5-mer parity signature per amplicon (src/qgram.cc:68-96), kept in HBM */

@@ -89,6 +89,23 @@ int swa_dn_write_seeds(const swa_dn_result * res, const swa_hostdb * db, const c
 int swa_dn_write_uclust(const swa_dn_result * res, const swa_hostdb * db, const char * path, int usearch_abundance,
                         int64_t append_abundance);
 
+/* ---- d = 0: dereplication (src/derep.cc) ------------------------------------------------
+   Clusters of identical sequences from swa_derep's array: members in db order, the first one
+   is the seed; clusters by decreasing mass, then by seed index (src/derep.cc:67-90). */
+typedef struct swa_d0_result swa_d0_result;
+int  swa_d0_cluster(const swa_hostdb * db, const uint32_t * first_identical, swa_d0_result ** out);
+void swa_d0_result_free(swa_d0_result * res);
+/* out3 = {clusters, largest cluster (members), heaviest cluster (mass)}  (src/derep.cc:405-410) */
+void swa_d0_result_summary(const swa_d0_result * res, uint64_t * out3);
+/* writers: src/derep.cc:207-273 (-o / -r), 188-204 (-w), 107-124 (-s), 127-148 (-i), 151-185 (-u) */
+int swa_d0_write_swarms(const swa_d0_result * res, const swa_hostdb * db, const char * path, int mothur,
+                        int usearch_abundance, int64_t append_abundance, int64_t differences);
+int swa_d0_write_seeds(const swa_d0_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_d0_write_stats(const swa_d0_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_d0_write_structure(const swa_d0_result * res, const swa_hostdb * db, const char * path, int usearch_abundance);
+int swa_d0_write_uclust(const swa_d0_result * res, const swa_hostdb * db, const char * path, int usearch_abundance,
+                        int64_t append_abundance);
+
 #ifdef __cplusplus
 }
 #endif

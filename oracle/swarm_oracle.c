@@ -524,3 +524,39 @@ uint64_t orc_nw_diff(const uint64_t * dseq, uint32_t dlen, const uint64_t * qseq
   free(he); free(dir);
   return alength - matches;
 }
+
+/* ------------------------------------------------------------------------------
+ * d = 0: dereplication, src/derep.cc:276-354 (dereplicating).  Buckets are found by
+ * hash & (tablesize - 1) with linear probing and wrap-around; a bucket matches when the hash,
+ * the length and the packed sequence are all equal.  Output: per amplicon the first amplicon
+ * (in db order) with the identical sequence — the reference's bucket.seqno_first.
+ * ------------------------------------------------------------------------------ */
+int orc_derep(const orc_db * db, uint32_t * first_identical) {
+  const uint32_t n = db->n;
+  if (n == 0) return 0;
+  const uint64_t tsize = orc_hashtable_size(n);                     /* derep.cc:387 */
+  const uint64_t mask = tsize - 1;
+  uint64_t * bhash = (uint64_t *)calloc(tsize, sizeof(uint64_t));
+  uint32_t * bfirst = (uint32_t *)malloc(tsize * sizeof(uint32_t));
+  uint8_t * used = (uint8_t *)calloc(tsize, 1);                     /* the reference tests mass != 0 */
+  const uint32_t zlen = db->longest + 2;
+  uint64_t * tab = (uint64_t *)malloc(4ULL * zlen * sizeof(uint64_t));
+  if (!bhash || !bfirst || !used || !tab) { free(bhash); free(bfirst); free(used); free(tab); return 1; }
+  orc_zobrist_table(zlen, tab);
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint64_t * seq = db->seqs + db->seq_off[i];
+    const uint32_t len = db->seqlen[i];
+    const uint64_t h = orc_zobrist_hash(tab, seq, len);
+    uint64_t b = h & mask;                                          /* derep.cc:299 */
+    while (used[b]) {
+      const uint32_t f = bfirst[b];
+      if (bhash[b] == h && db->seqlen[f] == len &&
+          memcmp(seq, db->seqs + db->seq_off[f], 8ULL * ((len + 31U) / 32U)) == 0) break;
+      b = (b + 1) & mask;                                           /* derep.cc:308-315 */
+    }
+    if (!used[b]) { used[b] = 1; bhash[b] = h; bfirst[b] = i; }     /* derep.cc:325-332 */
+    first_identical[i] = bfirst[b];
+  }
+  free(bhash); free(bfirst); free(used); free(tab);
+  return 0;
+}

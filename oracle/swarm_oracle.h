@@ -117,6 +117,10 @@ uint64_t orc_d1_network(const orc_db * db, orc_d1_index * ix, int no_cluster_bre
 int orc_d1_fastidious(const orc_db * db, const uint8_t * is_light, uint64_t light_nt,
                       uint32_t bloom_bits, uint32_t * graft_cand, uint64_t * counters);
 
+/* ---- d = 0: dereplication (src/derep.cc:276-354).  first_identical[i] = first amplicon in db
+        order with the identical sequence (== i for a first occurrence).  0 on success. */
+int orc_derep(const orc_db * db, uint32_t * first_identical);
+
 /* ---- B3: q-gram prefilter (src/qgram.cc:68-96, 247-252) ----------------------- */
 void     orc_findqgrams(const uint64_t * seq, uint32_t len, uint8_t * out128);
 uint64_t orc_qgram_diff(const uint8_t * a128, const uint8_t * b128);

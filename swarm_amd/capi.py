@@ -38,7 +38,7 @@ class DbView(C.Structure):
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize",
     "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_network", "swa_d1_network_device",
-    "swa_d1_debug_read", "swa_d1_table_size", "swa_d1_fastidious", "swa_qgram_build", "swa_qgram_diff",
+    "swa_d1_debug_read", "swa_d1_table_size", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
     "swa_hostdb_header", "swa_d1_cluster", "swa_d1_result_free", "swa_d1_result_summary", "swa_d1_result_swarmid",
@@ -83,6 +83,8 @@ def load_library() -> C.CDLL:
     lib.swa_d1_table_size.argtypes = [C.c_void_p]
     lib.swa_d1_table_size.restype = C.c_uint64
     lib.swa_d1_fastidious.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.swa_d1_fastidious_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_void_p]
     lib.swa_qgram_build.argtypes = [C.c_void_p]
     lib.swa_qgram_diff.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.swa_qgram_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -354,12 +356,15 @@ class Context:
         return out
 
     # ---- B2
-    def d1_fastidious(self, is_light: np.ndarray, light_nt: int, bloom_bits: int = 16):
+    def d1_fastidious(self, is_light: np.ndarray, light_nt: int, bloom_bits: int = 16, shard: int = 0,
+                      nshards: int = 1):
+        """B2.  With nshards > 1 only slice `shard` of the heavy amplicons is expanded on this GPU;
+        combine the shards with sharding.combine_grafts (minimum of graft_cand, sum of counters 1, 2)."""
         is_light = np.ascontiguousarray(is_light, dtype=np.uint8)
         graft = np.zeros(self.n, dtype=np.uint32)
         counters = np.zeros(8, dtype=np.uint64)
-        self._check(self.lib.swa_d1_fastidious(self.h, _ptr(is_light), int(light_nt), int(bloom_bits),
-                                               _ptr(graft), _ptr(counters)))
+        self._check(self.lib.swa_d1_fastidious_shard(self.h, _ptr(is_light), int(light_nt), int(bloom_bits),
+                                                     int(shard), int(nshards), _ptr(graft), _ptr(counters)))
         return graft, counters
 
     # ---- B3
@@ -481,6 +486,85 @@ class DnClusters:
     def close(self) -> None:
         if getattr(self, "h", None):
             self.lib.swa_dn_result_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- d = 0: dereplication ----------------------------------------------------------------------
+
+_D0_EXPORTS = ["swa_derep", "swa_d0_cluster", "swa_d0_result_free", "swa_d0_result_summary", "swa_d0_write_swarms",
+               "swa_d0_write_seeds", "swa_d0_write_stats", "swa_d0_write_structure", "swa_d0_write_uclust"]
+EXPORTS.extend(_D0_EXPORTS)
+
+
+def _declare_d0(lib) -> None:
+    if getattr(lib, "_d0_declared", False):
+        return
+    lib.swa_derep.argtypes = [C.c_void_p, C.c_void_p]
+    lib.swa_d0_cluster.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.swa_d0_result_free.argtypes = [C.c_void_p]
+    lib.swa_d0_result_free.restype = None
+    lib.swa_d0_result_summary.argtypes = [C.c_void_p, u64p]
+    lib.swa_d0_result_summary.restype = None
+    lib.swa_d0_write_swarms.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_int64]
+    for fn in (lib.swa_d0_write_seeds, lib.swa_d0_write_stats, lib.swa_d0_write_structure):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.swa_d0_write_uclust.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int64]
+    lib._d0_declared = True
+
+
+def derep(ctx: "Context") -> np.ndarray:
+    """swa_derep: per amplicon the smallest index with the identical sequence (GPU)."""
+    _declare_d0(ctx.lib)
+    out = np.zeros(ctx.n, dtype=np.uint32)
+    ctx._check(ctx.lib.swa_derep(ctx.h, _ptr(out)))
+    return out
+
+
+class D0Clusters:
+    """d = 0 clustering (src/derep.cc) from swa_derep's array; host side only."""
+
+    def __init__(self, hdb: HostDb, first_identical: np.ndarray):
+        self.lib = load_library()
+        _declare_d0(self.lib)
+        self.hdb = hdb
+        first_identical = np.ascontiguousarray(first_identical, dtype=np.uint32)
+        h = C.c_void_p()
+        rc = self.lib.swa_d0_cluster(hdb.h, _ptr(first_identical), C.byref(h))
+        if rc != SWA_OK:
+            raise SwaError(rc, "swa_d0_cluster failed")
+        self.h = h
+
+    def summary(self) -> dict:
+        out = np.zeros(3, dtype=np.uint64)
+        self.lib.swa_d0_result_summary(self.h, _p64(out))
+        return {"swarms": int(out[0]), "largest": int(out[1]), "heaviest": int(out[2])}
+
+    def write_swarms(self, path, mothur=False, usearch=False, append_abundance=0) -> None:
+        assert self.lib.swa_d0_write_swarms(self.h, self.hdb.h, str(path).encode(), int(mothur), int(usearch),
+                                            append_abundance, 0) == SWA_OK
+
+    def write_seeds(self, path, usearch=False) -> None:
+        assert self.lib.swa_d0_write_seeds(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_stats(self, path, usearch=False) -> None:
+        assert self.lib.swa_d0_write_stats(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_structure(self, path, usearch=False) -> None:
+        assert self.lib.swa_d0_write_structure(self.h, self.hdb.h, str(path).encode(), int(usearch)) == SWA_OK
+
+    def write_uclust(self, path, usearch=False, append_abundance=0) -> None:
+        assert self.lib.swa_d0_write_uclust(self.h, self.hdb.h, str(path).encode(), int(usearch),
+                                            append_abundance) == SWA_OK
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.swa_d0_result_free(self.h)
             self.h = None
 
     def __del__(self):

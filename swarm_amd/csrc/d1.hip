@@ -915,34 +915,18 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   return SWA_OK;
 }
 
-extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
-  if (ctx == nullptr) { return SWA_E_ARG; }
-  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build: no database"); }
-  SWA_HIP(ctx, hipSetDevice(ctx->device));
+// Zobrist table + per-amplicon sequence hashes (src/db.cc:761, src/zobrist.cc:89-112) and the
+// anchored-index metadata; shared by the d = 1 index and the d = 0 dereplication
+int swa_hash_sequences(swa_ctx * ctx) {
   const uint32_t n = ctx->db.n;
-  ctx->d1_ready = false;
   ctx->zobrist_len = ctx->db.longest + 2;                  // db.cc:652-653 (sequence part)
-  ctx->table_size = swa_hashtable_size(n);
-  const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
-  ctx->bloom_words = bloom_bytes >> 3;
-
   std::vector<uint64_t> zob;
-  std::vector<uint64_t> pat;
   swa_zobrist_table(ctx->zobrist_len, zob);
-  swa_bloom_patterns(1024, 8, pat);
   SWA_TRY(swa_reserve(ctx, ctx->d_zobrist, zob.size() * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_patterns, pat.size() * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_seqhash, uint64_t(n) * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_aux, uint64_t(n) * sizeof(swa_aux)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_table, ctx->table_size * sizeof(swa_slot)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_bloom, ctx->bloom_words * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemcpyAsync(ctx->d_zobrist.ptr, zob.data(), zob.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_patterns.ptr, pat.data(), pat.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
-  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));        // zob / pat are host temporaries
-
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));        // zob is a host temporary
   const size_t zbytes = zob.size() * sizeof(uint64_t);
   const int hgrid = grid_for(ctx, n, 256, 8);
   swa_t0(ctx, 0);
@@ -957,6 +941,31 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   }
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 0);
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build: no database"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  ctx->d1_ready = false;
+  ctx->anchor_ready = false;
+  ctx->table_size = swa_hashtable_size(n);
+  const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
+  ctx->bloom_words = bloom_bytes >> 3;
+
+  std::vector<uint64_t> pat;
+  swa_bloom_patterns(1024, 8, pat);
+  SWA_TRY(swa_reserve(ctx, ctx->d_patterns, pat.size() * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_table, ctx->table_size * sizeof(swa_slot)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_bloom, ctx->bloom_words * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_patterns.ptr, pat.data(), pat.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
+  SWA_TRY(swa_hash_sequences(ctx));                        // also synchronises: pat is a host temporary
+  const int hgrid = grid_for(ctx, n, 256, 8);
   swa_t0(ctx, 1);
   SWA_TRY(swa_d1_rebuild_table(ctx, nullptr));
   swa_t1(ctx, 1);
@@ -1150,7 +1159,13 @@ extern "C" int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out
 //           light amplicon — the reference's add_graft_candidate under a mutex.
 extern "C" int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
                                  uint32_t * graft_cand, uint64_t * counters) {
+  return swa_d1_fastidious_shard(ctx, is_light, light_nt, bloom_bits, 0, 1, graft_cand, counters);
+}
+
+extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
+                                       uint32_t shard, uint32_t nshards, uint32_t * graft_cand, uint64_t * counters) {
   if (ctx == nullptr) { return SWA_E_ARG; }
+  if (nshards == 0 || shard >= nshards) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious_shard: bad shard"); }
   if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: call swa_d1_index_build first"); }
   if (is_light == nullptr || graft_cand == nullptr || counters == nullptr || bloom_bits < 2 || bloom_bits > 64) {
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: bad argument");
@@ -1167,6 +1182,11 @@ extern "C" int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64
 
   std::vector<uint32_t> light_ids, heavy_ids;
   for (uint32_t i = 0; i < n; ++i) { (is_light[i] != 0 ? light_ids : heavy_ids).push_back(i); }
+  if (nshards > 1) {                       // this shard's contiguous slice of the heavy amplicons
+    const uint64_t h = heavy_ids.size();
+    const uint64_t lo = h * shard / nshards, hi = h * (shard + 1ull) / nshards;
+    heavy_ids.assign(heavy_ids.begin() + (ptrdiff_t)lo, heavy_ids.begin() + (ptrdiff_t)hi);
+  }
   std::vector<uint64_t> fpat;
   swa_bloom_patterns(65536, k, fpat);
 

@@ -252,10 +252,6 @@ int main(int argc, char ** argv) {
   std::fprintf(g_log, "Database info:     %" PRIu64 " nt in %u sequences, longest %u nt\n", swa_hostdb_nucleotides(db),
                view.n, view.longest);
 
-  if (o.differences == 0) {
-    die("d = 0 (dereplication) is not part of the GPU neighbour-finding build; use the reference for -d 0.");
-  }
-
   const uint32_t n = view.n;
   swa_ctx * ctx = nullptr;
   if (n > 0) {
@@ -267,7 +263,26 @@ int main(int argc, char ** argv) {
     if (swa_db_upload(ctx, &view) != SWA_OK) { die(swa_last_error(ctx)); }
   }
 
-  if (o.differences == 1) {
+  if (o.differences == 0) {
+    // ---- d = 0: identical-sequence search on the GPU, cluster bookkeeping on the host
+    std::vector<uint32_t> first_identical(n);
+    if (n > 0 && swa_derep(ctx, first_identical.data()) != SWA_OK) { die(swa_last_error(ctx)); }
+    swa_d0_result * res = nullptr;
+    if (swa_d0_cluster(db, first_identical.data(), &res) != SWA_OK) { die("dereplication failed"); }
+    phase(o, "Dereplicating:    ");
+    phase(o, "Sorting:          ");
+    check_writer(swa_d0_write_swarms(res, db, o.output.c_str(), o.mothur, o.usearch, o.append_abundance, o.differences), "output");
+    phase(o, "Writing swarms:   ");
+    if (!o.seeds.empty()) { check_writer(swa_d0_write_seeds(res, db, o.seeds.c_str(), o.usearch), "seeds"); phase(o, "Writing seeds:    "); }
+    if (!o.uclust.empty()) { check_writer(swa_d0_write_uclust(res, db, o.uclust.c_str(), o.usearch, o.append_abundance), "uclust"); phase(o, "Writing UCLUST:   "); }
+    if (!o.structure.empty()) { check_writer(swa_d0_write_structure(res, db, o.structure.c_str(), o.usearch), "internal structure"); phase(o, "Writing structure:"); }
+    if (!o.stats.empty()) { check_writer(swa_d0_write_stats(res, db, o.stats.c_str(), o.usearch), "statistics"); phase(o, "Writing stats:    "); }
+    uint64_t sum[3];
+    swa_d0_result_summary(res, sum);
+    std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nHeaviest swarm:    %" PRIu64 "\n", sum[0],
+                 sum[1], sum[2]);
+    swa_d0_result_free(res);
+  } else if (o.differences == 1) {
     // ---- seam B1: the network on the GPU
     std::vector<uint64_t> offsets((size_t)n + 1, 0);
     std::vector<uint32_t> neighbours;

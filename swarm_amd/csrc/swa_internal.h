@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -86,6 +87,7 @@ int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e);
 int swa_fail_msg(swa_ctx * ctx, int code, const std::string & msg);
 int swa_reserve(swa_ctx * ctx, swa_dbuf & buf, size_t bytes);   // grow-only hipMalloc
 void swa_release(swa_dbuf & buf);
+int swa_hash_sequences(swa_ctx * ctx);                           // d1.hip: Zobrist table + d_seqhash + d_aux
 
 // RAII-less timing brackets: SWA_T0(ctx, slot) ... SWA_T1(ctx, slot)
 inline void swa_t0(swa_ctx * ctx, int slot) {

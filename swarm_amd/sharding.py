@@ -86,3 +86,26 @@ def allgather_csr(local_offsets: torch.Tensor, local_nb: torch.Tensor, local_tot
     offsets[n] = base
     neighbours = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.int32, device=dev)
     return offsets, neighbours
+
+
+def combine_grafts(graft_cand, counters, device=None, group=None):
+    """Fastidious pass split over ranks by heavy-amplicon slice (swa_d1_fastidious_shard):
+    the reference keeps, per light amplicon, the smallest heavy id that reaches it
+    (src/algod1.cc:244-258), so the shards combine with an element-wise MIN all-reduce
+    (SWA_NO_AMPLICON = 0xFFFFFFFF is the neutral element); "heavy variants" and "graft
+    candidates" (counters[1], [2]) add up, the other counters are the same on every rank.
+
+    graft_cand : uint32 [n] numpy array (this rank's shard result)
+    counters   : uint64 [>= 5] numpy array
+    Returns (graft_cand uint32 [n], counters uint64) as numpy arrays, identical on all ranks.
+    """
+    g = torch.from_numpy(np.ascontiguousarray(graft_cand, dtype=np.uint32).astype(np.int64))
+    c = torch.from_numpy(np.ascontiguousarray(counters, dtype=np.uint64).astype(np.int64))
+    add = c[1:3].clone()
+    if device is not None:
+        g, add = g.to(device), add.to(device)
+    dist.all_reduce(g, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(add, op=dist.ReduceOp.SUM, group=group)
+    out_c = np.array(counters, dtype=np.uint64, copy=True)
+    out_c[1:3] = add.cpu().numpy().astype(np.uint64)
+    return g.cpu().numpy().astype(np.uint32), out_c

@@ -86,6 +86,38 @@ def usearch_case() -> None:
     (HERE / f"{name}.args").write_text(" ".join(args) + "\n")
 
 
+def derep_case() -> None:
+    """-d 0: raw-read-like input with many identical sequences (different headers / abundances /
+    letter case), abundance-1 entries, and clusters that tie on mass."""
+    src = S.read_fasta(HERE / "d1_short.fasta")[:120]
+    rng = np.random.default_rng(404)
+    entries = []
+    for k, (h, s) in enumerate(src):
+        copies = 1 + int(rng.geometric(0.45)) if k % 4 else 1
+        for c in range(copies):
+            ab = int(rng.choice([1, 1, 2, 3, 5, 8, 40]))
+            body = s.lower() if (k + c) % 3 == 0 else s
+            entries.append((f"r{k}c{c}_{ab}".encode(), body))
+    order = rng.permutation(len(entries))
+    fa = HERE / "d0_derep.fasta"
+    with open(fa, "wb") as fh:
+        for j in order:
+            h, body = entries[j]
+            fh.write(b">" + h + b"\n" + body + b"\n")
+    for name, args, keep in (("d0_derep", ["-d", "0"], "osiwu"), ("d0_mothur", ["-d", "0", "-r", "-a", "1"], "o")):
+        cmd = list(args)
+        for k in keep:
+            cmd += [FLAG[k], str(HERE / f"{name}.{k}")]
+        log = HERE / f"{name}.log"
+        cmd += ["-l", str(log), str(fa)]
+        r = S.run_ref_swarm(cmd)
+        assert r.returncode == 0, (name, r.stderr)
+        lines = [ln for ln in log.read_text().splitlines()
+                 if re.match(r"^(Database info|Number of swarms|Largest swarm|Heaviest swarm|Resolution)", ln)]
+        log.write_text("\n".join(lines) + "\n")
+        (HERE / f"{name}.args").write_text(" ".join(args) + "\n")
+
+
 def function_vectors() -> None:
     """Known answers of the reference's hot-path functions (through oracle/_ref/libswarmref.so)."""
     code = r'''
@@ -168,6 +200,10 @@ json.dump(out, open(%r, "w"))
 
 def main() -> None:
     assert S.have_reference(), "needs /root/reference (oracle/_ref) — run in the build container"
+    if sys.argv[1:] == ["derep"]:                      # add the d = 0 fixtures only
+        derep_case()
+        return
+    derep_case()
     for name, (gen, args, keep) in CASES.items():
         run_case(name, gen, args, keep)
     usearch_case()

@@ -224,6 +224,16 @@ def oracle_d1_network(db: Db, no_cluster_breaking: bool = False, first: int = 0,
         lib.orc_d1_index_free(ix)
 
 
+def oracle_derep(db: Db) -> np.ndarray:
+    lib = oracle()
+    lib.orc_derep.restype = C.c_int
+    lib.orc_derep.argtypes = [C.POINTER(OrcDb), u32p]
+    odb = orc_db(db)
+    out = np.zeros(db.n, dtype=np.uint32)
+    assert lib.orc_derep(C.byref(odb), _p(out, u32p)) == 0
+    return out
+
+
 def oracle_fastidious(db: Db, is_light: np.ndarray, bloom_bits: int = 16):
     lib = oracle()
     odb = orc_db(db)

@@ -13,7 +13,7 @@ G = S.GOLDEN
 BIN = S.ROOT / "swarm_amd" / "bin" / "swarm"
 FLAG = {"o": "-o", "s": "-s", "i": "-i", "w": "-w", "j": "-j", "u": "-u"}
 CASES = ["d1_1k", "d1_nobreak", "d1_mothur", "d1_short", "d1_usearch", "d1_fastidious", "d1_fastidious_b10_y8",
-         "d1_uclust", "d2_small", "d3_400", "d5_ties", "d8_16bit"]
+         "d1_uclust", "d2_small", "d3_400", "d5_ties", "d8_16bit", "d0_derep", "d0_mothur"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -23,7 +23,8 @@ def test_cli_matches_reference_files(tmp_path, name):
     cmd = [str(BIN)] + args
     for k in kept:
         cmd += [FLAG[k], str(tmp_path / k)]
-    cmd += ["-l", str(tmp_path / "log"), str(G / f"{name}.fasta")]
+    fasta = G / ("d0_derep.fasta" if name.startswith("d0_") else f"{name}.fasta")
+    cmd += ["-l", str(tmp_path / "log"), str(fasta)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for k in kept:

@@ -55,3 +55,24 @@ def test_fastidious_matches_oracle(gpu_ctx, tmp_path, n, length, seed, light, bo
     want_graft, want_counters = S.oracle_fastidious(db, flags, bits)
     assert np.array_equal(graft, want_graft)
     assert [int(x) for x in counters[:5]] == [int(x) for x in want_counters[:5]]
+
+
+@pytest.mark.parametrize("nshards", [2, 3])
+def test_fastidious_shards_combine_to_whole(gpu_ctx, tmp_path, nshards):
+    """heavy amplicons split over GPUs; minimum of graft_cand, sum of the heavy
+    counters == the unsharded pass (each shard run on this one GPU in turn)."""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 12000, 120, 51, 1, 0.3)
+    hdb, cl, flags, stats, graft, counters = _pipeline(gpu_ctx, fa, 3, 16)
+    assert (graft != 0xFFFFFFFF).sum() > 50
+    merged = np.full(hdb.n, 0xFFFFFFFF, dtype=np.uint32)
+    heavy_variants = candidates = 0
+    for shard in range(nshards):
+        assert gpu_ctx.d1_index_build() is False           # the fastidious pass re-purposes the table
+        g, c = gpu_ctx.d1_fastidious(flags, stats[2], 16, shard, nshards)
+        assert int(c[0]) == int(counters[0]) and (int(c[3]), int(c[4])) == (int(counters[3]), int(counters[4]))
+        merged = np.minimum(merged, g)
+        heavy_variants += int(c[1])
+        candidates += int(c[2])
+    assert np.array_equal(merged, graft)
+    assert (heavy_variants, candidates) == (int(counters[1]), int(counters[2]))

@@ -77,3 +77,42 @@ def test_partitions_cover_range():
                     assert f0 + c0 == f1
     lens = np.full(1000, 150, dtype=np.uint32)
     assert all(abs(c - 125) <= 1 for _, c in sharding.partition_by_length(lens, 8))
+
+
+GRAFT_WORKER = textwrap.dedent('''
+    import sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, sys.argv[1])
+    from swarm_amd import sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    NO = 0xFFFFFFFF
+    rng = np.random.default_rng(5)                       # same stream on every rank
+    n = 5000
+    full = np.where(rng.random(n) < 0.3, rng.integers(0, n, size=n), NO).astype(np.uint32)
+    owner = rng.integers(0, world, size=n)               # the rank whose heavy slice holds the minimum
+    worse = np.minimum(full.astype(np.int64) + rng.integers(1, 50, size=n), NO - 1).astype(np.uint32)
+    other = np.where(rng.random(n) < 0.5, worse, NO).astype(np.uint32)   # a larger candidate or none
+    mine = np.where(full == NO, NO, np.where(owner == rank, full, other)).astype(np.uint32)
+    counters = np.array([1234, 100 + rank, 7 * (rank + 1), 4096, 6, 0, 0, 0], dtype=np.uint64)
+    g, c = sharding.combine_grafts(mine, counters)
+    assert g.dtype == np.uint32 and np.array_equal(g, full), "graft minimum differs"
+    assert int(c[1]) == sum(100 + r for r in range(world)) and int(c[2]) == sum(7 * (r + 1) for r in range(world))
+    assert [int(c[0]), int(c[3]), int(c[4])] == [1234, 4096, 6]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+''')
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_combine_grafts_min_and_sum(tmp_path, world):
+    script = tmp_path / "worker.py"
+    script.write_text(GRAFT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), str(S.ROOT)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == world
