@@ -869,16 +869,16 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.item_count = acounters + 3 + pass;
     a.sched = acounters + 16 + 8 * pass;
     a.table_slots = 2 * kSmallGroup;
-    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup / 4));
-    if (zlds) { hipLaunchKernelGGL((k_d1_anchor<true, true>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
-    else { hipLaunchKernelGGL((k_d1_anchor<false, true>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
+    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup / 2));
+    if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
     a.item_count = acounters + pass;
     a.table_slots = 2 * kGroupCap;
-    const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 8);
-    if (zlds) { hipLaunchKernelGGL((k_d1_anchor<true, false>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
-    else { hipLaunchKernelGGL((k_d1_anchor<false, false>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 4);
+    if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_d1_anchor<false, 1>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     SWA_HIP(ctx, hipGetLastError());
   }
   // seeds (or halves of seeds) the anchored passes skipped
