@@ -782,6 +782,9 @@ static int build_anchor_index(swa_ctx * ctx) {
     SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], (uint64_t(n) + 128) * sizeof(swa_item)));   // big | small halves
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
+  hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
+                     static_cast<uint32_t *>(ctx->d_arank.ptr), static_cast<uint32_t *>(ctx->d_flags.ptr));
   const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
@@ -852,6 +855,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
     a.zlen = ctx->zobrist_len; a.maxwords = maxwords;
     a.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
+    a.rank = static_cast<const uint32_t *>(ctx->d_arank.ptr);
     a.members = static_cast<const uint32_t *>(ctx->d_amembers[pass].ptr);
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
     a.item_count = acounters + pass;
@@ -862,21 +866,21 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.seg_cap = ctx->seg_cap;
     a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
     a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
-    const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + kRing);   // in u64 units
+    const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + kRing + 2 * kPend);   // in u64 units
     const int grid = ctx->num_cus * 8;
     // small groups: one wave per group
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr) + (ctx->db.n / 2 + 64);
     a.item_count = acounters + 3 + pass;
     a.sched = acounters + 16 + 8 * pass;
     a.table_slots = 2 * kSmallGroup;
-    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup / 2));
+    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup / 2));   // table + ranks + Bloom
     if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
     a.item_count = acounters + pass;
     a.table_slots = 2 * kGroupCap;
-    const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 4);
+    const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 2 + a.table_slots / 4);
     if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<false, 1>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     SWA_HIP(ctx, hipGetLastError());
@@ -979,9 +983,11 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   swa_t0(ctx, 7);
   SWA_TRY(build_anchor_index(ctx));
   swa_t1(ctx, 7);
-  uint32_t flag = 0;
-  SWA_HIP(ctx, hipMemcpyAsync(&flag, ctx->d_flags.ptr, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t flags[2] = {0, 0};                               // [0] duplicates [1] abundances not in descending order
+  SWA_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags.ptr, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t flag = flags[0];
+  if (flags[1] != 0) { ctx->anchor_ready = false; }         // the anchored passes rely on the db order
   ctx->d1_ready = true;
   if (has_duplicates != nullptr) { *has_duplicates = flag != 0 ? 1 : 0; }
   if (flag != 0) {

@@ -60,7 +60,7 @@ struct swa_ctx {
   bool anchor_ready = false;
   uint64_t anchor_slots = 0;
   swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_acursor[2], d_aoffsets[2], d_aslot[2], d_amembers[2], d_aitems[2];
-  swa_dbuf d_acounters, d_afallback, d_awanted;
+  swa_dbuf d_acounters, d_afallback, d_awanted, d_arank;
   swa_dbuf d_seg_fill;           // u32 fill of every per-wave edge segment
   uint64_t seg_cap = 0;          // entries per segment
 
