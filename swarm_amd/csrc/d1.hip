@@ -873,7 +873,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.item_count = acounters + 3 + pass;
     a.sched = acounters + 16 + 8 * pass;
     a.table_slots = 2 * kSmallGroup;
-    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup / 2));   // table + ranks + Bloom
+    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom
     if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk

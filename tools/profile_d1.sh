@@ -27,16 +27,5 @@ done
 # keep the merged directory small: drop everything but the CSV summaries and logs
 find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 ls -la "$OUT"
-python - "$OUT" <<'EOF'
-import csv, sys, collections, glob, os
-out = sys.argv[1]
-for f in sorted(glob.glob(os.path.join(out, 'pmc*.csv'))):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    with open(f) as fh:
-        for row in csv.DictReader(fh):
-            agg[row['Kernel_Name'][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
-    for k, cs in agg.items():
-        if 'network' not in k: continue
-        print(os.path.basename(f), k, {c: sum(v)/len(v) for c, v in cs.items()}, 'launches', len(next(iter(cs.values()))))
-EOF
+python $REPO/tools/summarize_pmc.py "$OUT" $((STEPS+1)) "${3:-1000000x150_s1}" "$OUT/d1_network_pmc.json"
 head -8 "$OUT/kernel_stats.csv"
