@@ -178,3 +178,27 @@ def test_very_long_sequences_use_plain_kernel(gpu_ctx, tmp_path):
     S.gen_fasta(fa, 120, 5000, 31)
     db = S.db_from_fasta(fa)
     _check_vs_oracle(gpu_ctx, db)
+
+
+def test_unsorted_abundances_still_exact(gpu_ctx, tmp_path):
+    """The anchored passes apply the abundance rule through ranks, which presumes the reference's
+    db order (abundance descending).  A caller that uploads another order must still get the
+    rule applied to the abundances themselves (the library notices and uses the plain kernel)."""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 4000, 150, 61)
+    db = S.db_from_fasta(fa)
+    rng = np.random.default_rng(3)
+    db.abundance = np.ascontiguousarray(rng.permutation(db.abundance))
+    assert (np.diff(db.abundance.astype(np.int64)) > 0).any()
+    off, nb = _check_vs_oracle(gpu_ctx, db)
+    assert len(nb) > 500
+
+
+def test_abundance_ties_follow_the_rule(gpu_ctx, tmp_path):
+    """every amplicon has one of three abundances: the `>=` of the rule is decided by ties"""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 6000, 100, 62)
+    recs = S.read_fasta(fa)
+    db = S.build_db([(h.rsplit(b"_", 1)[0] + b"_%d" % (1 + i % 3), s) for i, (h, s) in enumerate(recs)])
+    off, nb = _check_vs_oracle(gpu_ctx, db)
+    assert len(nb) > 1000
