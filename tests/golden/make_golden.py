@@ -118,6 +118,30 @@ def derep_case() -> None:
         (HERE / f"{name}.args").write_text(" ".join(args) + "\n")
 
 
+TINY = {
+    "tiny_one": b">a_1\nA\n",
+    "tiny_mix": b">a_2\nA\n>b_1\nC\n>c_1\nAA\n>d_1\nAC\n>e_3\nG\n>f_1\nacgu\n>g_1\nACGTT\n>h_2\nACG\n",
+    "tiny_empty": b"",
+}
+
+
+def tiny_cases() -> None:
+    """Edge inputs: one amplicon of one nucleotide, lengths 1..5 (deletions down to the empty
+    sequence, lower case, U), and an empty file — at d = 0, 1, 2."""
+    for name, text in TINY.items():
+        fa = HERE / f"{name}.fasta"
+        fa.write_bytes(text)
+        for d in (0, 1, 2):
+            case = f"{name}_d{d}"
+            cmd = ["-d", str(d)]
+            for k in "osi":
+                cmd += [FLAG[k], str(HERE / f"{case}.{k}")]
+            cmd += ["-l", "/dev/null", str(fa)]
+            r = S.run_ref_swarm(cmd)
+            assert r.returncode == 0, (case, r.stderr)
+            (HERE / f"{case}.args").write_text(f"-d {d}\n")
+
+
 def function_vectors() -> None:
     """Known answers of the reference's hot-path functions (through oracle/_ref/libswarmref.so)."""
     code = r'''
@@ -203,7 +227,11 @@ def main() -> None:
     if sys.argv[1:] == ["derep"]:                      # add the d = 0 fixtures only
         derep_case()
         return
+    if sys.argv[1:] == ["tiny"]:
+        tiny_cases()
+        return
     derep_case()
+    tiny_cases()
     for name, (gen, args, keep) in CASES.items():
         run_case(name, gen, args, keep)
     usearch_case()

@@ -14,6 +14,7 @@ BIN = S.ROOT / "swarm_amd" / "bin" / "swarm"
 FLAG = {"o": "-o", "s": "-s", "i": "-i", "w": "-w", "j": "-j", "u": "-u"}
 CASES = ["d1_1k", "d1_nobreak", "d1_mothur", "d1_short", "d1_usearch", "d1_fastidious", "d1_fastidious_b10_y8",
          "d1_uclust", "d2_small", "d3_400", "d5_ties", "d8_16bit", "d0_derep", "d0_mothur"]
+CASES += [f"tiny_{t}_d{d}" for t in ("one", "mix", "empty") for d in (0, 1, 2)]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -24,6 +25,8 @@ def test_cli_matches_reference_files(tmp_path, name):
     for k in kept:
         cmd += [FLAG[k], str(tmp_path / k)]
     fasta = G / ("d0_derep.fasta" if name.startswith("d0_") else f"{name}.fasta")
+    if name.startswith("tiny_"):
+        fasta = G / (name.rsplit("_d", 1)[0] + ".fasta")
     cmd += ["-l", str(tmp_path / "log"), str(fasta)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
