@@ -681,7 +681,8 @@ __global__ __launch_bounds__(256) void k_scatter_edges(const uint64_t * __restri
                                                        const uint64_t * __restrict__ offsets, uint32_t * cursor,
                                                        uint32_t * __restrict__ neighbours, uint64_t cap) {
   for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-    const uint32_t fill = seg_fill[seg];
+    const uint32_t filled = seg_fill[seg];                    // may exceed the capacity (the run is then repeated)
+    const uint32_t fill = filled < seg_cap ? filled : (uint32_t)seg_cap;
     const uint64_t * e = edges + (uint64_t)seg * seg_cap;
     for (uint32_t j = threadIdx.x; j < fill; j += blockDim.x) {
       const uint64_t edge = e[j];
@@ -692,14 +693,21 @@ __global__ __launch_bounds__(256) void k_scatter_edges(const uint64_t * __restri
   }
 }
 
-// rows are tiny (about two neighbours per amplicon): one thread insertion-sorts a row;
-// long rows (> 64) are sorted by a whole wave with an odd-even transposition sort
+// rows are tiny (about two neighbours per amplicon): one thread insertion-sorts a row; rows
+// longer than 64 are queued (long_rows[0] = count, then the row indices) and sorted by a whole
+// wave each with an odd-even transposition sort
 __global__ __launch_bounds__(256) void k_sort_rows(const uint64_t * __restrict__ offsets, uint32_t count,
-                                                   uint32_t * neighbours, uint64_t cap) {
+                                                   uint32_t * neighbours, uint64_t cap, uint32_t * long_rows,
+                                                   uint32_t long_cap) {
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
     const uint64_t b = offsets[k];
     const uint64_t e = offsets[k + 1];
-    if (e > cap || e - b < 2 || e - b > 64) { continue; }
+    if (e > cap || e - b < 2) { continue; }
+    if (e - b > 64) {
+      const uint32_t at = atomicAdd(long_rows, 1u);
+      if (at < long_cap) { long_rows[1u + at] = k; }
+      continue;
+    }
     for (uint64_t i = b + 1; i < e; ++i) {
       const uint32_t v = neighbours[i];
       uint64_t j = i;
@@ -710,10 +718,16 @@ __global__ __launch_bounds__(256) void k_sort_rows(const uint64_t * __restrict__
 }
 
 __global__ __launch_bounds__(64) void k_sort_long_rows(const uint64_t * __restrict__ offsets, uint32_t count,
-                                                       uint32_t * neighbours, uint64_t cap) {
-  // one wave per row, grid-stride over rows; only rows longer than 64 do work
+                                                       uint32_t * neighbours, uint64_t cap,
+                                                       const uint32_t * __restrict__ long_rows, uint32_t long_cap) {
+  // one wave per queued row; if the queue overflowed (more than long_cap long rows) every row is
+  // visited instead, as a fallback
   const int lane = threadIdx.x;
-  for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+  const uint32_t queued = long_rows[0];
+  const bool all = queued > long_cap;
+  const uint32_t todo = all ? count : queued;
+  for (uint32_t q = blockIdx.x; q < todo; q += gridDim.x) {
+    const uint32_t k = all ? q : long_rows[1u + q];
     const uint64_t b = offsets[k];
     const uint64_t e = offsets[k + 1];
     const uint64_t len = e - b;
@@ -1065,6 +1079,8 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
     ctx->seg_cap = 512;
     while (ctx->seg_cap < 8ull * count / nseg) { ctx->seg_cap <<= 1; }
   }
+  constexpr uint32_t kLongRowCap = 1u << 16;
+  SWA_TRY(swa_reserve(ctx, ctx->d_long_rows, (kLongRowCap + 1ull) * sizeof(uint32_t)));
   uint64_t n_edges = 0;
   for (int attempt = 0; attempt < 3; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
@@ -1076,6 +1092,30 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
     uint64_t got[2] = {0, 0};
     SWA_HIP(ctx, hipMemcpyAsync(got, static_cast<uint64_t *>(ctx->d_stats.ptr) + 8, sizeof(got), hipMemcpyDeviceToHost,
                                 ctx->stream));
+    // CSR assembly is enqueued right behind, before the host looks at the totals: every kernel
+    // below guards its writes with `cap` / the segment capacity, so a run that turns out to
+    // need bigger segments or a bigger neighbour buffer has only wasted these launches.
+    // Offsets are always complete; neighbours only if they fit.
+    swa_t0(ctx, 4);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+                       static_cast<const uint32_t *>(ctx->d_counts.ptr), count, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+                       static_cast<const uint32_t *>(ctx->d_counts.ptr), count,
+                       static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), d_offsets);
+    if (d_neighbours != nullptr && cap > 0) {
+      SWA_HIP(ctx, hipMemsetAsync(ctx->d_cursor.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
+      SWA_HIP(ctx, hipMemsetAsync(ctx->d_long_rows.ptr, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(k_scatter_edges, dim3(std::min<uint32_t>(nseg, (uint32_t)ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
+                         static_cast<const uint64_t *>(ctx->d_edges.ptr), static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
+                         nseg, ctx->seg_cap, first, d_offsets, static_cast<uint32_t *>(ctx->d_cursor.ptr), d_neighbours, cap);
+      hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, d_offsets, count,
+                         d_neighbours, cap, static_cast<uint32_t *>(ctx->d_long_rows.ptr), kLongRowCap);
+      hipLaunchKernelGGL(k_sort_long_rows, dim3(ctx->num_cus), dim3(64), 0, ctx->stream, d_offsets, count, d_neighbours, cap,
+                         static_cast<const uint32_t *>(ctx->d_long_rows.ptr), kLongRowCap);
+    }
+    SWA_HIP(ctx, hipGetLastError());
+    swa_t1(ctx, 4);
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     n_edges = got[0];
     if (got[1] <= ctx->seg_cap) { break; }
@@ -1083,32 +1123,7 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
     while (ctx->seg_cap < got[1]) { ctx->seg_cap <<= 1; }
   }
   *total = n_edges;
-  // CSR: offsets are always complete; neighbours only if they fit
-  swa_t0(ctx, 4);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
-                     static_cast<const uint32_t *>(ctx->d_counts.ptr), count, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
-  hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
-                     static_cast<const uint32_t *>(ctx->d_counts.ptr), count,
-                     static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), d_offsets);
-  SWA_HIP(ctx, hipGetLastError());
-  if (n_edges > cap) {
-    swa_t1(ctx, 4);
-    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network: neighbour buffer too small");
-  }
-  if (n_edges > 0) {
-    SWA_HIP(ctx, hipMemsetAsync(ctx->d_cursor.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_scatter_edges, dim3(std::min<uint32_t>(nseg, (uint32_t)ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint64_t *>(ctx->d_edges.ptr), static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
-                       nseg, ctx->seg_cap, first, d_offsets, static_cast<uint32_t *>(ctx->d_cursor.ptr), d_neighbours, cap);
-    hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, d_offsets, count,
-                       d_neighbours, cap);
-    hipLaunchKernelGGL(k_sort_long_rows, dim3(grid_for(ctx, count, 1, 16)), dim3(64), 0, ctx->stream, d_offsets,
-                       count, d_neighbours, cap);
-    SWA_HIP(ctx, hipGetLastError());
-  }
-  swa_t1(ctx, 4);
+  if (n_edges > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network: neighbour buffer too small"); }
   return SWA_OK;
 }
 

@@ -55,7 +55,7 @@ struct swa_ctx {
   swa_dbuf d_flags;              // u32[16]: [0] duplicate flag
   swa_dbuf d_stats;              // u64[8] probe statistics + [8] edge counter
   swa_dbuf d_edges;              // u64 edge list (src << 32 | dst)
-  swa_dbuf d_counts, d_cursor, d_scan_tmp, d_offsets_tmp, d_nb_tmp;
+  swa_dbuf d_counts, d_cursor, d_scan_tmp, d_offsets_tmp, d_nb_tmp, d_long_rows;
   // anchored d=1 index (d1_anchor.inc): [0] prefix groups, [1] suffix groups
   bool anchor_ready = false;
   uint64_t anchor_slots = 0;
