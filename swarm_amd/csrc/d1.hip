@@ -880,7 +880,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.seg_cap = ctx->seg_cap;
     a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
     a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
-    const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + kRing + 2 * kPend);   // in u64 units
+    const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + 2 * kPend);   // in u64 units
     const int grid = ctx->num_cus * 8;
     // small groups: one wave per group
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr) + (ctx->db.n / 2 + 64);
