@@ -938,14 +938,17 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
 int swa_hash_sequences(swa_ctx * ctx) {
   const uint32_t n = ctx->db.n;
   ctx->zobrist_len = ctx->db.longest + 2;                  // db.cc:652-653 (sequence part)
-  std::vector<uint64_t> zob;
-  swa_zobrist_table(ctx->zobrist_len, zob);
-  SWA_TRY(swa_reserve(ctx, ctx->d_zobrist, zob.size() * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_seqhash, uint64_t(n) * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_aux, uint64_t(n) * sizeof(swa_aux)));
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_zobrist.ptr, zob.data(), zob.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));        // zob is a host temporary
-  const size_t zbytes = zob.size() * sizeof(uint64_t);
+  const size_t zbytes = 4ull * ctx->zobrist_len * sizeof(uint64_t);
+  if (ctx->zobrist_resident != ctx->zobrist_len) {         // the table only depends on its length: upload once
+    std::vector<uint64_t> zob;
+    swa_zobrist_table(ctx->zobrist_len, zob);
+    SWA_TRY(swa_reserve(ctx, ctx->d_zobrist, zob.size() * sizeof(uint64_t)));
+    SWA_HIP(ctx, hipMemcpyAsync(ctx->d_zobrist.ptr, zob.data(), zob.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));      // zob is a host temporary
+    ctx->zobrist_resident = ctx->zobrist_len;
+  }
   const int hgrid = grid_for(ctx, n, 256, 8);
   swa_t0(ctx, 0);
   if (zbytes <= kMaxZobristLds) {
@@ -973,16 +976,20 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
   ctx->bloom_words = bloom_bytes >> 3;
 
-  std::vector<uint64_t> pat;
-  swa_bloom_patterns(1024, 8, pat);
-  SWA_TRY(swa_reserve(ctx, ctx->d_patterns, pat.size() * sizeof(uint64_t)));
+  if (!ctx->patterns_resident) {                            // the 1024 Bloom patterns are constants: upload once
+    std::vector<uint64_t> pat;
+    swa_bloom_patterns(1024, 8, pat);
+    SWA_TRY(swa_reserve(ctx, ctx->d_patterns, pat.size() * sizeof(uint64_t)));
+    SWA_HIP(ctx, hipMemcpyAsync(ctx->d_patterns.ptr, pat.data(), pat.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));       // pat is a host temporary
+    ctx->patterns_resident = true;
+  }
   SWA_TRY(swa_reserve(ctx, ctx->d_table, ctx->table_size * sizeof(swa_slot)));
   SWA_TRY(swa_reserve(ctx, ctx->d_bloom, ctx->bloom_words * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_patterns.ptr, pat.data(), pat.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
-  SWA_TRY(swa_hash_sequences(ctx));                        // also synchronises: pat is a host temporary
+  SWA_TRY(swa_hash_sequences(ctx));
   const int hgrid = grid_for(ctx, n, 256, 8);
   swa_t0(ctx, 1);
   SWA_TRY(swa_d1_rebuild_table(ctx, nullptr));

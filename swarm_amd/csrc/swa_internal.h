@@ -51,6 +51,8 @@ struct swa_ctx {
   uint64_t table_size = 0;       // slots, power of two
   uint64_t bloom_words = 0;      // u64 words in the amplicon Bloom
   uint32_t zobrist_len = 0;      // positions in the Zobrist table (longest + 2)
+  uint32_t zobrist_resident = 0; // length of the table currently in d_zobrist (0 = none)
+  bool patterns_resident = false;
   swa_dbuf d_zobrist, d_seqhash, d_table, d_bloom, d_patterns;
   swa_dbuf d_flags;              // u32[16]: [0] duplicate flag
   swa_dbuf d_stats;              // u64[8] probe statistics + [8] edge counter
