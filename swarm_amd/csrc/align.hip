@@ -28,6 +28,8 @@
 //     in LDS.
 #include "swa_internal.h"
 
+#include <type_traits>
+
 namespace {
 
 struct AlignArgs {
@@ -62,6 +64,11 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {   // lane i <-
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 }
 
+// Lane layout of one pair's group of G lanes: lane 0 and the lanes above 2W+1 are GUARD lanes,
+// lanes 1 .. 2W+1 carry the band offsets -W .. +W.  A guard lane never computes a cell, so what
+// its neighbours read from it is forever the "outside the band" value — no per-step select is
+// needed at the band edges, and the first / last lane of the wave (whose DPP shift has no
+// source) are guards as well.  Needs 2W + 3 <= G.
 template <int G, bool WANT_LEN>
 __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
   extern __shared__ uint64_t lds[];
@@ -73,10 +80,8 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
 
   const uint32_t SAT = a.sat;
   const int W = a.W;
-  const int o = t - W;                                        // band offset = column - row
-  const bool lane_in_band = t <= 2 * W;
-  const bool has_above = t + 1 <= 2 * W;                      // lane t+1 holds an in-band cell
-  const bool has_below = t >= 1;
+  const int o = t - 1 - W;                                    // band offset = column - row
+  const bool lane_in_band = t >= 1 && t <= 2 * W + 1;
   const uint32_t go = a.gapopen, ge = a.gapextend, mm = a.mismatch;
   constexpr uint32_t kBigCount = 0xFFFFu;
   const uint32_t kOutside = SAT | (kBigCount << 16);          // what an out-of-band neighbour provides
@@ -103,9 +108,8 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
     const bool feasible = (delta <= W) && (-delta <= W);      // the end cell lies inside the band
     // Per-lane state = the last cell this lane computed.  The values handed to the neighbour
     // lanes travel packed: low 16 bits the (saturated) score, high 16 bits the diff counter.
-    // The loop body is branch-free: boundary inputs (row 0 / column 0, nw.cc:66-79) are
-    // wave-uniform functions of the step, everything else is selects, and the nucleotide
-    // comparison of the NEXT step is fetched from LDS while the current step computes.
+    // The loop body is branch-free, and the nucleotide comparison of the NEXT step is fetched
+    // from LDS while the current step computes.
     uint32_t Hown = 0, AMown = 0, LMown = 0;                  // H, A_M, alignment length (diagonal input)
     uint32_t dn_pk = kOutside, dn_len = 0;                    // E | A_I  passed down  to (r+1, c)
     uint32_t rt_pk = kOutside, rt_len = 0;                    // F | A_D  passed right to (r, c+1)
@@ -123,7 +127,12 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
         return ((dnt ^ qnt) & 3u) != 0u ? 1u : 0u;
       };
       uint32_t mis_next = mismatch_at(0);
-      for (int s = 0; s <= last; ++s) {
+      // One anti-diagonal step.  EDGE = the step may touch row 0 / column 0 (nw.cc:66-79) or the
+      // last row / column; interior steps (the bulk) need neither the boundary inputs, which are
+      // wave-uniform functions of the step, nor the range tests: a lane is active iff it is in
+      // the band and (s - o) is even.
+      auto step = [&](int s, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const uint32_t mis = mis_next;
         mis_next = mismatch_at(s + 1);                        // LDS latency hides behind this step's math
         // neighbour values from the previous step (every lane of the group takes part)
@@ -132,19 +141,23 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
         uint32_t above_len = 0, below_len = 0;
         if (WANT_LEN) { above_len = from_lane_above(dn_len); below_len = from_lane_below(rt_len); }
         const int rs = s - o;
-        const int r = rs >> 1;
-        const int c = s - r;
-        const bool act = lane_in_band && ((rs & 1) == 0) && rs >= 0 && r <= rmax && c >= 0 && c <= cmax;
-        const bool row0 = rs == 0;                            // r == 0  (then c == s)
-        const bool col0 = s + o == 0;                         // c == 0  (then r == s)
-        // boundary inputs, uniform over the wave for a given step
-        const uint32_t su = (uint32_t)s;
-        const uint32_t edge_h = s == 0 ? 0u : sat_add(go, su * ge, SAT);
-        const uint32_t edge_pk = sat_add(2u * go, (su + 2u) * ge, SAT) | ((su + 1u) << 16);
-        const uint32_t hd = (row0 || col0) ? edge_h : Hown;
-        const uint32_t amd = (row0 || col0) ? su : AMown;
-        const uint32_t left_pk = row0 ? edge_pk : (has_above ? above_pk : kOutside);   // "left" in nw.cc
-        const uint32_t top_pk = col0 ? edge_pk : (has_below ? below_pk : kOutside);    // "top" in nw.cc
+        bool act = lane_in_band && ((rs & 1) == 0);
+        uint32_t hd = Hown, amd = AMown, left_pk = above_pk, top_pk = below_pk;   // "left" / "top" as in nw.cc
+        bool row0 = false, col0 = false;
+        uint32_t su = (uint32_t)s;
+        if (EDGE) {
+          const int r = rs >> 1;
+          const int c = s - r;
+          act = act && rs >= 0 && r <= rmax && c >= 0 && c <= cmax;
+          row0 = rs == 0;                                      // r == 0  (then c == s)
+          col0 = s + o == 0;                                   // c == 0  (then r == s)
+          const uint32_t edge_h = s == 0 ? 0u : sat_add(go, su * ge, SAT);
+          const uint32_t edge_pk = sat_add(2u * go, (su + 2u) * ge, SAT) | ((su + 1u) << 16);
+          hd = (row0 || col0) ? edge_h : Hown;
+          amd = (row0 || col0) ? su : AMown;
+          left_pk = row0 ? edge_pk : above_pk;
+          top_pk = col0 ? edge_pk : below_pk;
+        }
         const uint32_t left = left_pk & 0xFFFFu, aiv = left_pk >> 16;
         const uint32_t top = top_pk & 0xFFFFu, adh = top_pk >> 16;
 
@@ -178,7 +191,15 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
           dn_len = act ? (el ? liv + 1u : lm) : dn_len;
           rt_len = act ? (eu ? ldh + 1u : lm) : rt_len;
         }
-      }
+      };
+      // interior steps: W < s <= 2 * min(rmax, cmax) - W  (every in-band cell of the step is
+      // inside the matrix and off its first row / column)
+      const int in_lo = W + 1;
+      const int in_hi = 2 * (rmax < cmax ? rmax : cmax) - W;
+      int s = 0;
+      for (; s <= last && s < in_lo; ++s) { step(s, std::true_type{}); }
+      for (; s <= last && s <= in_hi; ++s) { step(s, std::false_type{}); }
+      for (; s <= last; ++s) { step(s, std::true_type{}); }
     }
     // the lane whose offset equals ql - dl holds the end cell
     if (!feasible) {
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
         if (a.scores != nullptr) { a.scores[pair] = SAT; }
         if (a.alnlens != nullptr) { a.alnlens[pair] = 0; }
       }
-    } else if (o == delta) {
+    } else if (lane_in_band && o == delta) {
       // like the reference: a saturated score means "no alignment", diff = SAT (search8.cc:776-810)
       const bool overflow = Hown >= SAT;
       a.diffs[pair] = overflow ? SAT : AMown;
@@ -332,7 +353,7 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, 
   const uint32_t sat = d > diff_saturation ? 65535u : 255u;
   const uint64_t T = d * std::max<uint64_t>(mm, go + ge);
   const uint64_t W64 = T / ge + 1;
-  const bool generic = 2 * W64 + 1 > 64;
+  const bool generic = 2 * W64 + 3 > 64;                     // band + the two guard lanes must fit a group
   AlignArgs a{};
   a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen;
   a.query = query;
@@ -345,7 +366,7 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, 
   a.sat = sat;
   a.W = (int)W64;
   a.maxwords = ((ctx->db.longest + 31u) >> 5) + 1u;
-  const bool wide = 2 * W64 + 1 > 32;
+  const bool wide = 2 * W64 + 3 > 32;
   const int groups = wide ? 4 : 8;
   uint64_t blocks = ((uint64_t)max_count + groups - 1) / groups;
   const uint64_t cap = uint64_t(ctx->num_cus) * 8;
