@@ -55,6 +55,12 @@ __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b, uint32_t sat
   return s < sat ? s : sat;
 }
 
+// c ? x : y as a bit-field insert on an all-ones / all-zeros mask: never turned into a branch
+__device__ __forceinline__ uint32_t select_u32(bool c, uint32_t x, uint32_t y) {
+  const uint32_t m = 0u - (uint32_t)c;
+  return (x & m) | (y & ~m);
+}
+
 // value of `v` in the neighbouring lane (full-wave DPP shifts, GFX9 family): a few cycles
 // instead of an LDS-crossbar ds_bpermute on the critical path of every anti-diagonal step
 __device__ __forceinline__ uint32_t from_lane_below(uint32_t v) {   // lane i <- lane i-1
@@ -126,6 +132,19 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
         const uint32_t qnt = (uint32_t)(qw[c >> 5] >> ((c & 31) << 1));
         return ((dnt ^ qnt) & 3u) != 0u ? 1u : 0u;
       };
+      // interior steps: no clamping needed — in-band lanes stay inside the matrix (one word of
+      // slack past the last row / column is staged for the prefetch of the first EDGE step after
+      // the interior), guard lanes borrow offset 0 so that they read something valid too
+      const int o_safe = lane_in_band ? o : 0;
+      auto mismatch_inner = [&](int s) -> uint32_t {
+        const int r = (s - o_safe) >> 1;
+        const int c = s - r;
+        const uint32_t dnt = (uint32_t)(dw[r >> 5] >> ((r & 31) << 1));
+        const uint32_t qnt = (uint32_t)(qw[c >> 5] >> ((c & 31) << 1));
+        return ((dnt ^ qnt) & 3u) != 0u ? 1u : 0u;
+      };
+      const bool act_even = lane_in_band && ((o & 1) == 0);  // active on even steps
+      const bool act_odd = lane_in_band && ((o & 1) != 0);
       uint32_t mis_next = mismatch_at(0);
       // One anti-diagonal step.  EDGE = the step may touch row 0 / column 0 (nw.cc:66-79) or the
       // last row / column; interior steps (the bulk) need neither the boundary inputs, which are
@@ -134,14 +153,14 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
       auto step = [&](int s, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         const uint32_t mis = mis_next;
-        mis_next = mismatch_at(s + 1);                        // LDS latency hides behind this step's math
+        mis_next = EDGE ? mismatch_at(s + 1) : mismatch_inner(s + 1);   // LDS latency hides behind this step's math
         // neighbour values from the previous step (every lane of the group takes part)
         const uint32_t above_pk = from_lane_above(dn_pk);     // cell (r-1, c) lives in lane t+1
         const uint32_t below_pk = from_lane_below(rt_pk);     // cell (r, c-1) lives in lane t-1
         uint32_t above_len = 0, below_len = 0;
         if (WANT_LEN) { above_len = from_lane_above(dn_len); below_len = from_lane_below(rt_len); }
         const int rs = s - o;
-        bool act = lane_in_band && ((rs & 1) == 0);
+        bool act = (s & 1) ? act_odd : act_even;              // in the band and (s - o) even
         uint32_t hd = Hown, amd = AMown, left_pk = above_pk, top_pk = below_pk;   // "left" / "top" as in nw.cc
         bool row0 = false, col0 = false;
         uint32_t su = (uint32_t)s;
@@ -172,10 +191,13 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
         const bool eu = t2 < d2;                               // nw.cc:102
         const bool el = l2 < d2;                               // nw.cc:103
         // what the backtrack would count from here (priority: nw.cc:139-172)
-        uint32_t am = lb ? aiv + 1u : (up ? adh + 1u : amd + mis);
+        // (all candidates are computed, then selected: no divergent control flow in the loop)
+        const uint32_t via_l = aiv + 1u, via_t = adh + 1u, via_d = amd + mis;
+        uint32_t am = select_u32(up, via_t, via_d);
+        am = select_u32(lb, via_l, am);
         am = am < kBigCount ? am : kBigCount;
-        uint32_t ai = el ? aiv + 1u : am;
-        uint32_t ad = eu ? adh + 1u : am;
+        uint32_t ai = select_u32(el, via_l, am);
+        uint32_t ad = select_u32(eu, via_t, am);
         ai = ai < kBigCount ? ai : kBigCount;
         ad = ad < kBigCount ? ad : kBigCount;
         Hown = act ? h : Hown;
