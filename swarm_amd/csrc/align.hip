@@ -136,9 +136,11 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
       // slack past the last row / column is staged for the prefetch of the first EDGE step after
       // the interior), guard lanes borrow offset 0 so that they read something valid too
       const int o_safe = lane_in_band ? o : 0;
-      auto mismatch_inner = [&](int s) -> uint32_t {
-        const int r = (s - o_safe) >> 1;
-        const int c = s - r;
+      // A lane computes a cell every OTHER step, so inside the interior one comparison serves a
+      // pair of steps (s even, s + 1): the lane's own active step of the pair is s + ((o ^ s) & 1).
+      auto mismatch_pair = [&](int s_even) -> uint32_t {
+        const int r = (s_even + (o_safe & 1) - o_safe) >> 1;
+        const int c = s_even + (o_safe & 1) - r;
         const uint32_t dnt = (uint32_t)(dw[r >> 5] >> ((r & 31) << 1));
         const uint32_t qnt = (uint32_t)(qw[c >> 5] >> ((c & 31) << 1));
         return ((dnt ^ qnt) & 3u) != 0u ? 1u : 0u;
@@ -150,17 +152,20 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
       // last row / column; interior steps (the bulk) need neither the boundary inputs, which are
       // wave-uniform functions of the step, nor the range tests: a lane is active iff it is in
       // the band and (s - o) is even.
-      auto step = [&](int s, auto edge_tag) {
+      auto step = [&](int s, auto edge_tag, uint32_t mis_pair, bool act_inner) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        const uint32_t mis = mis_next;
-        mis_next = EDGE ? mismatch_at(s + 1) : mismatch_inner(s + 1);   // LDS latency hides behind this step's math
+        uint32_t mis = mis_pair;
+        if (EDGE) {
+          mis = mis_next;
+          mis_next = mismatch_at(s + 1);                      // LDS latency hides behind this step's math
+        }
         // neighbour values from the previous step (every lane of the group takes part)
         const uint32_t above_pk = from_lane_above(dn_pk);     // cell (r-1, c) lives in lane t+1
         const uint32_t below_pk = from_lane_below(rt_pk);     // cell (r, c-1) lives in lane t-1
         uint32_t above_len = 0, below_len = 0;
         if (WANT_LEN) { above_len = from_lane_above(dn_len); below_len = from_lane_below(rt_len); }
         const int rs = s - o;
-        bool act = (s & 1) ? act_odd : act_even;              // in the band and (s - o) even
+        bool act = EDGE ? (lane_in_band && ((rs & 1) == 0)) : act_inner;   // in the band and (s - o) even
         uint32_t hd = Hown, amd = AMown, left_pk = above_pk, top_pk = below_pk;   // "left" / "top" as in nw.cc
         bool row0 = false, col0 = false;
         uint32_t su = (uint32_t)s;
@@ -219,9 +224,18 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
       const int in_lo = W + 1;
       const int in_hi = 2 * (rmax < cmax ? rmax : cmax) - W;
       int s = 0;
-      for (; s <= last && s < in_lo; ++s) { step(s, std::true_type{}); }
-      for (; s <= last && s <= in_hi; ++s) { step(s, std::false_type{}); }
-      for (; s <= last; ++s) { step(s, std::true_type{}); }
+      for (; s <= last && (s < in_lo || (s & 1) != 0); ++s) { step(s, std::true_type{}, 0u, false); }
+      if (s + 1 <= in_hi && s + 1 <= last) {                 // interior, two steps per turn, s even
+        uint32_t mis_pair = mismatch_pair(s);
+        for (; s + 1 <= in_hi && s + 1 <= last; s += 2) {
+          const uint32_t mis_now = mis_pair;
+          mis_pair = mismatch_pair(s + 2);                    // (reads at most one word past the sequences)
+          step(s, std::false_type{}, mis_now, act_even);
+          step(s + 1, std::false_type{}, mis_now, act_odd);
+        }
+        mis_next = mismatch_at(s);                            // hand over to the generic prefetch chain
+      }
+      for (; s <= last; ++s) { step(s, std::true_type{}, 0u, false); }
     }
     // the lane whose offset equals ql - dl holds the end cell
     if (!feasible) {
