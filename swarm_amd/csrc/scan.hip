@@ -37,7 +37,6 @@ extern "C" int swa_scan_fetch(swa_ctx * ctx, uint32_t * hit_seedidx, uint32_t * 
 
 namespace {
 
-constexpr uint32_t kInlineHits = 680;   // hit triples returned with the first read-back (8 KB)
 
 struct ScanArgs {
   const ulonglong2 * sigs;
@@ -88,23 +87,35 @@ __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
   if (compared != 0ull) { atomicAdd(&a.totals[0], compared); }
 }
 
-__global__ __launch_bounds__(256) void k_scan_collect(const uint32_t * __restrict__ t_target,
-                                                      const uint32_t * __restrict__ t_seedidx,
-                                                      const uint32_t * __restrict__ diffs, uint32_t * counters,
-                                                      uint32_t cap, uint32_t d, uint8_t * swarmed,
-                                                      uint32_t * __restrict__ hits, unsigned long long * totals) {
-  if (counters[2] != 0u) { return; }            // pair overflow: the host grows the buffers and redoes the batch
-  const uint32_t nt = counters[0] < cap ? counters[0] : cap;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
-    if (diffs[t] <= d) {
-      const uint32_t at = atomicAdd(&counters[1], 1u);
-      hits[3u * at] = t_seedidx[t];
-      hits[3u * at + 1u] = t_target[t];
-      hits[3u * at + 2u] = diffs[t];
-      swarmed[t_target[t]] = 1;
+// `mirror` is pinned host memory the GPU writes directly (zero copy): [0..3] = pairs, hits,
+// overflow flag, 0, then the first mirror_cap hit triples — what the host needs after every
+// batch without a single copy command.  The complete hit list stays in `hits` (device) for the
+// rare batch with more hits than the mirror holds.  One workgroup: the header is written after
+// the last hit.
+__global__ __launch_bounds__(1024) void k_scan_collect(const uint32_t * __restrict__ t_target,
+                                                       const uint32_t * __restrict__ t_seedidx,
+                                                       const uint32_t * __restrict__ diffs, uint32_t * counters,
+                                                       uint32_t cap, uint32_t d, uint8_t * swarmed,
+                                                       uint32_t * __restrict__ hits, unsigned long long * totals,
+                                                       uint32_t * mirror, uint32_t mirror_cap) {
+  if (counters[2] == 0u) {                      // (pair overflow: the host grows the buffers and redoes the batch)
+    const uint32_t nt = counters[0] < cap ? counters[0] : cap;
+    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) {
+      if (diffs[t] <= d) {
+        const uint32_t at = atomicAdd(&counters[1], 1u);
+        const uint32_t sidx = t_seedidx[t], id = t_target[t], df = diffs[t];
+        hits[3u * at] = sidx; hits[3u * at + 1u] = id; hits[3u * at + 2u] = df;
+        if (at < mirror_cap) { mirror[4u + 3u * at] = sidx; mirror[5u + 3u * at] = id; mirror[6u + 3u * at] = df; }
+        swarmed[id] = 1;
+      }
     }
+    if (threadIdx.x == 0) { atomicAdd(&totals[1], (unsigned long long)nt); }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&totals[1], (unsigned long long)nt); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mirror[0] = counters[0]; mirror[1] = counters[1]; mirror[2] = counters[2]; mirror[3] = 0u;
+    __threadfence_system();
+  }
 }
 
 __global__ void k_mark(uint8_t * swarmed, const uint32_t * ids, uint32_t count) {
@@ -153,12 +164,16 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
   auto * counters = static_cast<uint32_t *>(ctx->d_scan_counters.ptr);          // u32[4] then u64 totals[4]
   auto * totals = reinterpret_cast<unsigned long long *>(counters + 4);
 
-  // seeds + limits -> device (one small upload)
-  ctx->scan_host.resize(2 * (size_t)nseeds);
-  for (uint32_t k = 0; k < nseeds; ++k) { ctx->scan_host[k] = seeds[k]; ctx->scan_host[nseeds + k] = radii[k] + d; }
-  SWA_TRY(swa_reserve(ctx, ctx->d_scan_seeds, 2 * (size_t)nseeds * sizeof(uint32_t)));
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_scan_seeds.ptr, ctx->scan_host.data(), 2 * (size_t)nseeds * sizeof(uint32_t),
-                              hipMemcpyHostToDevice, ctx->stream));
+  // seeds + limits travel through pinned host memory the kernels read directly, the hits come
+  // back the same way (k_scan_collect): no copy command in the per-generation sequence
+  constexpr uint32_t kMirrorHits = 16384;
+  const size_t pinned_words = 2 * 65536 + 4 + 3 * (size_t)kMirrorHits;
+  if (ctx->h_scan_pinned == nullptr) {
+    SWA_HIP(ctx, hipHostMalloc(&ctx->h_scan_pinned, pinned_words * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  uint32_t * pin_seeds = static_cast<uint32_t *>(ctx->h_scan_pinned);
+  uint32_t * mirror = pin_seeds + 2 * 65536;
+  for (uint32_t k = 0; k < nseeds; ++k) { pin_seeds[k] = seeds[k]; pin_seeds[nseeds + k] = radii[k] + d; }
   const uint32_t lo = lowest_unswarmed < n ? lowest_unswarmed : n;
   const uint32_t span = n - lo;
   // pair capacity: a first guess that is grown (and the batch redone) if it ever overflows
@@ -177,7 +192,7 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     a.est = static_cast<uint32_t *>(ctx->d_scan_est.ptr);
     a.swarmed = static_cast<uint8_t *>(ctx->d_scan_swarmed.ptr);
     a.n = n; a.lo = lo; a.nseeds = nseeds;
-    a.seeds = static_cast<const uint32_t *>(ctx->d_scan_seeds.ptr);
+    a.seeds = pin_seeds;
     a.limits = a.seeds + nseeds;
     a.first_generation = first_generation != 0 ? 1u : 0u;
     a.d = d;
@@ -202,17 +217,15 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
       const uint64_t max_pairs = std::min<uint64_t>((uint64_t)span * nseeds, a.cap);
       SWA_TRY(swa_align_launch(ctx, 0, a.t_query, a.t_target, counters, (uint32_t)max_pairs,
                                static_cast<uint32_t *>(ctx->d_scan_diffs.ptr), nullptr, nullptr));
-      hipLaunchKernelGGL(k_scan_collect, dim3(64), dim3(256), 0, ctx->stream, a.t_target, a.t_seedidx,
+      hipLaunchKernelGGL(k_scan_collect, dim3(1), dim3(1024), 0, ctx->stream, a.t_target, a.t_seedidx,
                          static_cast<const uint32_t *>(ctx->d_scan_diffs.ptr), counters, a.cap, d, a.swarmed, hits + 4,
-                         totals);
+                         totals, mirror, kMirrorHits);
       SWA_HIP(ctx, hipGetLastError());
+    } else {
+      mirror[0] = mirror[1] = mirror[2] = mirror[3] = 0u;   // nothing launched: no pairs, no hits
     }
-    // one read-back: [pairs, hits, overflow, 0] + the first kInlineHits triples
-    SWA_HIP(ctx, hipMemcpyAsync(hits, counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    ctx->scan_host.resize(4 + 3 * (size_t)kInlineHits);
-    SWA_HIP(ctx, hipMemcpyAsync(ctx->scan_host.data(), hits, ctx->scan_host.size() * sizeof(uint32_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->scan_host.assign(mirror, mirror + 4);
     if (ctx->scan_host[2] != 0u) {
       // more (seed, target) pairs than the buffers hold.  Nothing irreversible happened (est
       // stores are idempotent, k_scan_collect marks nothing when the flag is set), so grow and
@@ -221,8 +234,10 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
       continue;
     }
     got = ctx->scan_host[1];
-    if (got > kInlineHits) {
-      ctx->scan_host.resize(4 + 3 * (size_t)got);
+    ctx->scan_host.resize(4 + 3 * (size_t)got);
+    if (got <= kMirrorHits) {
+      std::copy(mirror + 4, mirror + 4 + 3 * (size_t)got, ctx->scan_host.begin() + 4);
+    } else {                                                 // more hits than the mirror holds: fetch them all
       SWA_HIP(ctx, hipMemcpyAsync(ctx->scan_host.data() + 4, hits + 4, 3 * (size_t)got * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, ctx->stream));
       SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
