@@ -158,6 +158,10 @@ int swa_qgram_debug_read(swa_ctx * ctx, uint8_t * out, size_t out_bytes);
 /* penalties after the reference's gcd reduction (src/swarm.cc:466-483): defaults
    mismatch 18, gapopen 24, gapextend 13.  resolution d = -d value. */
 int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, uint64_t d);
+/* 1 when the penalties / d given to swa_search_begin admit the wavefront kernel (every cost <= T
+   decomposes uniquely, so the optimal cost alone fixes diff and alignment length), 0 when the
+   banded tie-tracking kernel is used.  Same results either way; informational. */
+int swa_search_uses_wavefront(const swa_ctx * ctx);
 /* diffs[i] == the reference's search8/search16 + backtrack value whenever that value
    is <= d; otherwise some value > d (the caller only tests diff <= d, src/algo.cc:460,
    554).  scores / alignlengths may be NULL (never read by the reference's caller). */

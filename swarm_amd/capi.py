@@ -38,7 +38,7 @@ class DbView(C.Structure):
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize",
     "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_network", "swa_d1_network_device",
-    "swa_d1_debug_read", "swa_d1_table_size", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
+    "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
     "swa_hostdb_header", "swa_d1_cluster", "swa_d1_result_free", "swa_d1_result_summary", "swa_d1_result_swarmid",
@@ -385,6 +385,10 @@ class Context:
     # ---- B4
     def search_begin(self, mismatch: int = 18, gapopen: int = 24, gapextend: int = 13, d: int = 3) -> None:
         self._check(self.lib.swa_search_begin(self.h, mismatch, gapopen, gapextend, d))
+
+    def search_uses_wavefront(self) -> bool:
+        self.lib.swa_search_uses_wavefront.argtypes = [C.c_void_p]
+        return bool(self.lib.swa_search_uses_wavefront(self.h))
 
     def search_do(self, query: int, targets: np.ndarray):
         targets = np.ascontiguousarray(targets, dtype=np.uint64)

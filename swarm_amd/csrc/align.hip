@@ -28,7 +28,10 @@
 //     in LDS.
 #include "swa_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -255,6 +258,151 @@ __global__ __launch_bounds__(256) void k_align(const AlignArgs a) {
   }
 }
 
+// ---- wavefront formulation (the fast path) -------------------------------------------------
+// For near-identical pairs — the only ones the caller keeps — filling even a banded matrix is
+// wasteful: ~(Lq + Lt) dependent anti-diagonal steps.  The wavefront recurrences of gap-affine
+// alignment (furthest-reaching point per diagonal and per score; Marco-Sola et al. 2021) reach
+// the optimal cost in one step per REACHABLE cost value <= T plus ~L/32 word comparisons.
+// They give the optimal cost, not the reference's tie-broken path.  That is enough whenever
+// every cost <= T can be written in exactly one way as a*mismatch + g*gapopen + e*gapextend
+// up to (a + e, e): then all optimal alignments of a pair have the same number of
+// non-identical columns (a + e = diff) and of columns ((Lq + Lt + e) / 2), whichever one the
+// reference's tie-breaking picks.  swa_search_begin checks this for the penalties and d in use
+// (true for the default 18/24/13 up to d = 5) and the banded kernel above remains the
+// general path.
+struct swa_wfa_step {
+  uint32_t score;           // a reachable cost value, ascending
+  int32_t from_x;           // index of score - mismatch in the list, or -1
+  int32_t from_oe;          //          score - gapopen - gapextend
+  int32_t from_e;           //          score - gapextend
+  uint32_t diff;            // a + e of the (unique) decomposition
+  uint32_t gapcols;         // e
+};
+
+constexpr int kWfaMaxSteps = 64;
+
+struct WfaArgs {
+  AlignArgs a;
+  const swa_wfa_step * steps;
+  uint32_t nsteps;
+};
+
+// 32 nucleotides of `seq` starting at position p (2 bits each, LSB first)
+__device__ __forceinline__ uint64_t window_at(const uint64_t * seq, uint32_t p) {
+  const uint32_t wi = p >> 5, sh = (p & 31u) << 1;
+  const uint64_t lo = seq[wi], hi = seq[wi + 1u];
+  return sh != 0u ? (lo >> sh) | (hi << (64u - sh)) : lo;
+}
+
+// Lanes: as in k_align, lane t of a 32-lane group owns diagonal k = t - 1 - W (column - row),
+// lanes 0 and > 2W+1 are guards that stay invalid.  Offsets are columns (query positions).
+__global__ __launch_bounds__(128) void k_align_wfa(const WfaArgs w) {
+  extern __shared__ uint64_t lds[];
+  constexpr int G = 32;
+  constexpr int kGroups = 128 / G;
+  const AlignArgs & a = w.a;
+  const int group = threadIdx.x / G;
+  const int t = threadIdx.x % G;
+  uint64_t * qw = lds + (size_t)(2 * group) * a.maxwords;
+  uint64_t * dw = qw + a.maxwords;
+  // wavefront history: [step][M | I | D][lane], offset + 1 as u16 (0 = invalid)
+  uint16_t * hist = reinterpret_cast<uint16_t *>(lds + (size_t)(2 * kGroups) * a.maxwords) +
+                    (size_t)group * (kWfaMaxSteps * 3 * G);
+  const int W = a.W;
+  const int k = t - 1 - W;
+  const bool lane_in_band = t >= 1 && t <= 2 * W + 1;
+  const uint32_t ntargets = a.ntargets_dev != nullptr ? min(*a.ntargets_dev, a.ntargets) : a.ntargets;
+  for (uint32_t base = blockIdx.x * kGroups; base < ntargets; base += gridDim.x * kGroups) {
+    const uint32_t pair = base + group;
+    const bool have = pair < ntargets;
+    const uint32_t target = have ? a.targets[pair] : 0u;
+    const uint32_t query = have ? (a.queries != nullptr ? a.queries[pair] : a.query) : 0u;
+    const int dl = have ? (int)a.seqlen[target] : 0;         // rows (pattern)
+    const int ql = have ? (int)a.seqlen[query] : 0;          // columns (text)
+    if (have) {
+      const uint64_t * gd = a.seqs + a.seq_off[target];
+      const uint64_t * gq = a.seqs + a.seq_off[query];
+      const uint32_t dn = ((uint32_t)dl + 31u) >> 5;
+      const uint32_t qn = ((uint32_t)ql + 31u) >> 5;
+      for (uint32_t x = t; x < dn + 1u; x += G) { dw[x] = x < dn ? gd[x] : 0ull; }
+      for (uint32_t x = t; x < qn + 1u; x += G) { qw[x] = x < qn ? gq[x] : 0ull; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    const int kend = ql - dl;
+    const bool feasible = have && kend <= W && -kend <= W;
+    int found = -1;                                          // step index at which the end was reached
+    bool running = feasible;
+    for (uint32_t i = 0; i < w.nsteps; ++i) {
+      if (__ballot(running) == 0ull) { break; }
+      const swa_wfa_step st = w.steps[i];
+      auto load = [&](int from, int which) -> int {
+        return from >= 0 ? (int)hist[((size_t)from * 3 + which) * G + t] - 1 : -1;
+      };
+      const int m_x = load(st.from_x, 0);                     // own diagonal
+      const int m_oe = load(st.from_oe, 0);
+      const int i_e = load(st.from_e, 1);
+      const int d_e = load(st.from_e, 2);
+      // insertion: from diagonal k-1 (lane t-1), consumes one query column
+      const int m_oe_below = (int)from_lane_below((uint32_t)m_oe), i_e_below = (int)from_lane_below((uint32_t)i_e);
+      // deletion: from diagonal k+1 (lane t+1), consumes one target row
+      const int m_oe_above = (int)from_lane_above((uint32_t)m_oe), d_e_above = (int)from_lane_above((uint32_t)d_e);
+      int I = (m_oe_below > i_e_below ? m_oe_below : i_e_below);
+      I = (I >= 0 && I + 1 <= ql) ? I + 1 : -1;               // row = I - k stays what it was: valid
+      int D = (m_oe_above > d_e_above ? m_oe_above : d_e_above);
+      D = (D >= 0 && D - k <= dl) ? D : -1;                   // same column, one more row
+      int M = (m_x >= 0 && m_x + 1 <= ql && m_x + 1 - k <= dl) ? m_x + 1 : -1;
+      M = M > I ? M : I;
+      M = M > D ? M : D;
+      if (i == 0u) { M = (k == 0) ? 0 : -1; }                // score 0 starts at the origin
+      if (!lane_in_band || !running) { M = -1; I = -1; D = -1; }
+      // extend M along the diagonal while the sequences agree, 32 nucleotides per turn
+      bool ext = M >= 0;
+      while (__ballot(ext) != 0ull) {
+        if (ext) {
+          const int r = M - k;
+          const int rem = min(ql - M, dl - r);
+          if (rem <= 0) { ext = false; }
+          else {
+            const uint64_t x = window_at(qw, (uint32_t)M) ^ window_at(dw, (uint32_t)r);
+            int n = x != 0ull ? (__ffsll((unsigned long long)x) - 1) >> 1 : 32;
+            n = n < rem ? n : rem;
+            M += n;
+            ext = n == 32;
+          }
+        }
+      }
+      hist[((size_t)i * 3 + 0) * G + t] = (uint16_t)(M + 1);
+      hist[((size_t)i * 3 + 1) * G + t] = (uint16_t)(I + 1);
+      hist[((size_t)i * 3 + 2) * G + t] = (uint16_t)(D + 1);
+      // finished when the end diagonal's furthest point is the last column (then row = dl too)
+      const bool at_end = running && lane_in_band && k == kend && M == ql;
+      const uint64_t endmask = __ballot(at_end);
+      // (a 64-lane wave holds two groups: look at this group's half only)
+      const uint64_t mine = (endmask >> ((threadIdx.x & 32u))) & 0xFFFFFFFFull;
+      if (running && mine != 0ull) { found = (int)i; running = false; }
+      // (a lane only ever reads back the history it wrote itself: no synchronisation needed)
+    }
+    if (have && t == 0) {
+      uint32_t diff = a.sat, score = a.sat, alen = 0;
+      if (found >= 0) {
+        const swa_wfa_step st = w.steps[found];
+        if (st.score < a.sat) {                               // a saturated score means "no alignment" (search8.cc:776-810)
+          diff = st.diff;
+          score = st.score;
+          alen = ((uint32_t)(ql + dl) + st.gapcols) >> 1;
+        }
+      }
+      a.diffs[pair] = diff;
+      if (a.scores != nullptr) { a.scores[pair] = score; }
+      if (a.alnlens != nullptr) { a.alnlens[pair] = alen; }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Generic fallback for bands wider than 64 lanes (large d or unusual penalties): one thread
 // per pair walks the band row by row with the previous row kept in an interleaved global
 // scratch (column-major across threads, so a wave's accesses coalesce).  Same recurrences,
@@ -358,7 +506,59 @@ extern "C" int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapop
   ctx->pen_gapextend = gapextend;
   ctx->resolution = d;
   ctx->search_ready = true;
+  // Wavefront fast path (k_align_wfa): usable when every cost <= T has one decomposition only
+  // into (non-identical columns, gap columns) — see the comment above the kernel.
+  ctx->wfa_steps = 0;
+  {
+    const uint64_t T = d * std::max<uint64_t>(mismatch, gapopen + gapextend);
+    struct Way { uint64_t cost; uint32_t diff, gapcols; };
+    std::vector<Way> ways;
+    bool unique = T < (1u << 20);
+    for (uint64_t a = 0; unique && a * mismatch <= T; ++a) {
+      for (uint64_t g = 0; a * mismatch + g * (gapopen + gapextend) <= T; ++g) {
+        for (uint64_t e = g; a * mismatch + g * gapopen + e * gapextend <= T; ++e) {
+          ways.push_back({a * mismatch + g * gapopen + e * gapextend, (uint32_t)(a + e), (uint32_t)e});
+          if (g == 0) { break; }                          // no gap: no gap columns
+        }
+        if (ways.size() > 100000) { unique = false; break; }
+      }
+    }
+    std::sort(ways.begin(), ways.end(), [](const Way & x, const Way & y) {
+      return x.cost != y.cost ? x.cost < y.cost : (x.diff != y.diff ? x.diff < y.diff : x.gapcols < y.gapcols);
+    });
+    std::vector<swa_wfa_step> steps;
+    for (size_t i = 0; unique && i < ways.size(); ++i) {
+      if (i > 0 && ways[i].cost == ways[i - 1].cost) {
+        if (ways[i].diff != ways[i - 1].diff || ways[i].gapcols != ways[i - 1].gapcols) { unique = false; }
+        continue;
+      }
+      swa_wfa_step st{};
+      st.score = (uint32_t)ways[i].cost; st.diff = ways[i].diff; st.gapcols = ways[i].gapcols;
+      steps.push_back(st);
+    }
+    if (unique && !steps.empty() && steps.size() <= (size_t)kWfaMaxSteps) {
+      auto index_of = [&](int64_t cost) -> int32_t {
+        if (cost < 0) { return -1; }
+        for (size_t j = 0; j < steps.size(); ++j) { if (steps[j].score == (uint64_t)cost) { return (int32_t)j; } }
+        return -1;
+      };
+      for (auto & st : steps) {
+        st.from_x = index_of((int64_t)st.score - (int64_t)mismatch);
+        st.from_oe = index_of((int64_t)st.score - (int64_t)(gapopen + gapextend));
+        st.from_e = index_of((int64_t)st.score - (int64_t)gapextend);
+      }
+      SWA_HIP(ctx, hipSetDevice(ctx->device));
+      SWA_TRY(swa_reserve(ctx, ctx->d_wfa, steps.size() * sizeof(swa_wfa_step)));
+      SWA_HIP(ctx, hipMemcpyAsync(ctx->d_wfa.ptr, steps.data(), steps.size() * sizeof(swa_wfa_step), hipMemcpyHostToDevice, ctx->stream));
+      SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->wfa_steps = (uint32_t)steps.size();
+    }
+  }
   return SWA_OK;
+}
+
+extern "C" int swa_search_uses_wavefront(const swa_ctx * ctx) {
+  return ctx != nullptr && ctx->search_ready && ctx->wfa_steps != 0 ? 1 : 0;
 }
 
 namespace {
@@ -409,7 +609,18 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, 
   if (blocks > cap) { blocks = cap; }
   if (blocks < 1) { blocks = 1; }
   const size_t lds = sizeof(uint64_t) * (size_t)a.maxwords * (2 * groups);
-  if (generic) {
+  const char * no_wfa = std::getenv("SWA_ALIGN_BANDED");         // test / comparison switch: force the banded kernel
+  if (ctx->wfa_steps != 0 && !wide && ctx->db.longest < 65000u && (no_wfa == nullptr || no_wfa[0] == '0')) {
+    WfaArgs w{};
+    w.a = a;
+    w.steps = static_cast<const swa_wfa_step *>(ctx->d_wfa.ptr);
+    w.nsteps = ctx->wfa_steps;
+    uint64_t wblocks = ((uint64_t)max_count + 3) / 4;
+    if (wblocks > cap) { wblocks = cap; }
+    if (wblocks < 1) { wblocks = 1; }
+    const size_t wlds = sizeof(uint64_t) * (size_t)a.maxwords * 8 + sizeof(uint16_t) * 4 * (size_t)kWfaMaxSteps * 3 * 32;
+    hipLaunchKernelGGL(k_align_wfa, dim3((unsigned)wblocks), dim3(128), wlds, ctx->stream, w);
+  } else if (generic) {
     a.W = W64 > 0x3FFFFFFF ? 0x3FFFFFFF : (int)W64;
     const uint32_t qcap = ctx->db.longest + 1u;
     uint64_t nthreads = max_count < 65536 ? (((uint64_t)max_count + 63) / 64) * 64 : 65536;

@@ -71,6 +71,8 @@ struct swa_ctx {
   swa_dbuf d_qgrams, d_list_a, d_list_b, d_list_c, d_list_d;
   uint64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13, resolution = 1;
   bool search_ready = false;
+  uint32_t wfa_steps = 0;        // > 0: the wavefront alignment kernel is exact for the penalties / d in use
+  swa_dbuf d_wfa;
 
   // fused d >= 2 scan state (scan.hip)
   bool scan_ready = false;

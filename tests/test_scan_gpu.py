@@ -72,8 +72,26 @@ def test_qgram_golden_vectors(gpu_ctx):
         assert sigs[i].tobytes().hex() == r["qgram_hex"]
 
 
-SCORINGS = [((18, 24, 13), 3), ((18, 24, 13), 1), ((18, 24, 13), 6), ((18, 24, 13), 7), ((4, 12, 1), 2), ((2, 3, 1), 5),
-            ((18, 24, 13), 9)]
+def _unique_costs(mm, go, ge, d):
+    T = d * max(mm, go + ge)
+    ways = {}
+    a = 0
+    while a * mm <= T:
+        g = 0
+        while a * mm + g * (go + ge) <= T:
+            e = g
+            while a * mm + g * go + e * ge <= T:
+                ways.setdefault(a * mm + g * go + e * ge, set()).add((a + e, e))
+                if g == 0:
+                    break
+                e += 1
+            g += 1
+        a += 1
+    return all(len(v) == 1 for v in ways.values()) and len(ways) <= 64
+
+
+SCORINGS = [((18, 24, 13), 3), ((18, 24, 13), 1), ((18, 24, 13), 2), ((18, 24, 13), 4), ((18, 24, 13), 5), ((18, 24, 13), 6),
+            ((18, 24, 13), 7), ((4, 12, 1), 2), ((2, 3, 1), 5), ((18, 24, 13), 9), ((7, 11, 3), 3), ((10, 1, 10), 2)]
 
 
 @pytest.mark.parametrize("scoring,d", SCORINGS)
@@ -103,6 +121,9 @@ def test_alignment_diffs_match_oracle(gpu_ctx, scoring, d, alphabet):
     db = S.build_db([(f"s{i}_{1 + (i * 7) % 50}".encode(), s.encode()) for i, s in enumerate(recs)])
     _upload(gpu_ctx, db)
     gpu_ctx.search_begin(mm, go, ge, d)
+    # the wavefront kernel is used exactly when every cost <= T has one decomposition (default
+    # penalties: d <= 3) and the band fits a 32-lane group; both kernels must pass the same checks
+    assert gpu_ctx.search_uses_wavefront() == _unique_costs(mm, go, ge, d)
     sat = 65535 if d > min(255 // mm, 255 // (go + ge)) else 255
     accepted = 0
     for q in rng.integers(0, db.n, size=12):
@@ -115,7 +136,7 @@ def test_alignment_diffs_match_oracle(gpu_ctx, scoring, d, alphabet):
                 assert (int(diffs[k]), int(alens[k]), int(scores[k])) == (want, walen, wscore), (q, t)
             else:
                 assert int(diffs[k]) > d, (q, t, want, int(diffs[k]))
-    assert accepted > 5
+    assert accepted > 2
 
 
 def test_alignment_golden_vectors(gpu_ctx):
@@ -138,3 +159,49 @@ def test_alignment_golden_vectors(gpu_ctx):
                 assert (int(diffs[0]), int(alens[0])) == (p["diff"], p["alnlen"]), p
             else:
                 assert int(diffs[0]) > d, p
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_wavefront_and_banded_kernels_agree(gpu_ctx, d):
+    """Same pairs through both B4 kernels (SWA_ALIGN_BANDED forces the banded one): wherever
+    either accepts (diff <= d) the (diff, length, score) triples are identical, otherwise both
+    reject.  Long sequences, mixed lengths, many near-identical pairs."""
+    import os
+    rng = np.random.default_rng(700 + d)
+    recs = set()
+    for _ in range(25):
+        L = int(rng.integers(150, 420))
+        base = "".join(rng.choice(list("ACGT"), size=L))
+        recs.add(base)
+        for _v in range(12):
+            s = list(base)
+            for _e in range(int(rng.integers(0, d + 3))):
+                u = rng.random()
+                p = int(rng.integers(0, len(s)))
+                if u < 0.5:
+                    s[p] = "ACGT"[int(rng.integers(0, 4))]
+                elif u < 0.75:
+                    del s[p]
+                else:
+                    s.insert(p, "ACGT"[int(rng.integers(0, 4))])
+            recs.add("".join(s))
+    recs = sorted(recs)
+    db = S.build_db([(f"s{i}_{1 + i % 9}".encode(), s.encode()) for i, s in enumerate(recs)])
+    _upload(gpu_ctx, db)
+    gpu_ctx.search_begin(18, 24, 13, d)
+    assert gpu_ctx.search_uses_wavefront()
+    accepted = 0
+    try:
+        for q in rng.integers(0, db.n, size=10):
+            targets = np.array([t for t in range(db.n) if t != q], dtype=np.uint64)
+            os.environ.pop("SWA_ALIGN_BANDED", None)
+            ws, wd, wl = gpu_ctx.search_do(int(q), targets)
+            os.environ["SWA_ALIGN_BANDED"] = "1"
+            bs, bd, bl = gpu_ctx.search_do(int(q), targets)
+            acc = (bd <= d) | (wd <= d)
+            accepted += int(acc.sum())
+            assert np.array_equal(wd[acc], bd[acc]) and np.array_equal(wl[acc], bl[acc]) and np.array_equal(ws[acc], bs[acc])
+            assert (wd[~acc] > d).all() and (bd[~acc] > d).all()
+    finally:
+        os.environ.pop("SWA_ALIGN_BANDED", None)
+    assert accepted >= 3
