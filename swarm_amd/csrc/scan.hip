@@ -53,6 +53,12 @@ struct ScanArgs {
   uint32_t cap;                 // capacity of the pair arrays
   uint32_t * counters;          // [0] pairs [1] hits [2] pair overflow flag
   unsigned long long * totals;  // [0] q-gram comparisons [1] aligned pairs
+  // candidate list of the current swarm: the pool amplicons whose estimate against the initial
+  // seed is <= cand_bound.  Later generations can only ever look at those (algo.cc:521-522 prunes
+  // on that same estimate), so they scan the list instead of the whole pool.
+  uint32_t * cand;              // amplicon ids, unordered
+  uint32_t * cand_count;
+  uint32_t cand_bound;
 };
 
 __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
@@ -76,7 +82,10 @@ __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
     if (sub == 0u) {
       const uint32_t qd = (pop + 9u) / 10u;
       ++compared;
-      if (a.first_generation != 0u) { a.est[i] = qd; }                          // algo.cc:442
+      if (a.first_generation != 0u) {
+        a.est[i] = qd;                                                           // algo.cc:442
+        if (qd <= a.cand_bound) { a.cand[atomicAdd(a.cand_count, 1u)] = i; }
+      }
       if (qd <= a.d) {
         const uint32_t at = atomicAdd(&a.counters[0], 1u);
         if (at < a.cap) { a.t_query[at] = seed; a.t_target[at] = i; a.t_seedidx[at] = sidx; }
@@ -115,6 +124,49 @@ __global__ __launch_bounds__(1024) void k_scan_collect(const uint32_t * __restri
   if (threadIdx.x == 0) {
     mirror[0] = counters[0]; mirror[1] = counters[1]; mirror[2] = counters[2]; mirror[3] = 0u;
     __threadfence_system();
+  }
+}
+
+// later generations: the same tests as k_scan_filter over the swarm's candidate list
+__global__ __launch_bounds__(256) void k_scan_filter_list(const ScanArgs a) {
+  const uint32_t sidx = blockIdx.y;
+  const uint32_t seed = a.seeds[sidx];
+  const uint32_t limit = a.limits[sidx];
+  const uint32_t sub = threadIdx.x & 7u;
+  const ulonglong2 mine = a.sigs[(uint64_t)seed * 8u + sub];
+  const uint64_t seed_ab = a.abundance[seed];
+  const uint32_t groups = gridDim.x * (blockDim.x >> 3);
+  const uint32_t ncand = *a.cand_count;
+  unsigned long long compared = 0;
+  for (uint32_t c = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); c < ncand; c += groups) {
+    const uint32_t i = a.cand[c];
+    if (i < a.lo || i == seed || a.swarmed[i] != 0) { continue; }
+    if (a.est[i] > limit) { continue; }                                          // algo.cc:521-522
+    if (a.ncb == 0u && a.abundance[i] > seed_ab) { continue; }                  // algo.cc:523-525
+    const ulonglong2 other = a.sigs[(uint64_t)i * 8u + sub];
+    uint32_t pop = (uint32_t)__popcll(mine.x ^ other.x) + (uint32_t)__popcll(mine.y ^ other.y);
+    pop += __shfl_xor(pop, 1, 8);
+    pop += __shfl_xor(pop, 2, 8);
+    pop += __shfl_xor(pop, 4, 8);
+    if (sub == 0u) {
+      const uint32_t qd = (pop + 9u) / 10u;
+      ++compared;
+      if (qd <= a.d) {
+        const uint32_t at = atomicAdd(&a.counters[0], 1u);
+        if (at < a.cap) { a.t_query[at] = seed; a.t_target[at] = i; a.t_seedidx[at] = sidx; }
+        else { a.counters[2] = 1u; }
+      }
+    }
+  }
+  if (compared != 0ull) { atomicAdd(&a.totals[0], compared); }
+}
+
+// a sub-seed's limit outgrew the list's bound: collect the list again from the stored estimates
+__global__ __launch_bounds__(256) void k_scan_relist(const uint32_t * __restrict__ est, const uint8_t * __restrict__ swarmed,
+                                                     uint32_t lo, uint32_t n, uint32_t bound, uint32_t * cand,
+                                                     uint32_t * cand_count) {
+  for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (swarmed[i] == 0 && est[i] <= bound) { cand[atomicAdd(cand_count, 1u)] = i; }
   }
 }
 
@@ -185,6 +237,7 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     SWA_TRY(swa_reserve(ctx, ctx->d_scan_targets, 3 * pair_cap * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_scan_diffs, pair_cap * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_scan_hits, (3 * pair_cap + 8) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_scan_cand, (uint64_t)n * sizeof(uint32_t)));
     ctx->scan_pair_cap = pair_cap;
     ScanArgs a{};
     a.sigs = static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr);
@@ -203,6 +256,8 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     a.cap = (uint32_t)std::min<uint64_t>(pair_cap, 0xFFFFFFFFull);
     a.counters = counters;
     a.totals = totals;
+    a.cand = static_cast<uint32_t *>(ctx->d_scan_cand.ptr);
+    a.cand_count = counters + 12;                      // (u32[4] counters, u64[4] totals, then the list length)
     auto * hits = static_cast<uint32_t *>(ctx->d_scan_hits.ptr);
     SWA_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), ctx->stream));
     if (a.first_generation != 0u) {                    // the initial seed joins its own swarm
@@ -212,7 +267,25 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
       uint64_t blocks = ((uint64_t)span + 31) / 32;
       const uint64_t gcap = std::max<uint64_t>(1, uint64_t(ctx->num_cus) * 8 / nseeds);
       if (blocks > gcap) { blocks = gcap; }
-      hipLaunchKernelGGL(k_scan_filter, dim3((unsigned)blocks, nseeds), dim3(256), 0, ctx->stream, a);
+      if (a.first_generation != 0u) {
+        // whole pool: estimates for everybody, and the candidate list of this swarm
+        ctx->scan_cand_bound = 4u * d;
+        a.cand_bound = ctx->scan_cand_bound;
+        SWA_HIP(ctx, hipMemsetAsync(a.cand_count, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_scan_filter, dim3((unsigned)blocks, nseeds), dim3(256), 0, ctx->stream, a);
+      } else {
+        uint32_t max_limit = 0;
+        for (uint32_t k = 0; k < nseeds; ++k) { max_limit = std::max(max_limit, radii[k] + d); }
+        if (max_limit > ctx->scan_cand_bound) {          // (rare) the radius outgrew the list: collect it again, wider
+          ctx->scan_cand_bound = std::max(2u * ctx->scan_cand_bound, max_limit);
+          SWA_HIP(ctx, hipMemsetAsync(a.cand_count, 0, sizeof(uint32_t), ctx->stream));
+          hipLaunchKernelGGL(k_scan_relist, dim3((unsigned)std::min<uint64_t>(((uint64_t)span + 255) / 256, uint64_t(ctx->num_cus) * 8)),
+                             dim3(256), 0, ctx->stream, a.est, a.swarmed, lo, n, ctx->scan_cand_bound, a.cand, a.cand_count);
+        }
+        a.cand_bound = ctx->scan_cand_bound;
+        const uint64_t lblocks = std::max<uint64_t>(1, std::min<uint64_t>(gcap, 64));
+        hipLaunchKernelGGL(k_scan_filter_list, dim3((unsigned)lblocks, nseeds), dim3(256), 0, ctx->stream, a);
+      }
       SWA_HIP(ctx, hipGetLastError());
       const uint64_t max_pairs = std::min<uint64_t>((uint64_t)span * nseeds, a.cap);
       SWA_TRY(swa_align_launch(ctx, 0, a.t_query, a.t_target, counters, (uint32_t)max_pairs,
