@@ -70,30 +70,54 @@ __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
   const uint64_t seed_ab = a.abundance[seed];
   const uint32_t groups = gridDim.x * (blockDim.x >> 3);
   unsigned long long compared = 0;
-  for (uint32_t i = a.lo + blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); i < a.n; i += groups) {
-    if (i == seed || a.swarmed[i] != 0) { continue; }
-    if (a.first_generation == 0u && a.est[i] > limit) { continue; }             // algo.cc:521-522
-    if (a.ncb == 0u && a.abundance[i] > seed_ab) { continue; }                  // algo.cc:427-428, 523-525
-    const ulonglong2 other = a.sigs[(uint64_t)i * 8u + sub];
-    uint32_t pop = (uint32_t)__popcll(mine.x ^ other.x) + (uint32_t)__popcll(mine.y ^ other.y);
-    pop += __shfl_xor(pop, 1, 8);
-    pop += __shfl_xor(pop, 2, 8);
-    pop += __shfl_xor(pop, 4, 8);
-    if (sub == 0u) {
-      const uint32_t qd = (pop + 9u) / 10u;
-      ++compared;
-      if (a.first_generation != 0u) {
-        a.est[i] = qd;                                                           // algo.cc:442
-        if (qd <= a.cand_bound) { a.cand[atomicAdd(a.cand_count, 1u)] = i; }
-      }
-      if (qd <= a.d) {
-        const uint32_t at = atomicAdd(&a.counters[0], 1u);
-        if (at < a.cap) { a.t_query[at] = seed; a.t_target[at] = i; a.t_seedidx[at] = sidx; }
-        else { a.counters[2] = 1u; }
+  // kUnroll amplicons per turn with every load issued before the first test: the pool scan is a
+  // stream of 128-byte signatures and must not serialise on "swarmed? -> abundance? -> signature"
+  constexpr uint32_t kUnroll = 4;
+  for (uint32_t i0 = a.lo + blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); i0 < a.n; i0 += kUnroll * groups) {
+    uint32_t idx[kUnroll];
+    bool in[kUnroll];
+    uint8_t sw[kUnroll];
+    uint32_t es[kUnroll];
+    uint64_t ab[kUnroll];
+    ulonglong2 other[kUnroll];
+#pragma unroll
+    for (uint32_t u = 0; u < kUnroll; ++u) {
+      idx[u] = i0 + u * groups;
+      in[u] = idx[u] < a.n;
+      const uint32_t j = in[u] ? idx[u] : seed;              // (an index that is always valid)
+      sw[u] = a.swarmed[j];
+      es[u] = a.first_generation == 0u ? a.est[j] : 0u;
+      ab[u] = a.abundance[j];
+      other[u] = a.sigs[(uint64_t)j * 8u + sub];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kUnroll; ++u) {
+      const uint32_t i = idx[u];
+      bool go = in[u] && i != seed && sw[u] == 0;
+      go = go && !(a.first_generation == 0u && es[u] > limit);                  // algo.cc:521-522
+      go = go && !(a.ncb == 0u && ab[u] > seed_ab);                             // algo.cc:427-428, 523-525
+      uint32_t pop = (uint32_t)__popcll(mine.x ^ other[u].x) + (uint32_t)__popcll(mine.y ^ other[u].y);
+      pop += __shfl_xor(pop, 1, 8);
+      pop += __shfl_xor(pop, 2, 8);
+      pop += __shfl_xor(pop, 4, 8);
+      if (go && sub == 0u) {
+        const uint32_t qd = (pop + 9u) / 10u;
+        ++compared;
+        if (a.first_generation != 0u) {
+          a.est[i] = qd;                                                         // algo.cc:442
+          if (qd <= a.cand_bound) { a.cand[atomicAdd(a.cand_count, 1u)] = i; }
+        }
+        if (qd <= a.d) {
+          const uint32_t at = atomicAdd(&a.counters[0], 1u);
+          if (at < a.cap) { a.t_query[at] = seed; a.t_target[at] = i; a.t_seedidx[at] = sidx; }
+          else { a.counters[2] = 1u; }
+        }
       }
     }
   }
-  if (compared != 0ull) { atomicAdd(&a.totals[0], compared); }
+  // one atomic per wave, not per group of 8 lanes (65 k atomics on one address cost tens of us)
+  for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, 64); }
+  if ((threadIdx.x & 63u) == 0u && compared != 0ull) { atomicAdd(&a.totals[0], compared); }
 }
 
 // `mirror` is pinned host memory the GPU writes directly (zero copy): [0..3] = pairs, hits,
@@ -158,7 +182,9 @@ __global__ __launch_bounds__(256) void k_scan_filter_list(const ScanArgs a) {
       }
     }
   }
-  if (compared != 0ull) { atomicAdd(&a.totals[0], compared); }
+  // one atomic per wave, not per group of 8 lanes (65 k atomics on one address cost tens of us)
+  for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, 64); }
+  if ((threadIdx.x & 63u) == 0u && compared != 0ull) { atomicAdd(&a.totals[0], compared); }
 }
 
 // a sub-seed's limit outgrew the list's bound: collect the list again from the stored estimates
@@ -170,8 +196,13 @@ __global__ __launch_bounds__(256) void k_scan_relist(const uint32_t * __restrict
   }
 }
 
-__global__ void k_mark(uint8_t * swarmed, const uint32_t * ids, uint32_t count) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) { swarmed[ids[i]] = 1; }
+// seeds + limits: pinned host memory -> HBM, by one workgroup.  (Letting every wave of the pool
+// scan read them across PCIe cost ~80 us per launch.)  In a first generation the initial seed
+// joins its own swarm here.
+__global__ void k_scan_stage(const uint32_t * __restrict__ pinned, uint32_t * __restrict__ staged, uint32_t words,
+                             uint8_t * swarmed, uint32_t mark_first) {
+  for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) { staged[i] = pinned[i]; }
+  if (mark_first != 0u && threadIdx.x == 0) { swarmed[pinned[0]] = 1; }
 }
 
 }  // namespace
@@ -238,6 +269,7 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     SWA_TRY(swa_reserve(ctx, ctx->d_scan_diffs, pair_cap * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_scan_hits, (3 * pair_cap + 8) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_scan_cand, (uint64_t)n * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_scan_seeds, 2 * (size_t)nseeds * sizeof(uint32_t)));
     ctx->scan_pair_cap = pair_cap;
     ScanArgs a{};
     a.sigs = static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr);
@@ -245,7 +277,7 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     a.est = static_cast<uint32_t *>(ctx->d_scan_est.ptr);
     a.swarmed = static_cast<uint8_t *>(ctx->d_scan_swarmed.ptr);
     a.n = n; a.lo = lo; a.nseeds = nseeds;
-    a.seeds = pin_seeds;
+    a.seeds = static_cast<const uint32_t *>(ctx->d_scan_seeds.ptr);
     a.limits = a.seeds + nseeds;
     a.first_generation = first_generation != 0 ? 1u : 0u;
     a.d = d;
@@ -260,16 +292,15 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     a.cand_count = counters + 12;                      // (u32[4] counters, u64[4] totals, then the list length)
     auto * hits = static_cast<uint32_t *>(ctx->d_scan_hits.ptr);
     SWA_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), ctx->stream));
-    if (a.first_generation != 0u) {                    // the initial seed joins its own swarm
-      hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, ctx->stream, a.swarmed, a.seeds, 1u);
-    }
+    hipLaunchKernelGGL(k_scan_stage, dim3(1), dim3(256), 0, ctx->stream, pin_seeds,
+                       static_cast<uint32_t *>(ctx->d_scan_seeds.ptr), 2u * nseeds, a.swarmed, a.first_generation);
     if (span > 0) {
       uint64_t blocks = ((uint64_t)span + 31) / 32;
       const uint64_t gcap = std::max<uint64_t>(1, uint64_t(ctx->num_cus) * 8 / nseeds);
       if (blocks > gcap) { blocks = gcap; }
       if (a.first_generation != 0u) {
         // whole pool: estimates for everybody, and the candidate list of this swarm
-        ctx->scan_cand_bound = 4u * d;
+        ctx->scan_cand_bound = 8u * d;
         a.cand_bound = ctx->scan_cand_bound;
         SWA_HIP(ctx, hipMemsetAsync(a.cand_count, 0, sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(k_scan_filter, dim3((unsigned)blocks, nseeds), dim3(256), 0, ctx->stream, a);
