@@ -27,6 +27,7 @@
 #include "swa_internal.h"
 
 #include <algorithm>
+#include <vector>
 
 int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, const uint32_t * d_targets,
                      const uint32_t * d_count, uint32_t max_count, uint32_t * d_diffs, uint32_t * d_scores,
@@ -52,7 +53,8 @@ struct ScanArgs {
   uint32_t * t_seedidx;         //                  index of the seed inside the batch
   uint32_t cap;                 // capacity of the pair arrays
   uint32_t * counters;          // [0] pairs [1] hits [2] pair overflow flag
-  unsigned long long * totals;  // [0] q-gram comparisons [1] aligned pairs
+  unsigned long long * totals;  // [0] (unused) [1] aligned pairs
+  unsigned long long * compare_slots;   // q-gram comparisons, one partial sum per workgroup slot
   // candidate list of the current swarm: the pool amplicons whose estimate against the initial
   // seed is <= cand_bound.  Later generations can only ever look at those (algo.cc:521-522 prunes
   // on that same estimate), so they scan the list instead of the whole pool.
@@ -60,6 +62,22 @@ struct ScanArgs {
   uint32_t * cand_count;
   uint32_t cand_bound;
 };
+
+// The comparison count is a statistic, and it must not cost anything: thousands of atomics on
+// ONE address per launch serialise in L2 (~100 per us) and were 90 % of the pool scan's time.
+// Every workgroup adds its sum to its own slot of a 4096-entry table (summed by swa_scan_totals).
+constexpr uint32_t kCompareSlots = 4096;
+__device__ __forceinline__ void add_comparisons(const ScanArgs & a, unsigned long long compared) {
+  __shared__ unsigned long long block_sum;
+  if (threadIdx.x == 0) { block_sum = 0ull; }
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, 64); }
+  if ((threadIdx.x & 63u) == 0u && compared != 0ull) { atomicAdd(&block_sum, compared); }
+  __syncthreads();
+  if (threadIdx.x == 0 && block_sum != 0ull) {
+    atomicAdd(&a.compare_slots[(blockIdx.y * gridDim.x + blockIdx.x) & (kCompareSlots - 1u)], block_sum);
+  }
+}
 
 __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
   const uint32_t sidx = blockIdx.y;
@@ -115,9 +133,7 @@ __global__ __launch_bounds__(256) void k_scan_filter(const ScanArgs a) {
       }
     }
   }
-  // one atomic per wave, not per group of 8 lanes (65 k atomics on one address cost tens of us)
-  for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, 64); }
-  if ((threadIdx.x & 63u) == 0u && compared != 0ull) { atomicAdd(&a.totals[0], compared); }
+  add_comparisons(a, compared);
 }
 
 // `mirror` is pinned host memory the GPU writes directly (zero copy): [0..3] = pairs, hits,
@@ -182,9 +198,7 @@ __global__ __launch_bounds__(256) void k_scan_filter_list(const ScanArgs a) {
       }
     }
   }
-  // one atomic per wave, not per group of 8 lanes (65 k atomics on one address cost tens of us)
-  for (int o = 32; o > 0; o >>= 1) { compared += __shfl_xor(compared, o, 64); }
-  if ((threadIdx.x & 63u) == 0u && compared != 0ull) { atomicAdd(&a.totals[0], compared); }
+  add_comparisons(a, compared);
 }
 
 // a sub-seed's limit outgrew the list's bound: collect the list again from the stored estimates
@@ -217,6 +231,8 @@ extern "C" int swa_scan_begin(swa_ctx * ctx) {
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_est, n * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_swarmed, n));
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_counters, 64));
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_compares, kCompareSlots * sizeof(unsigned long long)));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_scan_compares.ptr, 0, kCompareSlots * sizeof(unsigned long long), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_scan_est.ptr, 0, n * sizeof(uint32_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_scan_swarmed.ptr, 0, n, ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_scan_counters.ptr, 0, 64, ctx->stream));
@@ -288,6 +304,7 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     a.cap = (uint32_t)std::min<uint64_t>(pair_cap, 0xFFFFFFFFull);
     a.counters = counters;
     a.totals = totals;
+    a.compare_slots = static_cast<unsigned long long *>(ctx->d_scan_compares.ptr);
     a.cand = static_cast<uint32_t *>(ctx->d_scan_cand.ptr);
     a.cand_count = counters + 12;                      // (u32[4] counters, u64[4] totals, then the list length)
     auto * hits = static_cast<uint32_t *>(ctx->d_scan_hits.ptr);
@@ -396,8 +413,12 @@ extern "C" int swa_scan_totals(swa_ctx * ctx, uint64_t * out3) {
   if (!ctx->scan_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_scan_totals: no scan state"); }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   uint64_t t[4] = {};
+  std::vector<unsigned long long> slots(kCompareSlots);
   SWA_HIP(ctx, hipMemcpyAsync(t, static_cast<uint32_t *>(ctx->d_scan_counters.ptr) + 4, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(slots.data(), ctx->d_scan_compares.ptr, kCompareSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  out3[0] = t[0]; out3[1] = t[1]; out3[2] = ctx->scan_launches;
+  uint64_t compared = 0;
+  for (unsigned long long v : slots) { compared += v; }
+  out3[0] = compared; out3[1] = t[1]; out3[2] = ctx->scan_launches;
   return SWA_OK;
 }

@@ -79,6 +79,7 @@ struct swa_ctx {
   swa_dbuf d_scan_est, d_scan_swarmed, d_scan_targets, d_scan_diffs, d_scan_hits, d_scan_counters;
   swa_dbuf d_scan_cand;          // candidate list of the current swarm (scan.hip)
   swa_dbuf d_scan_seeds;         // seeds + limits of the current batch
+  swa_dbuf d_scan_compares;      // q-gram comparison counts, one slot per workgroup
   uint32_t scan_cand_bound = 0;
   void * h_scan_pinned = nullptr;   // pinned, GPU-visible: seeds + limits in, hit mirror out
   std::vector<uint32_t> scan_host, scan_perm, scan_idx_tmp;
