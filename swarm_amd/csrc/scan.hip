@@ -213,10 +213,17 @@ __global__ __launch_bounds__(256) void k_scan_relist(const uint32_t * __restrict
 // seeds + limits: pinned host memory -> HBM, by one workgroup.  (Letting every wave of the pool
 // scan read them across PCIe cost ~80 us per launch.)  In a first generation the initial seed
 // joins its own swarm here.
+// Also resets the batch counters (and, for a first generation, the candidate list): the first
+// kernel of every launch sequence, so that the sequence needs no memset commands.
 __global__ void k_scan_stage(const uint32_t * __restrict__ pinned, uint32_t * __restrict__ staged, uint32_t words,
-                             uint8_t * swarmed, uint32_t mark_first) {
+                             uint8_t * swarmed, uint32_t mark_first, uint32_t * counters, uint32_t * cand_count,
+                             uint32_t reset_cand) {
   for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) { staged[i] = pinned[i]; }
-  if (mark_first != 0u && threadIdx.x == 0) { swarmed[pinned[0]] = 1; }
+  if (threadIdx.x < 4u) { counters[threadIdx.x] = 0u; }
+  if (threadIdx.x == 0) {
+    if (mark_first != 0u) { swarmed[pinned[0]] = 1; }
+    if (reset_cand != 0u) { *cand_count = 0u; }
+  }
 }
 
 }  // namespace
@@ -308,9 +315,12 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
     a.cand = static_cast<uint32_t *>(ctx->d_scan_cand.ptr);
     a.cand_count = counters + 12;                      // (u32[4] counters, u64[4] totals, then the list length)
     auto * hits = static_cast<uint32_t *>(ctx->d_scan_hits.ptr);
-    SWA_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+    uint32_t max_limit = 0;
+    for (uint32_t k = 0; k < nseeds; ++k) { max_limit = std::max(max_limit, radii[k] + d); }
+    const bool relist = a.first_generation == 0u && max_limit > ctx->scan_cand_bound;
     hipLaunchKernelGGL(k_scan_stage, dim3(1), dim3(256), 0, ctx->stream, pin_seeds,
-                       static_cast<uint32_t *>(ctx->d_scan_seeds.ptr), 2u * nseeds, a.swarmed, a.first_generation);
+                       static_cast<uint32_t *>(ctx->d_scan_seeds.ptr), 2u * nseeds, a.swarmed, a.first_generation, counters,
+                       a.cand_count, (a.first_generation != 0u || relist) ? 1u : 0u);
     if (span > 0) {
       uint64_t blocks = ((uint64_t)span + 31) / 32;
       const uint64_t gcap = std::max<uint64_t>(1, uint64_t(ctx->num_cus) * 8 / nseeds);
@@ -319,14 +329,10 @@ extern "C" int swa_scan_batch(swa_ctx * ctx, uint32_t nseeds, const uint32_t * s
         // whole pool: estimates for everybody, and the candidate list of this swarm
         ctx->scan_cand_bound = 8u * d;
         a.cand_bound = ctx->scan_cand_bound;
-        SWA_HIP(ctx, hipMemsetAsync(a.cand_count, 0, sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(k_scan_filter, dim3((unsigned)blocks, nseeds), dim3(256), 0, ctx->stream, a);
       } else {
-        uint32_t max_limit = 0;
-        for (uint32_t k = 0; k < nseeds; ++k) { max_limit = std::max(max_limit, radii[k] + d); }
-        if (max_limit > ctx->scan_cand_bound) {          // (rare) the radius outgrew the list: collect it again, wider
+        if (relist) {                                      // (rare) the radius outgrew the list: collect it again, wider
           ctx->scan_cand_bound = std::max(2u * ctx->scan_cand_bound, max_limit);
-          SWA_HIP(ctx, hipMemsetAsync(a.cand_count, 0, sizeof(uint32_t), ctx->stream));
           hipLaunchKernelGGL(k_scan_relist, dim3((unsigned)std::min<uint64_t>(((uint64_t)span + 255) / 256, uint64_t(ctx->num_cus) * 8)),
                              dim3(256), 0, ctx->stream, a.est, a.swarmed, lo, n, ctx->scan_cand_bound, a.cand, a.cand_count);
         }
