@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <omp.h>
 #include <string>
 #include <vector>
 
@@ -179,16 +180,35 @@ extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * d
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   if (mothur) { o.str("swarm_"); o.u64((uint64_t)differences); o.put('\t'); o.u64(r->swarmcount_adjusted); }
-  for (const auto & s : r->swarms) {
-    if (s.attached) { continue; }
-    bool first = true;
-    for_each_member(r, s, [&](uint32_t a) {
-      if (mothur) { o.put(first ? '\t' : ','); }
-      else if (!first) { o.put(' '); }
-      first = false;
-      swa_out::id(o, db, a, usearch != 0, append_abundance);
-    });
-    if (!mothur) { o.put('\n'); }
+  auto format_range = [&](BufOut & sink, size_t begin, size_t end) {
+    for (size_t k = begin; k < end; ++k) {
+      const auto & s = r->swarms[k];
+      if (s.attached) { continue; }
+      bool first = true;
+      for_each_member(r, s, [&](uint32_t a) {
+        if (mothur) { sink.put(first ? '\t' : ','); }
+        else if (!first) { sink.put(' '); }
+        first = false;
+        swa_out::id(sink, db, a, usearch != 0, append_abundance);
+      });
+      if (!mothur) { sink.put('\n'); }
+    }
+  };
+  // big outputs (tens of MB at 10 M amplicons) are formatted by several threads, one range of
+  // swarms each, and written in order
+  const size_t ns = r->swarms.size();
+  const int threads = std::min(omp_get_max_threads(), 64);
+  if (r->n < 200000 || threads < 2) {
+    format_range(o, 0, ns);
+  } else {
+    std::vector<std::string> pieces((size_t)threads);
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < threads; ++t) {
+      BufOut sink;
+      format_range(sink, ns * (size_t)t / (size_t)threads, ns * (size_t)(t + 1) / (size_t)threads);
+      pieces[(size_t)t] = sink.take();
+    }
+    for (const auto & piece : pieces) { o.write(piece.data(), piece.size()); }
   }
   if (mothur) { o.put('\n'); }
   return SWA_OK;

@@ -12,6 +12,10 @@
 
 class BufOut {
  public:
+  // memory-only sink: formatted bytes pile up in the buffer until take() (used by writers that
+  // format ranges of clusters on several threads and then emit the pieces in order)
+  BufOut() : memory_only_(true) {}
+  std::string take() { std::string out; out.swap(buf_); return out; }
   explicit BufOut(const char * path) {
     if (path == nullptr) { return; }
     if (std::strcmp(path, "-") == 0) { fp_ = stdout; owned_ = false; }
@@ -46,10 +50,11 @@ class BufOut {
 
  private:
   static constexpr size_t kFlush = 1 << 20;
-  void maybe_flush() { if (buf_.size() >= kFlush) { flush(); } }
+  void maybe_flush() { if (!memory_only_ && buf_.size() >= kFlush) { flush(); } }
   void flush() { if (!buf_.empty()) { std::fwrite(buf_.data(), 1, buf_.size(), fp_); buf_.clear(); } }
   FILE * fp_ = nullptr;
   bool owned_ = false;
+  bool memory_only_ = false;
   std::string buf_;
 };
 

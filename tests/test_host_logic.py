@@ -3,6 +3,7 @@ the d=1 clustering / grafting / writers, checked against the reference's own out
 tests/golden/.  The neighbour lists fed to the host logic here come from the oracle (the GPU
 tests feed it the HIP path's lists)."""
 import filecmp
+import os
 import re
 
 import numpy as np
@@ -143,3 +144,37 @@ def test_d1_uclust_byte_identical(tmp_path):
     assert filecmp.cmp(tmp_path / "u", G / "d1_uclust.u", shallow=False)
     cl.write_swarms(tmp_path / "o")
     assert filecmp.cmp(tmp_path / "o", G / "d1_uclust.o", shallow=False)
+
+
+def test_parallel_swarm_writer_equals_serial(tmp_path):
+    """-o of a big result is formatted by several threads (ranges of swarms) and written in
+    order: byte-identical to the single-threaded path (OMP_NUM_THREADS=1 in a child process)."""
+    import subprocess
+    import sys
+    fa = tmp_path / "big.fa"
+    S.gen_fasta(fa, 260000, 24, 5)
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(S.ROOT)!r})\n"
+        "from swarm_amd import D1Clusters, HostDb\n"
+        f"hdb = HostDb({str(fa)!r})\n"
+        "rng = np.random.default_rng(1)\n"
+        "# a synthetic network: chains i -> i+1 inside blocks of random length (valid for the host\n"
+        "# clustering: any CSR is), so that swarms have many different sizes\n"
+        "n = hdb.n\n"
+        "cut = rng.random(n) < 0.3\n"
+        "deg = np.where(cut | (np.arange(n) == n - 1), 0, 1).astype(np.uint64)\n"
+        "off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum(deg)\n"
+        "nb = (np.arange(n, dtype=np.uint32) + 1)[deg == 1]\n"
+        "cl = D1Clusters(hdb, off, nb)\n"
+        "cl.write_swarms(sys.argv[1]); cl.write_swarms(sys.argv[1] + '.r', mothur=True)\n")
+    outs = []
+    for threads in ("1", "4"):
+        out = tmp_path / f"o{threads}"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS=threads), timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append(out)
+    assert outs[0].stat().st_size > 2_000_000
+    assert filecmp.cmp(outs[0], outs[1], shallow=False)
+    assert filecmp.cmp(str(outs[0]) + ".r", str(outs[1]) + ".r", shallow=False)
