@@ -114,6 +114,9 @@ def main():
         if r:
             same = subprocess.run(["cmp", "-s", r["out"], str(out)]).returncode == 0
             r["output_identical"] = same
+            if not same:                                   # leave enough behind to tell which side is off
+                r["sizes"] = [os.path.getsize(r["out"]), os.path.getsize(out)]
+                r["first_difference"] = subprocess.run(["cmp", r["out"], str(out)], capture_output=True, text=True).stdout.strip()
             res["reference"] = r
     print(json.dumps(res))
 
