@@ -202,3 +202,35 @@ def test_abundance_ties_follow_the_rule(gpu_ctx, tmp_path):
     db = S.build_db([(h.rsplit(b"_", 1)[0] + b"_%d" % (1 + i % 3), s) for i, (h, s) in enumerate(recs)])
     off, nb = _check_vs_oracle(gpu_ctx, db)
     assert len(nb) > 1000
+
+
+def test_results_do_not_depend_on_stale_device_memory(tmp_path):
+    """Device memory is poisoned (0xFF, then 0xA5) before a fresh context runs index + network +
+    fastidious: any read of memory the library did not initialise itself would change the result."""
+    import torch
+    from swarm_amd import Context, D1Clusters, HostDb
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 30000, 150, 71, 1, 0.3)
+    db = S.db_from_fasta(fa)
+    woff, wnb, _ = _oracle_sorted_rows(db)
+    results = []
+    for pattern in (0xFF, 0xA5):
+        junk = torch.empty(6 * (1 << 30), dtype=torch.uint8, device="cuda")
+        junk.fill_(pattern)
+        torch.cuda.synchronize()
+        del junk
+        torch.cuda.empty_cache()
+        ctx = Context(0)
+        hdb = HostDb(fa)
+        ctx.upload_hostdb(hdb)
+        assert ctx.d1_index_build() is False
+        off, nb = ctx.d1_network()
+        assert np.array_equal(off, woff) and np.array_equal(nb, wnb)
+        cl = D1Clusters(hdb, off, nb)
+        flags, stats = cl.light_flags(3)
+        graft, counters = ctx.d1_fastidious(flags, stats[2], 16)
+        results.append((graft.copy(), counters[:5].copy()))
+        ctx.close()
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    want_graft, want_counters = S.oracle_fastidious(db, flags, 16)
+    assert np.array_equal(results[0][0], want_graft)
