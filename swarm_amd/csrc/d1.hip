@@ -776,15 +776,18 @@ static bool anchored_enabled() {
   return !(e != nullptr && e[0] == '1');
 }
 
-static int build_anchor_index(swa_ctx * ctx) {
-  ctx->anchor_ready = false;
+// whether the anchored passes may be used at all for this database (decided at index build)
+static bool anchor_applicable(const swa_ctx * ctx) {
   // (the anchored kernel prefetches a seed's words into kPrefetchWords registers per lane)
-  if (!anchored_enabled() || ctx->db.longest < kMinAnchoredLen || ctx->db.longest > 64u * kPrefetchWords * 32u - 64u) {
-    return SWA_OK;
-  }
+  return anchored_enabled() && ctx->db.longest >= kMinAnchoredLen && ctx->db.longest <= 64u * kPrefetchWords * 32u - 64u;
+}
+
+// (re)builds the two anchor indexes for the query range [first, first + count)
+static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
+  ctx->anchor_ready = false;
   const uint32_t n = ctx->db.n;
   uint64_t asize = 64;
-  while (asize < 2ull * n) { asize <<= 1; }
+  while (asize < 2ull * count) { asize <<= 1; }
   ctx->anchor_slots = asize;
   for (int which = 0; which < 2; ++which) {
     SWA_TRY(swa_reserve(ctx, ctx->d_akeys[which], asize * sizeof(uint64_t)));
@@ -796,9 +799,6 @@ static int build_anchor_index(swa_ctx * ctx) {
     SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], (uint64_t(n) + 128) * sizeof(swa_item)));   // big | small halves
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
-  hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
-                     static_cast<uint32_t *>(ctx->d_arank.ptr), static_cast<uint32_t *>(ctx->d_flags.ptr));
   const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
@@ -811,8 +811,12 @@ static int build_anchor_index(swa_ctx * ctx) {
     hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, keys, counts, cursor, asize);
     AnchorBuildArgs b{};
     b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n; b.which = which;
+    b.first = first; b.count = count;
     b.keys = keys; b.counts = counts; b.amask = asize - 1; b.slot_of = slot_of;
-    hipLaunchKernelGGL(k_anchor_insert, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_anchor_insert, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
+    if (count < n) {
+      hipLaunchKernelGGL(k_anchor_lookup, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
+    }
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, counts, (uint32_t)asize,
                        static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
@@ -822,6 +826,8 @@ static int build_anchor_index(swa_ctx * ctx) {
                        static_cast<uint32_t *>(ctx->d_amembers[which].ptr));
     SWA_HIP(ctx, hipGetLastError());
   }
+  ctx->anchor_first = first;
+  ctx->anchor_count = count;
   ctx->anchor_ready = true;
   return SWA_OK;
 }
@@ -840,27 +846,14 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
   auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
   swa_t0(ctx, 3);
-  // work items of this call: only groups that own a seed of [first, first+count) (all of them
-  // when the whole database is queried)
+  // work items: every group of the index (it was built for exactly this query range)
   const uint64_t asize = ctx->anchor_slots;
-  const bool whole = first == 0 && count == ctx->db.n;
-  uint8_t * wanted[2] = {nullptr, nullptr};
-  if (!whole) {
-    SWA_TRY(swa_reserve(ctx, ctx->d_awanted, 2 * asize));
-    SWA_HIP(ctx, hipMemsetAsync(ctx->d_awanted.ptr, 0, 2 * asize, ctx->stream));
-    wanted[0] = static_cast<uint8_t *>(ctx->d_awanted.ptr);
-    wanted[1] = wanted[0] + asize;
-    hipLaunchKernelGGL(k_anchor_flag, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first, count,
-                       static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_aslot[1].ptr),
-                       wanted[0], wanted[1]);
-  }
   for (int which = 0; which < 2; ++which) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                        static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
                        static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr), acounters + which,
-                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + (ctx->db.n / 2 + 64), acounters + 3 + which,
-                       wanted[which]);
+                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + (ctx->db.n / 2 + 64), acounters + 3 + which);
   }
   SWA_HIP(ctx, hipGetLastError());
   for (int pass = 0; pass < 2; ++pass) {
@@ -1001,14 +994,20 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
                      static_cast<uint32_t *>(ctx->d_flags.ptr));
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 2);
-  swa_t0(ctx, 7);
-  SWA_TRY(build_anchor_index(ctx));
-  swa_t1(ctx, 7);
+  // the anchored index itself is built by the first network call, for that call's query range
+  ctx->anchor_ready = false;
+  ctx->anchor_usable = anchor_applicable(ctx);
+  if (ctx->anchor_usable) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
+                       static_cast<uint32_t *>(ctx->d_arank.ptr), static_cast<uint32_t *>(ctx->d_flags.ptr));
+    SWA_HIP(ctx, hipGetLastError());
+  }
   uint32_t flags[2] = {0, 0};                               // [0] duplicates [1] abundances not in descending order
   SWA_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags.ptr, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t flag = flags[0];
-  if (flags[1] != 0) { ctx->anchor_ready = false; }         // the anchored passes rely on the db order
+  if (flags[1] != 0) { ctx->anchor_usable = false; }        // the anchored passes rely on the db order
   ctx->d1_ready = true;
   if (has_duplicates != nullptr) { *has_duplicates = flag != 0 ? 1 : 0; }
   if (flag != 0) {
@@ -1092,7 +1091,14 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
   for (int attempt = 0; attempt < 3; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
     SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, uint64_t(nseg) * sizeof(uint32_t), ctx->stream));
-    if (ctx->anchor_ready && !stats) { SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count)); }
+    if (ctx->anchor_usable && !stats) {
+      if (!ctx->anchor_ready || ctx->anchor_first != first || ctx->anchor_count != count) {
+        swa_t0(ctx, 7);
+        SWA_TRY(build_anchor_index(ctx, first, count));
+        swa_t1(ctx, 7);
+      }
+      SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count));
+    }
     else { SWA_TRY(launch_network(ctx, no_cluster_breaking, first, count, stats)); }
     hipLaunchKernelGGL(k_seg_reduce, dim3(1), dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
                        nseg, static_cast<unsigned long long *>(ctx->d_stats.ptr) + 8);

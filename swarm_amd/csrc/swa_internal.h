@@ -59,10 +59,12 @@ struct swa_ctx {
   swa_dbuf d_edges;              // u64 edge list (src << 32 | dst)
   swa_dbuf d_counts, d_cursor, d_scan_tmp, d_offsets_tmp, d_nb_tmp, d_long_rows;
   // anchored d=1 index (d1_anchor.inc): [0] prefix groups, [1] suffix groups
-  bool anchor_ready = false;
+  bool anchor_usable = false;    // decided by swa_d1_index_build: lengths fit, db order holds, not switched off
+  bool anchor_ready = false;     // the index below exists, built for [anchor_first, anchor_first + anchor_count)
+  uint32_t anchor_first = 0, anchor_count = 0;
   uint64_t anchor_slots = 0;
   swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_acursor[2], d_aoffsets[2], d_aslot[2], d_amembers[2], d_aitems[2];
-  swa_dbuf d_acounters, d_afallback, d_awanted, d_arank;
+  swa_dbuf d_acounters, d_afallback, d_arank;
   swa_dbuf d_seg_fill;           // u32 fill of every per-wave edge segment
   uint64_t seg_cap = 0;          // entries per segment
 

@@ -206,31 +206,37 @@ def test_abundance_ties_follow_the_rule(gpu_ctx, tmp_path):
 
 def test_results_do_not_depend_on_stale_device_memory(tmp_path):
     """Device memory is poisoned (0xFF, then 0xA5) before a fresh context runs index + network +
-    fastidious: any read of memory the library did not initialise itself would change the result."""
-    import torch
-    from swarm_amd import Context, D1Clusters, HostDb
+    fastidious: any read of memory the library did not initialise itself would change the result.
+    Own process: torch (used only to poison HBM) must initialise its HIP runtime first."""
+    import os
+    import subprocess
+    import sys
     fa = tmp_path / "in.fa"
     S.gen_fasta(fa, 30000, 150, 71, 1, 0.3)
-    db = S.db_from_fasta(fa)
-    woff, wnb, _ = _oracle_sorted_rows(db)
-    results = []
-    for pattern in (0xFF, 0xA5):
-        junk = torch.empty(6 * (1 << 30), dtype=torch.uint8, device="cuda")
-        junk.fill_(pattern)
-        torch.cuda.synchronize()
-        del junk
-        torch.cuda.empty_cache()
-        ctx = Context(0)
-        hdb = HostDb(fa)
-        ctx.upload_hostdb(hdb)
-        assert ctx.d1_index_build() is False
-        off, nb = ctx.d1_network()
-        assert np.array_equal(off, woff) and np.array_equal(nb, wnb)
-        cl = D1Clusters(hdb, off, nb)
-        flags, stats = cl.light_flags(3)
-        graft, counters = ctx.d1_fastidious(flags, stats[2], 16)
-        results.append((graft.copy(), counters[:5].copy()))
-        ctx.close()
-    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
-    want_graft, want_counters = S.oracle_fastidious(db, flags, 16)
-    assert np.array_equal(results[0][0], want_graft)
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(S.ROOT)!r}); sys.path.insert(0, {str(S.ROOT / 'tests')!r})\n"
+        "import support as S\n"
+        "from swarm_amd import Context, D1Clusters, HostDb\n"
+        f"fa = {str(fa)!r}\n"
+        "db = S.db_from_fasta(fa)\n"
+        "woff, wnb, _ = S.oracle_d1_network(db)\n"
+        "wnb = wnb.copy()\n"
+        "for i in range(db.n): wnb[int(woff[i]):int(woff[i + 1])].sort()\n"
+        "results = []\n"
+        "for pattern in (0xFF, 0xA5):\n"
+        "    junk = torch.empty(6 * (1 << 30), dtype=torch.uint8, device='cuda'); junk.fill_(pattern)\n"
+        "    torch.cuda.synchronize(); del junk; torch.cuda.empty_cache()\n"
+        "    ctx = Context(0); hdb = HostDb(fa); ctx.upload_hostdb(hdb)\n"
+        "    assert ctx.d1_index_build() is False\n"
+        "    off, nb = ctx.d1_network()\n"
+        "    assert np.array_equal(off, woff) and np.array_equal(nb, wnb), 'network differs'\n"
+        "    cl = D1Clusters(hdb, off, nb); flags, stats = cl.light_flags(3)\n"
+        "    graft, counters = ctx.d1_fastidious(flags, stats[2], 16)\n"
+        "    results.append((graft.copy(), counters[:5].copy())); ctx.close()\n"
+        "assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])\n"
+        "want_graft, _ = S.oracle_fastidious(db, flags, 16)\n"
+        "assert np.array_equal(results[0][0], want_graft), 'graft differs'\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ), timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
