@@ -47,3 +47,29 @@ def test_cli_stdout_and_duplicates(tmp_path):
     assert r.returncode == 1 and "some fasta entries have identical sequences" in r.stderr
     r = subprocess.run([str(BIN), "-d", "2", str(dup)], capture_output=True, text=True)
     assert r.returncode == 1 and "some fasta entries have identical sequences" in r.stderr
+
+
+@pytest.mark.skipif(not S.have_reference(), reason="compiled reference not available on this box")
+@pytest.mark.parametrize("n,length,seed,light,args", [
+    (60000, 150, 301, 0.0, ["-d", "1"]),
+    (60000, 150, 302, 0.3, ["-d", "1", "-f"]),
+    (40000, 80, 303, 0.3, ["-d", "1", "-f", "-b", "5", "-y", "10"]),
+    (30000, 250, 304, 0.0, ["-d", "1", "-n"]),
+    (20000, 100, 305, 0.0, ["-d", "1", "-r"]),
+])
+def test_cli_against_reference_binary(tmp_path, n, length, seed, light, args):
+    """Random sets, both binaries, every output file byte-compared (the reference binary is the
+    one oracle/Makefile builds into oracle/_ref; it travels with the repository snapshot)."""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, n, length, seed, 1, light)
+    outs = "osiwj" if "-r" not in args else "o"
+    ref_cmd, our_cmd = list(args), [str(BIN)] + list(args)
+    for k in outs:
+        ref_cmd += [FLAG[k], str(tmp_path / f"r{k}")]
+        our_cmd += [FLAG[k], str(tmp_path / f"g{k}")]
+    r = S.run_ref_swarm(ref_cmd + ["-l", "/dev/null", str(fa)])
+    assert r.returncode == 0, r.stderr
+    g = subprocess.run(our_cmd + ["-l", "/dev/null", str(fa)], capture_output=True, text=True)
+    assert g.returncode == 0, g.stderr
+    for k in outs:
+        assert filecmp.cmp(tmp_path / f"r{k}", tmp_path / f"g{k}", shallow=False), k

@@ -34,7 +34,12 @@ def test_dn_outputs_byte_identical(gpu_ctx, tmp_path, name):
 
 
 @pytest.mark.skipif(not S.have_reference(), reason="compiled reference not available on this box")
-@pytest.mark.parametrize("n,length,d,edits,extra", [(3000, 150, 2, 2, []), (2000, 400, 3, 3, []), (1500, 100, 3, 3, ["-n"])])
+@pytest.mark.parametrize("n,length,d,edits,extra", [(3000, 150, 2, 2, []), (2000, 400, 3, 3, []), (1500, 100, 3, 3, ["-n"]),
+                                                     # bigger sets: long generation chains (radius outgrows the candidate
+                                                     # list's bound), many swarms, the wavefront kernel at d = 2 and 3, the
+                                                     # banded one at d = 4
+                                                     (25000, 200, 2, 2, []), (15000, 300, 3, 3, []), (8000, 120, 4, 4, []),
+                                                     (6000, 60, 3, 3, ["-n"])])
 def test_dn_against_reference_binary(gpu_ctx, tmp_path, n, length, d, edits, extra):
     fa = tmp_path / "in.fa"
     S.gen_fasta(fa, n, length, 900 + d, edits)
