@@ -97,6 +97,46 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
                 "sample": f"oracle/ C restatement, index build + network only, {sample_n} x {length} bp, {dt:.2f} s"}
 
 
+def scale_check(torch, dev, local_rank: int, args, n: int = 10_000_000, steps: int = 3) -> dict:
+    """The bench step (index build + network, db and CSR resident) on n x length amplicons."""
+    from swarm_amd import Context, HostDb
+    fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{args.length}_s{args.seed}.fa"
+    if not fasta.exists():
+        tmp = fasta.with_suffix(f".tmp{os.getpid()}")
+        subprocess.run([str(gen_tool()), str(n), str(args.length), str(args.seed), "1", "0", str(tmp)], check=True)
+        os.replace(tmp, fasta)
+    hdb = HostDb(fasta)
+
+    def to_dev(a: np.ndarray, as_dtype):
+        return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
+
+    t_seqs = to_dev(np.concatenate([hdb.seqs, np.zeros(2, dtype=np.uint64)]), np.int64)
+    t_off, t_len, t_ab = to_dev(hdb.seq_off, np.int64), to_dev(hdb.seqlen, np.int32), to_dev(hdb.abundance, np.int64)
+    ctx = Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    ctx.attach_db(t_seqs, t_off, t_len, t_ab, hdb.longest)
+    ctx.timing_enable(True)
+    cap = 8 * hdb.n
+    d_offsets = torch.zeros(hdb.n + 1, dtype=torch.int64, device=dev)
+    d_nb = torch.zeros(cap, dtype=torch.int32, device=dev)
+    total, k_ms = 0, []
+    for it in range(1 + steps):
+        if it == 1:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+        assert not ctx.d1_index_build()
+        total = ctx.d1_network_device(d_offsets, d_nb, cap, False, 0, hdb.n)
+        if it >= 1:
+            k_ms.append(ctx.timing_read()[3])
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    k = float(np.mean(k_ms))
+    abytes = algorithmic_bytes(hdb.seqlen, total)
+    ctx.close()
+    return {"workload": f"{hdb.n} synthetic amplicons x {args.length} bp, d=1", "value": hdb.n * steps / elapsed,
+            "unit": "amplicons/s", "steps": steps, "ms_per_step": 1000.0 * elapsed / steps, "network_kernels_ms": k,
+            "neighbour_links": int(total), "roofline_frac": abytes / (k * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +146,8 @@ def main() -> None:
     ap.add_argument("--length", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale-check", action="store_true",
+                    help="skip the extra 10 M x 150 measurement reported under config.scale_check (N = 1 only)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="development aid: run rank 0's share of an N-GPU job on this one GPU (no collectives); "
                          "the JSON line is marked simulated and is not a result")
@@ -234,6 +276,9 @@ def main() -> None:
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_kernel_ms": k_ms},
         }
+        if world == 1 and not sim_world and not args.no_scale_check and not args.no_cpu_baseline:
+            # BASELINE.json's metric string names 10 M x 150 bp: the same step at that size, same run
+            out["config"]["scale_check"] = scale_check(torch, dev, local_rank, args)
         if sim_world:
             out["simulated"] = f"rank 0 of {sim_world}, no collectives: value counts all {n_total} amplicons as if every rank finished in this time"
         if world == 1 and not sim_world and not args.no_cpu_baseline:
