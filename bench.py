@@ -8,9 +8,11 @@ C ABI, with the packed database already resident in HBM and the CSR left in HBM:
 and, for N > 1, the RCCL all-gather of the per-rank CSR slices (hit counts, then padded hit
 lists) over xGMI.
 
-Workload at N = 1: BASELINE.json configs[1] — 1M synthetic amplicons x 150 bp, d = 1.
-For N > 1 the job is weak-scaled: the database holds N x 1M amplicons, replicated on every
-GPU (table + Bloom built per GPU), and rank r answers the queries of its contiguous 1M slice.
+Workload at N = 1: the size BASELINE.json's metric string names — 10 M synthetic amplicons x
+150 bp, d = 1 (configs[1], 1 M x 150, is measured in the same run and reported under
+config.configs1).  For N > 1 the job is weak-scaled: the database holds N x 10 M amplicons
+(N = 8: 80 M, the order of configs[4]), replicated on every GPU (table + Bloom built per GPU),
+and rank r answers the queries of its contiguous 10 M slice.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline"     — algorithmic bytes of the dominant kernel group (the d=1 network: the anchored
@@ -55,6 +57,46 @@ def gen_tool() -> Path:
     return out
 
 
+def gen_fasta(n: int, length: int, seed: int) -> Path:
+    """The synthetic amplicon set (SURVEY.md section 8d shapes; tools/gen_amplicons.c), cached in
+    the temp dir.  Sets above 2 M are generated as independent blocks of <= 2 M amplicons by
+    parallel processes (disjoint header numbers, seeds derived from `seed`) and concatenated."""
+    fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{length}_s{seed}.fa"
+    if fasta.exists():
+        return fasta
+    tool = str(gen_tool())
+    tmp = fasta.with_suffix(f".tmp{os.getpid()}")
+    block = 2_000_000
+    if n <= block:
+        subprocess.run([tool, str(n), str(length), str(seed), "1", "0", str(tmp)], check=True)
+    else:
+        parts, procs, at, b = [], [], 0, 0
+        limit = max(1, min(32, (os.cpu_count() or 2) // 2))
+        while at < n:
+            size = min(block, n - at)
+            part = fasta.with_suffix(f".part{b}.{os.getpid()}")
+            parts.append(part)
+            procs.append(subprocess.Popen([tool, str(size), str(length), str(seed * 1000 + b + 1), "1", "0", str(part), str(at)]))
+            at += size
+            b += 1
+            while sum(p.poll() is None for p in procs) >= limit:
+                time.sleep(0.05)
+        for p in procs:
+            if p.wait() != 0:
+                raise SystemExit("gen_amplicons failed")
+        with open(tmp, "wb") as out:
+            for part in parts:
+                with open(part, "rb") as src:
+                    while True:
+                        chunk = src.read(64 << 20)
+                        if not chunk:
+                            break
+                        out.write(chunk)
+                part.unlink()
+    os.replace(tmp, fasta)
+    return fasta
+
+
 def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
     """Reference swarm (or, failing that, the C oracle) on this box's host cores, bounded sample."""
     cores = os.cpu_count() or 1
@@ -97,15 +139,10 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
                 "sample": f"oracle/ C restatement, index build + network only, {sample_n} x {length} bp, {dt:.2f} s"}
 
 
-def scale_check(torch, dev, local_rank: int, args, n: int = 10_000_000, steps: int = 3) -> dict:
+def extra_measurement(torch, dev, local_rank: int, args, n: int, steps: int) -> dict:
     """The bench step (index build + network, db and CSR resident) on n x length amplicons."""
     from swarm_amd import Context, HostDb
-    fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{args.length}_s{args.seed}.fa"
-    if not fasta.exists():
-        tmp = fasta.with_suffix(f".tmp{os.getpid()}")
-        subprocess.run([str(gen_tool()), str(n), str(args.length), str(args.seed), "1", "0", str(tmp)], check=True)
-        os.replace(tmp, fasta)
-    hdb = HostDb(fasta)
+    hdb = HostDb(gen_fasta(n, args.length, args.seed))
 
     def to_dev(a: np.ndarray, as_dtype):
         return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
@@ -142,12 +179,12 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--per-gpu", type=int, default=1_000_000, help="amplicons queried per GPU")
+    ap.add_argument("--per-gpu", type=int, default=10_000_000, help="amplicons queried per GPU")
     ap.add_argument("--length", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-scale-check", action="store_true",
-                    help="skip the extra 10 M x 150 measurement reported under config.scale_check (N = 1 only)")
+    ap.add_argument("--no-configs1", action="store_true",
+                    help="skip the extra configs[1] (1 M x 150) measurement reported under config.configs1 (N = 1 only)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="development aid: run rank 0's share of an N-GPU job on this one GPU (no collectives); "
                          "the JSON line is marked simulated and is not a result")
@@ -171,10 +208,8 @@ def main() -> None:
     sim_world = args.simulate_world if world == 1 and args.simulate_world > 1 else 0
     n_total = args.per_gpu * (sim_world or world)
     fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n_total}x{args.length}_s{args.seed}.fa"
-    if local_rank == 0 and not fasta.exists():
-        tmp = fasta.with_suffix(f".tmp{os.getpid()}")
-        subprocess.run([str(gen_tool()), str(n_total), str(args.length), str(args.seed), "1", "0", str(tmp)], check=True)
-        os.replace(tmp, fasta)
+    if local_rank == 0:
+        gen_fasta(n_total, args.length, args.seed)
     if world > 1:
         dist.barrier()
     hdb = HostDb(fasta)
@@ -262,7 +297,8 @@ def main() -> None:
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_total} synthetic amplicons x {args.length} bp, d=1 (BASELINE configs[1] per GPU)",
+                "workload": f"{n_total} synthetic amplicons x {args.length} bp, d=1 ({args.per_gpu} per GPU: the size "
+                            "BASELINE.json's metric names; configs[1] under config.configs1)",
                 "per_gpu_queries": count,
                 "db_amplicons": n_total,
                 "step": "swa_d1_index_build + swa_d1_network_device (B1 seam), db and CSR resident in HBM"
@@ -276,13 +312,16 @@ def main() -> None:
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_kernel_ms": k_ms},
         }
-        if world == 1 and not sim_world and not args.no_scale_check and not args.no_cpu_baseline:
-            # BASELINE.json's metric string names 10 M x 150 bp: the same step at that size, same run
-            out["config"]["scale_check"] = scale_check(torch, dev, local_rank, args)
+        if world == 1 and not sim_world and not args.no_configs1 and not args.no_cpu_baseline:
+            # BASELINE.json configs[1] (1 M x 150, d=1): the same step at that size, same run
+            out["config"]["configs1"] = extra_measurement(torch, dev, local_rank, args, 1_000_000, 10)
         if sim_world:
             out["simulated"] = f"rank 0 of {sim_world}, no collectives: value counts all {n_total} amplicons as if every rank finished in this time"
         if world == 1 and not sim_world and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fasta, n_total, args.length, args.seed)
+            # bounded sample: the reference needs ~25 s per run on the 10 M set; 1 M keeps the three
+            # thread settings it is tried with inside the 10-30 s budget
+            sample_n = min(n_total, 1_000_000)
+            out["cpu_baseline"] = cpu_baseline(gen_fasta(sample_n, args.length, args.seed), sample_n, args.length, args.seed)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

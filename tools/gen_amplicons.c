@@ -86,6 +86,8 @@ static uint32_t apply_edit(rng_t * r, uint8_t * s, uint32_t len) {
 }
 
 /* Generates the set and writes FASTA.  Returns 0 on success. */
+static uint64_t g_id_offset = 0;   /* first header number (blocks generated separately get disjoint names) */
+
 int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edits,
                         double light_frac, const char * path) {
   if (n == 0 || L < 8 || L > 60000 || max_edits == 0) return 1;
@@ -160,7 +162,7 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
   setvbuf(fp, NULL, _IOFBF, 1 << 22);
   for (uint64_t k = 0; k < n; ++k) {
     const amp_t * a = &amps[order[k]];
-    int w = sprintf(line, ">s%u_%llu\n", order[k], (unsigned long long)a->abundance);
+    int w = sprintf(line, ">s%llu_%llu\n", (unsigned long long)(g_id_offset + order[k]), (unsigned long long)a->abundance);
     for (uint32_t i = 0; i < a->len; ++i) line[w + (int)i] = sym[pool[a->off + i]];
     line[w + a->len] = '\n';
     fwrite(line, 1, (size_t)w + a->len + 1, fp);
@@ -172,10 +174,11 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
 
 #ifndef GEN_NO_MAIN
 int main(int argc, char ** argv) {
-  if (argc != 7) {
-    fprintf(stderr, "usage: %s <n> <L> <seed> <max_edits> <light_frac> <out.fasta>\n", argv[0]);
+  if (argc != 7 && argc != 8) {
+    fprintf(stderr, "usage: %s <n> <L> <seed> <max_edits> <light_frac> <out.fasta> [first header number]\n", argv[0]);
     return 2;
   }
+  if (argc == 8) g_id_offset = strtoull(argv[7], NULL, 10);
   const int rc = gen_amplicons_fasta(strtoull(argv[1], NULL, 10), (uint32_t)atoi(argv[2]),
                                      strtoull(argv[3], NULL, 10), (uint32_t)atoi(argv[4]),
                                      atof(argv[5]), argv[6]);
