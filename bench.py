@@ -5,8 +5,8 @@ One "step" = one full pass of the hot path over the synthetic amplicon set, thro
 C ABI, with the packed database already resident in HBM and the CSR left in HBM:
     swa_d1_index_build   (sequence hashes, amplicon hash table, Bloom filter, duplicate check)
     swa_d1_network_device (microvariant hashes -> Bloom -> table probe -> verify -> CSR)
-and, for N > 1, the RCCL all-gather of the per-rank CSR slices (hit counts, then padded hit
-lists) over xGMI.
+and, for N > 1, a MAX all-reduce of the per-rank duplicate flags and the RCCL all-gather of the
+per-rank CSR slices (hit counts, then padded hit lists) over xGMI.
 
 Workload at N = 1: the size BASELINE.json's metric string names — 10 M synthetic amplicons x
 150 bp, d = 1 (configs[1], 1 M x 150, is measured in the same run and reported under
@@ -238,8 +238,15 @@ def main() -> None:
     kernel_ms = []
     hits_seen = [0]
 
+    dup_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
     def step(record: bool) -> None:
-        dup = ctx.d1_index_build()
+        # every rank checks its own slice for duplicate sequences; the flags are OR-ed below
+        dup = ctx.d1_index_build(first, count)
+        if world > 1:
+            dup_flag.fill_(1 if dup else 0)
+            dist.all_reduce(dup_flag, op=dist.ReduceOp.MAX)
+            dup = bool(dup_flag.item())
         assert not dup
         total = ctx.d1_network_device(d_offsets, d_nb, cap, False, first, count)
         hits_seen[0] = total

@@ -100,6 +100,11 @@ int swa_db_attach(swa_ctx * ctx, const swa_db_view * device_db);
    src/bloompat.cc) for ALL amplicons, built on the GPU.  *has_duplicates != 0 (and
    SWA_E_DUPLICATES returned) when two amplicons have identical sequences. */
 int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates);
+/* Multi-GPU form: the index covers the whole database as above, but only the amplicons of
+   [first, first + count) are checked for an identical twin (anywhere in the database).  A job
+   that gives every rank its slice and ORs the flags detects every duplicate exactly once more
+   cheaply than every rank checking everything.  Returns SWA_E_DUPLICATES like the above. */
+int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates);
 
 /* Neighbour lists of amplicons [first, first+count) as CSR: offsets[count+1],
    neighbours[offsets[count]]; row k = { j != first+k : seq_j is a microvariant of

@@ -37,7 +37,7 @@ class DbView(C.Structure):
 
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize",
-    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_network", "swa_d1_network_device",
+    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_network", "swa_d1_network_device",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
@@ -315,10 +315,15 @@ class Context:
         self.n = n
 
     # ---- B1
-    def d1_index_build(self) -> bool:
-        """Returns True when duplicate sequences were found (the reference aborts in that case)."""
+    def d1_index_build(self, first: int = 0, count: int | None = None) -> bool:
+        """Returns True when duplicate sequences were found (the reference aborts in that case).
+        With a range only the amplicons of [first, first+count) are checked for a twin (multi-GPU:
+        every rank its slice, flags combined with a MAX all-reduce)."""
         dup = C.c_int(0)
-        self._check(self.lib.swa_d1_index_build(self.h, C.byref(dup)), allow=(SWA_E_DUPLICATES,))
+        if count is None:
+            count = self.n - first
+        self.lib.swa_d1_index_build_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
+        self._check(self.lib.swa_d1_index_build_range(self.h, first, count, C.byref(dup)), allow=(SWA_E_DUPLICATES,))
         return bool(dup.value)
 
     def d1_network(self, no_cluster_breaking: bool = False, first: int = 0, count: int | None = None):

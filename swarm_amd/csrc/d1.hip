@@ -151,10 +151,11 @@ __global__ __launch_bounds__(256) void k_table_insert(const uint64_t * __restric
 __global__ __launch_bounds__(256) void k_dup_check(const uint64_t * __restrict__ seqs,
                                                    const uint64_t * __restrict__ seq_off,
                                                    const uint32_t * __restrict__ seqlen,
-                                                   const uint64_t * __restrict__ seqhash, uint32_t n,
-                                                   const swa_slot * __restrict__ table, uint64_t tmask,
+                                                   const uint64_t * __restrict__ seqhash, uint32_t first,
+                                                   uint32_t count, const swa_slot * __restrict__ table, uint64_t tmask,
                                                    uint32_t * flag) {
-  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+    const uint32_t a = first + k;
     const uint64_t h = seqhash[a];
     const uint32_t len = seqlen[a];
     uint64_t idx = (h >> 32) & tmask;
@@ -960,7 +961,13 @@ int swa_hash_sequences(swa_ctx * ctx) {
 
 extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   if (ctx == nullptr) { return SWA_E_ARG; }
+  return swa_d1_index_build_range(ctx, 0, ctx->db.n, has_duplicates);
+}
+
+extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
   if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build: no database"); }
+  if (first > ctx->db.n || count > ctx->db.n - first) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_range: bad range"); }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n = ctx->db.n;
   ctx->d1_ready = false;
@@ -983,15 +990,16 @@ extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
   SWA_TRY(swa_hash_sequences(ctx));
-  const int hgrid = grid_for(ctx, n, 256, 8);
   swa_t0(ctx, 1);
   SWA_TRY(swa_d1_rebuild_table(ctx, nullptr));
   swa_t1(ctx, 1);
   swa_t0(ctx, 2);
-  hipLaunchKernelGGL(k_dup_check, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                     ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_seqhash.ptr), n,
+  if (count > 0) {
+  hipLaunchKernelGGL(k_dup_check, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_seqhash.ptr), first, count,
                      static_cast<const swa_slot *>(ctx->d_table.ptr), ctx->table_size - 1,
                      static_cast<uint32_t *>(ctx->d_flags.ptr));
+  }
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 2);
   // the anchored index itself is built by the first network call, for that call's query range

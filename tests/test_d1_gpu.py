@@ -240,3 +240,26 @@ def test_results_do_not_depend_on_stale_device_memory(tmp_path):
         "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ), timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_duplicate_check_by_slices(gpu_ctx, tmp_path):
+    """swa_d1_index_build_range: each slice reports the duplicates it contains (a twin anywhere in
+    the database counts), the OR over slices equals the whole-database answer."""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 3000, 60, 81)
+    recs = S.read_fasta(fa)
+    dup_of = recs[1200][1]
+    recs.append((b"twin_1", dup_of))                       # identical to an amplicon in the middle of the db
+    db = S.build_db(recs)
+    _upload(gpu_ctx, db)
+    assert gpu_ctx.d1_index_build() is True
+    where = [i for i in range(db.n) if db.seq_str(i) == dup_of.decode().upper()]
+    assert len(where) == 2
+    flags = []
+    for first, count in [(0, 1000), (1000, 1000), (2000, db.n - 2000)]:
+        got = gpu_ctx.d1_index_build(first, count)
+        flags.append(got)
+        assert got == any(first <= w < first + count for w in where)
+    assert any(flags)
+    _upload(gpu_ctx, S.db_from_fasta(fa))
+    assert [gpu_ctx.d1_index_build(f, c) for f, c in [(0, 1500), (1500, 1500)]] == [False, False]
