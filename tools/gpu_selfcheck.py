@@ -49,6 +49,13 @@ def main() -> None:
         same = np.array_equal(off, woff) and np.array_equal(nb, wnb)
         print(f"round {r}: {len(nb)} links, {'identical to the oracle' if same else 'DIFFERENT from the oracle (' + str(len(wnb)) + ')'}")
         bad += 0 if same else 1
+        # a sharded rank's view: the index rebuilt for a sub-range (insert + lookup kernels)
+        first, count = 250_000 * (r % 3), 250_000
+        soff, snb = ctx.d1_network(False, first, count)
+        lo, hi = int(woff[first]), int(woff[first + count])
+        sub_ok = np.array_equal(soff, woff[first:first + count + 1] - woff[first]) and np.array_equal(snb, wnb[lo:hi])
+        print(f"         sub-range [{first}, {first + count}): {'identical' if sub_ok else 'DIFFERENT'}")
+        bad += 0 if sub_ok else 1
         ctx.close()
     sys.exit(1 if bad else 0)
 
