@@ -63,7 +63,15 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
   r->generation.assign(n, 0);
   r->graft_cand.assign(n, SWA_NO_AMPLICON);
   r->order.reserve(n);
-  std::vector<uint32_t> fresh;
+  // The walk is a chain of dependent random reads (row of s -> ids -> swarmid of each id), so the
+  // loop touches as little as possible per amplicon: the visited test reads swarmid[] only,
+  // parent / generation go to arrays aligned with `order` (sequential writes) and are scattered
+  // afterwards in one pass of independent writes, and the rows of the next generation are
+  // prefetched while the current one is expanded.
+  std::vector<uint32_t> order_parent, order_generation;
+  order_parent.reserve(n);
+  order_generation.reserve(n);
+  std::vector<uint64_t> fresh;                // (id << 32 | parent): sorting it sorts by id
   for (uint32_t seed = 0; seed < n; ++seed) {
     if (r->swarmid[seed] != SWA_NO_AMPLICON) { continue; }
     const uint32_t sid = (uint32_t)r->swarms.size();
@@ -72,6 +80,8 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
     sw.begin = (uint32_t)r->order.size();
     r->swarmid[seed] = sid;
     r->order.push_back(seed);
+    order_parent.push_back(SWA_NO_AMPLICON);
+    order_generation.push_back(0);
     uint32_t gen_begin = sw.begin;            // current generation = order[gen_begin, gen_end)
     uint32_t gen_end = gen_begin + 1;
     uint32_t gen = 0;
@@ -79,19 +89,24 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
       fresh.clear();
       for (uint32_t k = gen_begin; k < gen_end; ++k) {
         const uint32_t s = r->order[k];
-        for (uint64_t e = offsets[s]; e < offsets[s + 1]; ++e) {
+        const uint64_t row_end = offsets[s + 1];
+        for (uint64_t e = offsets[s]; e < row_end; ++e) {
+          if (e + 8 < row_end) { __builtin_prefetch(&r->swarmid[neighbours[e + 8]]); }
           const uint32_t amp = neighbours[e];
           if (r->swarmid[amp] == SWA_NO_AMPLICON) {
             r->swarmid[amp] = sid;
-            r->generation[amp] = gen + 1;
-            r->parent[amp] = s;
-            fresh.push_back(amp);
+            __builtin_prefetch(&offsets[amp]);
+            fresh.push_back(((uint64_t)amp << 32) | s);
           }
         }
       }
       // each generation joins the swarm sorted by db index (= abundance, then header)
       std::sort(fresh.begin(), fresh.end());
-      r->order.insert(r->order.end(), fresh.begin(), fresh.end());
+      for (const uint64_t f : fresh) {
+        r->order.push_back((uint32_t)(f >> 32));
+        order_parent.push_back((uint32_t)f);
+        order_generation.push_back(gen + 1);
+      }
       gen_begin = gen_end;
       gen_end = (uint32_t)r->order.size();
       if (!fresh.empty()) { ++gen; }
@@ -99,15 +114,23 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
     sw.end = (uint32_t)r->order.size();
     sw.size = sw.end - sw.begin;
     sw.maxgen = gen;
+    r->largest = std::max(r->largest, sw.size);
+    r->maxgen = std::max(r->maxgen, sw.maxgen);
+    r->swarms.push_back(std::move(sw));
+  }
+  // per-amplicon results and per-swarm sums: independent gathers / scatters over `order`
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t a = r->order[k];
+    r->parent[a] = order_parent[k];
+    r->generation[a] = order_generation[k];
+  }
+  for (auto & sw : r->swarms) {
     for (uint32_t k = sw.begin; k < sw.end; ++k) {
       const uint32_t a = r->order[k];
       sw.mass += db->abundance[a];
       sw.sumlen += db->seqlen[a];
       if (db->abundance[a] == 1) { ++sw.singletons; }
     }
-    r->largest = std::max(r->largest, sw.size);
-    r->maxgen = std::max(r->maxgen, sw.maxgen);
-    r->swarms.push_back(std::move(sw));
   }
   r->swarmcount_adjusted = r->swarms.size();
   return SWA_OK;
