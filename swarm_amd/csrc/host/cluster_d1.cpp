@@ -16,6 +16,7 @@
 #include <cstring>
 #include <numeric>
 #include <omp.h>
+#include <parallel/algorithm>
 #include <string>
 #include <vector>
 
@@ -166,24 +167,24 @@ extern "C" void swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, ui
 
 // ---- grafting (src/algod1.cc:214-241 attach, 274-336 attach_candidates) -----------------
 extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand) {
-  struct Pair { uint32_t parent, child; };
-  std::vector<Pair> pairs;
+  // (parent << 32 | child): sorting the packed pairs is the (parent, child) order of
+  // src/algod1.cc:263-271, and a plain integer sort runs on all cores
+  std::vector<uint64_t> pairs;
   for (uint32_t i = 0; i < r->n; ++i) {
     r->graft_cand[i] = graft_cand[i];
-    if (graft_cand[i] != SWA_NO_AMPLICON) { pairs.push_back({graft_cand[i], i}); }
+    if (graft_cand[i] != SWA_NO_AMPLICON) { pairs.push_back(((uint64_t)graft_cand[i] << 32) | i); }
   }
-  std::sort(pairs.begin(), pairs.end(), [](const Pair & a, const Pair & b) {
-    return a.parent != b.parent ? a.parent < b.parent : a.child < b.child;
-  });
+  __gnu_parallel::sort(pairs.begin(), pairs.end());
   uint32_t grafts = 0;
-  for (const Pair & p : pairs) {
-    auto & light = r->swarms[r->swarmid[p.child]];
+  for (const uint64_t packed : pairs) {
+    const uint32_t parent = (uint32_t)(packed >> 32), child = (uint32_t)packed;
+    auto & light = r->swarms[r->swarmid[child]];
     if (light.attached) {
-      r->graft_cand[p.child] = SWA_NO_AMPLICON;     // this light swarm already hangs somewhere
+      r->graft_cand[child] = SWA_NO_AMPLICON;       // this light swarm already hangs somewhere
       continue;
     }
-    auto & heavy = r->swarms[r->swarmid[p.parent]];
-    heavy.grafted.push_back(r->swarmid[p.child]);
+    auto & heavy = r->swarms[r->swarmid[parent]];
+    heavy.grafted.push_back(r->swarmid[child]);
     heavy.size += light.size;
     heavy.singletons += light.singletons;
     heavy.mass += light.mass;
