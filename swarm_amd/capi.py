@@ -215,6 +215,12 @@ class D1Clusters:
     def swarmid(self) -> np.ndarray:
         return self._arr(self.lib.swa_d1_result_swarmid)
 
+    def parent(self) -> np.ndarray:
+        return self._arr(self.lib.swa_d1_result_parent)
+
+    def generation(self) -> np.ndarray:
+        return self._arr(self.lib.swa_d1_result_generation)
+
     def light_flags(self, boundary: int = 3):
         flags = np.zeros(self.hdb.n, dtype=np.uint8)
         stats = np.zeros(5, dtype=np.uint64)

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <omp.h>
@@ -51,6 +52,136 @@ void for_each_member(const swa_d1_result * r, const swa_d1_result::Swarm & s, F 
 
 }  // namespace
 
+// ---- the same clustering, computed without the serial walk --------------------------------
+// The greedy loop above is equivalent to three order-free statements (i -> j = "j is in i's
+// neighbour list"; ids are db order):
+//   swarm(v)      = seed(v) = the smallest id among v and everything that reaches v.
+//                   (That id m is a seed: anything claiming m earlier would reach v and be smaller.
+//                   When m's turn comes nothing on a path m -> ... -> v is taken, for the same
+//                   reason, so m's walk claims v.)
+//   generation(v) = the distance from seed(v) to v (every path from the seed to v stays inside
+//                   the swarm, again because a node taken earlier would make v's seed smaller).
+//   parent(v)     = the smallest id u with u -> v and generation(u) = generation(v) - 1 (a
+//                   generation is expanded in ascending id order and the first to reach v keeps it).
+// Members are listed by (generation, id), swarms by seed id.  Each statement is a data-parallel
+// fixed point / sweep over the CSR, which is what the many cores of a GPU host are for: used for
+// large inputs, and checked against the serial walk in tests/test_host_logic.py.
+namespace {
+
+inline void atomic_min_u32(uint32_t * addr, uint32_t value) {
+  uint32_t seen = __atomic_load_n(addr, __ATOMIC_RELAXED);
+  while (value < seen && !__atomic_compare_exchange_n(addr, &seen, value, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+
+void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
+                             swa_d1_result * r) {
+  const uint32_t n = db->n;
+  const int64_t n64 = (int64_t)n;
+  constexpr uint32_t kUnset = SWA_NO_AMPLICON;
+  // 1. seed(v): push the smaller label along every edge until nothing changes
+  std::vector<uint32_t> label(n);
+  std::vector<uint8_t> active(n, 1), next_active(n, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < n64; ++v) { label[(size_t)v] = (uint32_t)v; }
+  for (bool changed = true; changed;) {
+    changed = false;
+#pragma omp parallel for schedule(dynamic, 8192) reduction(|| : changed)
+    for (int64_t u = 0; u < n64; ++u) {
+      if (active[(size_t)u] == 0) { continue; }
+      active[(size_t)u] = 0;
+      const uint32_t lu = __atomic_load_n(&label[(size_t)u], __ATOMIC_RELAXED);
+      for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
+        const uint32_t v = neighbours[e];
+        if (lu < __atomic_load_n(&label[v], __ATOMIC_RELAXED)) {
+          atomic_min_u32(&label[v], lu);
+          __atomic_store_n(&next_active[v], (uint8_t)1, __ATOMIC_RELAXED);
+          changed = true;
+        }
+      }
+    }
+    active.swap(next_active);              // (next_active is all zero again: every visited flag was cleared)
+  }
+  // 2. generation(v): level-synchronous distances from the seeds inside their swarms;
+  //    parent(v): smallest id of the previous level that points at v
+  std::vector<uint32_t> & gen = r->generation;
+  std::vector<uint32_t> & parent = r->parent;
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < n64; ++v) { gen[(size_t)v] = label[(size_t)v] == (uint32_t)v ? 0u : kUnset; parent[(size_t)v] = kUnset; }
+  for (uint32_t level = 1;; ++level) {
+    bool grew = false;
+#pragma omp parallel for schedule(dynamic, 8192) reduction(|| : grew)
+    for (int64_t u = 0; u < n64; ++u) {
+      if (gen[(size_t)u] != level - 1) { continue; }
+      const uint32_t lu = label[(size_t)u];
+      for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
+        const uint32_t v = neighbours[e];
+        if (label[v] == lu && __atomic_load_n(&gen[v], __ATOMIC_RELAXED) == kUnset) {
+          __atomic_store_n(&gen[v], level, __ATOMIC_RELAXED);
+          grew = true;
+        }
+      }
+    }
+    if (!grew) { break; }
+#pragma omp parallel for schedule(dynamic, 8192)
+    for (int64_t u = 0; u < n64; ++u) {
+      if (gen[(size_t)u] != level - 1) { continue; }
+      const uint32_t lu = label[(size_t)u];
+      for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
+        const uint32_t v = neighbours[e];
+        if (label[v] == lu && gen[v] == level) { atomic_min_u32(&parent[v], (uint32_t)u); }
+      }
+    }
+  }
+  // 3. swarms in seed order, members by (generation, id)
+  std::vector<uint32_t> sid_of_seed(n, 0);
+  uint32_t nswarms = 0;
+  for (uint32_t v = 0; v < n; ++v) { if (label[v] == v) { sid_of_seed[v] = nswarms++; } }
+  r->swarms.resize(nswarms);
+  std::vector<uint32_t> size(nswarms, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < n64; ++v) {
+    const uint32_t sid = sid_of_seed[label[(size_t)v]];
+    r->swarmid[(size_t)v] = sid;
+    __atomic_fetch_add(&size[sid], 1u, __ATOMIC_RELAXED);
+  }
+  uint32_t at = 0;
+  for (uint32_t s = 0; s < nswarms; ++s) {
+    auto & sw = r->swarms[s];
+    sw.begin = at;
+    at += size[s];
+    sw.end = sw.begin;                      // filled below (used as the cursor)
+  }
+  r->order.resize(n);
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < n64; ++v) {
+    auto & sw = r->swarms[r->swarmid[(size_t)v]];
+    r->order[__atomic_fetch_add(&sw.end, 1u, __ATOMIC_RELAXED)] = (uint32_t)v;
+  }
+  uint32_t largest = 0, maxgen = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(max : largest) reduction(max : maxgen)
+  for (int64_t s = 0; s < (int64_t)nswarms; ++s) {
+    auto & sw = r->swarms[(size_t)s];
+    std::sort(r->order.begin() + sw.begin, r->order.begin() + sw.end, [&](uint32_t x, uint32_t y) {
+      return gen[x] != gen[y] ? gen[x] < gen[y] : x < y;
+    });
+    sw.seed = r->order[sw.begin];
+    sw.size = sw.end - sw.begin;
+    for (uint32_t k = sw.begin; k < sw.end; ++k) {
+      const uint32_t a = r->order[k];
+      sw.mass += db->abundance[a];
+      sw.sumlen += db->seqlen[a];
+      if (db->abundance[a] == 1) { ++sw.singletons; }
+      sw.maxgen = std::max(sw.maxgen, gen[a]);
+    }
+    largest = std::max(largest, sw.size);
+    maxgen = std::max(maxgen, sw.maxgen);
+  }
+  r->largest = largest;
+  r->maxgen = maxgen;
+}
+
+}  // namespace
+
 // ---- clustering (src/algod1.cc:1185-1280, process_seed 673-718) ------------------------
 extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
                               swa_d1_result ** out) {
@@ -63,6 +194,18 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
   r->parent.assign(n, SWA_NO_AMPLICON);
   r->generation.assign(n, 0);
   r->graft_cand.assign(n, SWA_NO_AMPLICON);
+  // large inputs on a many-core host: the order-free formulation (SWARM_AMD_CLUSTER=serial|parallel
+  // overrides the choice)
+  {
+    const char * mode = std::getenv("SWARM_AMD_CLUSTER");
+    const bool force_parallel = mode != nullptr && std::strcmp(mode, "parallel") == 0;
+    const bool force_serial = mode != nullptr && std::strcmp(mode, "serial") == 0;
+    if (force_parallel || (!force_serial && n >= 500000 && omp_get_max_threads() >= 8)) {
+      cluster_by_fixed_points(db, offsets, neighbours, r);
+      r->swarmcount_adjusted = r->swarms.size();
+      return SWA_OK;
+    }
+  }
   r->order.reserve(n);
   // The walk is a chain of dependent random reads (row of s -> ids -> swarmid of each id), so the
   // loop touches as little as possible per amplicon: the visited test reads swarmid[] only,

@@ -178,3 +178,66 @@ def test_parallel_swarm_writer_equals_serial(tmp_path):
     assert outs[0].stat().st_size > 2_000_000
     assert filecmp.cmp(outs[0], outs[1], shallow=False)
     assert filecmp.cmp(str(outs[0]) + ".r", str(outs[1]) + ".r", shallow=False)
+
+
+def _cluster_both_ways(hdb, off, nb, tmp_path):
+    out = {}
+    for mode in ("serial", "parallel"):
+        os.environ["SWARM_AMD_CLUSTER"] = mode
+        try:
+            cl = D1Clusters(hdb, off, nb)
+        finally:
+            os.environ.pop("SWARM_AMD_CLUSTER", None)
+        cl.write_swarms(tmp_path / f"o_{mode}")
+        cl.write_stats(tmp_path / f"s_{mode}")
+        cl.write_structure(tmp_path / f"i_{mode}")
+        out[mode] = (cl.swarmid().copy(), cl.parent().copy(), cl.generation().copy(), cl.summary())
+    a, b = out["serial"], out["parallel"]
+    assert np.array_equal(a[0], b[0]), "swarm ids differ"
+    assert np.array_equal(a[2], b[2]), "generations differ"
+    assert np.array_equal(a[1], b[1]), "parents differ"
+    assert a[3] == b[3]
+    for k in "osi":
+        assert filecmp.cmp(tmp_path / f"{k}_serial", tmp_path / f"{k}_parallel", shallow=False), k
+
+
+@pytest.mark.parametrize("name", ["d1_1k", "d1_nobreak", "d1_short", "d1_fastidious"])
+def test_order_free_clustering_equals_the_walk_on_fixtures(tmp_path, name):
+    """The data-parallel formulation of the d=1 clustering (smallest reaching id, distance, smallest
+    previous-level pointer) against the serial walk, on the oracle's networks of the fixtures."""
+    fa = G / f"{name}.fasta"
+    hdb = HostDb(fa)
+    db = S.db_from_fasta(fa)
+    ncb = "-n" in (G / f"{name}.args").read_text().split()
+    off, nb, _ = S.oracle_d1_network(db, ncb)
+    _cluster_both_ways(hdb, off, nb, tmp_path)
+
+
+@pytest.mark.parametrize("seed,n,avg_deg,symmetric", [(1, 3000, 1.5, False), (2, 3000, 3.0, True), (3, 20000, 0.7, False),
+                                                      (4, 5000, 6.0, False), (5, 400, 2.0, True)])
+def test_order_free_clustering_equals_the_walk_on_random_graphs(tmp_path, seed, n, avg_deg, symmetric):
+    """Any CSR is a valid input for the host clustering: random digraphs (with the abundance-rule
+    shape: edges point to larger ids) and symmetric ones (the -n shape), long chains included."""
+    rng = np.random.default_rng(seed)
+    fa = tmp_path / "g.fa"
+    S.gen_fasta(fa, n, 30, 100 + seed)
+    hdb = HostDb(fa)
+    n = hdb.n
+    m = int(avg_deg * n)
+    src = rng.integers(0, n, size=m)
+    dst = np.clip(src + rng.integers(1, 40, size=m), 0, n - 1)          # local edges: long generation chains
+    far = rng.random(m) < 0.1
+    dst[far] = rng.integers(0, n, size=int(far.sum()))
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    if symmetric:
+        src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
+    else:
+        lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+        src, dst = lo, hi
+    pairs = np.unique(np.stack([src, dst], axis=1), axis=0)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.add.at(off, pairs[:, 0] + 1, 1)
+    off = np.cumsum(off).astype(np.uint64)
+    nb = pairs[:, 1].astype(np.uint32)
+    _cluster_both_ways(hdb, off, nb, tmp_path)
