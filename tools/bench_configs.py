@@ -54,6 +54,15 @@ def reference(fa, args, threads):
     return {"seconds": round(time.perf_counter() - t0, 2), "threads": threads, "out": str(out)}
 
 
+def dn_rates(scan, seconds, length):
+    """q-gram comparisons/s, aligned pairs/s and full-matrix-equivalent DP cells/s (the reference
+    fills Lq x Lt cells per pair, src/search8.cc; the wavefront / banded kernels touch far fewer)."""
+    return {"qgram_comparisons_per_s": scan["qgram_comparisons"] / seconds,
+            "aligned_pairs_per_s": scan["aligned_pairs"] / seconds,
+            "full_matrix_equivalent_cells_per_s": scan["aligned_pairs"] * length * length / seconds,
+            "over": "dn_cluster_gpu_scan (host greedy loop + all launches), nominal length squared per pair"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("mode", choices=["d1", "dn"])
@@ -108,6 +117,8 @@ def main():
         res["summary"] = cl.summary()
         refargs = ["-d", str(args.d)]
     res["seconds"] = T.t
+    if "scan" in res:                                      # the three d>=2 rates, over the clustering phase
+        res["rates"] = dn_rates(res["scan"], T.t["dn_cluster_gpu_scan"], args.length)
     res["total_seconds_without_generate"] = round(sum(v for k, v in T.t.items() if k != "generate"), 3)
     if args.reference:
         r = reference(fa, refargs, args.threads)
