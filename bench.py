@@ -139,7 +139,7 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
                 "sample": f"oracle/ C restatement, index build + network only, {sample_n} x {length} bp, {dt:.2f} s"}
 
 
-def extra_measurement(torch, dev, local_rank: int, args, n: int, steps: int) -> dict:
+def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int) -> dict:
     """The bench step (index build + network, db and CSR resident) on n x length amplicons."""
     from swarm_amd import Context, HostDb
     hdb = HostDb(gen_fasta(n, args.length, args.seed))
@@ -149,7 +149,7 @@ def extra_measurement(torch, dev, local_rank: int, args, n: int, steps: int) -> 
 
     t_seqs = to_dev(np.concatenate([hdb.seqs, np.zeros(2, dtype=np.uint64)]), np.int64)
     t_off, t_len, t_ab = to_dev(hdb.seq_off, np.int64), to_dev(hdb.seqlen, np.int32), to_dev(hdb.abundance, np.int64)
-    ctx = Context(local_rank, torch.cuda.current_stream(dev).cuda_stream)
+    ctx = Context(device_index, torch.cuda.current_stream(dev).cuda_stream)
     ctx.attach_db(t_seqs, t_off, t_len, t_ab, hdb.longest)
     ctx.timing_enable(True)
     cap = 8 * hdb.n
@@ -188,6 +188,9 @@ def main() -> None:
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="development aid: run rank 0's share of an N-GPU job on this one GPU (no collectives); "
                          "the JSON line is marked simulated and is not a result")
+    ap.add_argument("--dev-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="development aid: 'gloo' runs the N>1 flow with every rank on GPU 0 (collectives staged "
+                         "through the host), to exercise the sharded step on a one-GPU box; marked simulated")
     args = ap.parse_args()
 
     import torch
@@ -198,10 +201,15 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    one_gpu = world > 1 and args.dev_backend == "gloo"
+    device_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from swarm_amd import Context, HostDb, sharding
 
@@ -225,7 +233,7 @@ def main() -> None:
     t_len = to_dev(hdb.seqlen, np.int32)
     t_ab = to_dev(hdb.abundance, np.int64)
     stream = torch.cuda.current_stream(dev)
-    ctx = Context(local_rank, stream.cuda_stream)
+    ctx = Context(device_index, stream.cuda_stream)
     ctx.attach_db(t_seqs, t_off, t_len, t_ab, hdb.longest)
     ctx.timing_enable(True)
 
@@ -237,6 +245,7 @@ def main() -> None:
 
     kernel_ms = []
     hits_seen = [0]
+    gathered = [None]
 
     dup_flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -253,7 +262,7 @@ def main() -> None:
         if world > 1:
             # exchange step named by the north star: all-gather hit counts, then row offsets and
             # hit lists padded to the largest slice, so every rank holds the whole CSR
-            sharding.allgather_csr(d_offsets, d_nb, total, [c for _, c in parts])
+            gathered[0] = sharding.allgather_csr(d_offsets, d_nb, total, [c for _, c in parts])
         if record:
             kernel_ms.append(ctx.timing_read()[3])
 
@@ -275,6 +284,17 @@ def main() -> None:
         elapsed = float(t.item())
 
     timings = ctx.timing_read()
+    sharded_ok = None
+    if one_gpu and rank == 0:
+        # development aid only: the gathered CSR against the whole network computed by this rank alone
+        g_off, g_nb = gathered[0]
+        w_off = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
+        w_nb = torch.zeros(8 * n_total, dtype=torch.int32, device=dev)
+        assert not ctx.d1_index_build()
+        w_total = ctx.d1_network_device(w_off, w_nb, 8 * n_total, False, 0, n_total)
+        sharded_ok = bool(w_total == g_nb.numel() and torch.equal(w_off, g_off) and torch.equal(w_nb[:w_total], g_nb))
+    if one_gpu:
+        dist.barrier()
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = n_total * args.steps / elapsed
@@ -321,7 +341,10 @@ def main() -> None:
         }
         if world == 1 and not sim_world and not args.no_configs1 and not args.no_cpu_baseline:
             # BASELINE.json configs[1] (1 M x 150, d=1): the same step at that size, same run
-            out["config"]["configs1"] = extra_measurement(torch, dev, local_rank, args, 1_000_000, 10)
+            out["config"]["configs1"] = extra_measurement(torch, dev, device_index, args, 1_000_000, 10)
+        if one_gpu:
+            out["simulated"] = f"{world} ranks sharing GPU 0 over gloo: exercises the sharded step, not a result"
+            out["sharded_csr_equals_whole"] = sharded_ok
         if sim_world:
             out["simulated"] = f"rank 0 of {sim_world}, no collectives: value counts all {n_total} amplicons as if every rank finished in this time"
         if world == 1 and not sim_world and not args.no_cpu_baseline:
