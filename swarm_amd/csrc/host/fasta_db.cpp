@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -359,7 +360,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   if (n64 > 0xFFFFFFFEull) { db->error = "\nError: too many sequences.\n"; return SWA_E_ARG; }
   const uint32_t n = (uint32_t)n64;
   db->n = n;
-  std::vector<const RawEntry *> ent(n);
+  swa_vec<const RawEntry *> ent(n);
   run_parallel(threads, [&](unsigned t) {
     uint64_t k = piece_first[t];
     for (const auto & e : pieces[t].entries) { ent[k++] = &e; }
@@ -376,7 +377,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
   {
     const uint64_t tsize = n ? 2ull * n : 1;
-    std::vector<std::atomic<uint32_t>> idtab(tsize);
+    std::unique_ptr<std::atomic<uint32_t>[]> idtab(new std::atomic<uint32_t>[tsize]);   // filled in parallel below
     run_parallel(threads, [&](unsigned t) {
       for (uint64_t i = tsize * t / threads; i < tsize * (t + 1) / threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
     });
@@ -422,8 +423,10 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   // them while building the amplicon table (algod1.cc:1131-1150 / swa_d1_index_build)
   if (check_dup_seqs && n > 1) {
     const uint64_t tsize = 2ull * n;
-    std::vector<std::atomic<uint32_t>> tab(tsize);
-    for (auto & a : tab) { a.store(0xFFFFFFFFu, std::memory_order_relaxed); }
+    std::unique_ptr<std::atomic<uint32_t>[]> tab(new std::atomic<uint32_t>[tsize]);
+    run_parallel(threads, [&](unsigned t) {
+      for (uint64_t i = tsize * t / threads; i < tsize * (t + 1) / threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
+    });
     std::atomic<bool> dup{false};
     run_parallel(threads, [&](unsigned t) {
       for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads && !dup.load(std::memory_order_relaxed); ++i) {
@@ -479,21 +482,34 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   // ---- db order: abundance descending, then header (strcmp) ascending — db.cc:388-413.
   // Parallel merge sort; the 8-byte big-endian header prefix decides most ties without
   // touching the header text (equal prefixes fall through to strcmp: same order).
-  std::vector<uint32_t> order(n);
-  std::iota(order.begin(), order.end(), 0u);
-  auto less = [&](uint32_t a, uint32_t b) {
-    const RawEntry * x = ent[a];
-    const RawEntry * y = ent[b];
-    if (x->abundance != y->abundance) { return x->abundance > y->abundance; }
-    if (x->key8 != y->key8) { return x->key8 < y->key8; }
-    return std::strcmp(hdr_of(x), hdr_of(y)) < 0;
+  // The sort moves compact records (the keys travel with the index, no pointer chasing);
+  // inputs that are already in db order (swarm's own -w output, vsearch output) skip it.
+  struct SortRec { uint64_t abundance, key8; uint32_t entry; };
+  swa_vec<SortRec> recs(n);
+  run_parallel(threads, [&](unsigned t) {
+    for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads; ++i) {
+      recs[i] = SortRec{ent[i]->abundance, ent[i]->key8, (uint32_t)i};
+    }
+  });
+  auto less = [&](const SortRec & a, const SortRec & b) {
+    if (a.abundance != b.abundance) { return a.abundance > b.abundance; }
+    if (a.key8 != b.key8) { return a.key8 < b.key8; }
+    return std::strcmp(hdr_of(ent[a.entry]), hdr_of(ent[b.entry])) < 0;
   };
-  if (!std::is_sorted(order.begin(), order.end(), less)) {
+  std::atomic<bool> sorted{true};
+  run_parallel(threads, [&](unsigned t) {
+    const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
+    for (uint64_t i = std::max<uint64_t>(lo, 1); i < hi && sorted.load(std::memory_order_relaxed); ++i) {
+      if (less(recs[i], recs[i - 1])) { sorted.store(false, std::memory_order_relaxed); }
+    }
+  });
+  if (!sorted.load()) {
     // libstdc++ parallel mode: multiway merge sort over the host cores (OpenMP); the order is a
     // strict total order (identifiers are unique), so the result equals std::sort's
     omp_set_num_threads((int)threads);
-    __gnu_parallel::sort(order.begin(), order.end(), less);
+    __gnu_parallel::sort(recs.begin(), recs.end(), less);
   }
+  auto order = [&](uint64_t k) { return recs[k].entry; };
   timer.lap("sort");
   // ---- contiguous SoA in sorted order (offsets by prefix sum, copies in parallel)
   db->seq_off.resize((size_t)n + 1);
@@ -509,7 +525,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     run_parallel(threads, [&](unsigned t) {
       uint64_t w = 0, h = 0;
       for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
-        const RawEntry * e = ent[order[k]];
+        const RawEntry * e = ent[order(k)];
         w += (e->seqlen + 31u) >> 5;
         h += (uint64_t)e->hdr_len + 1;
       }
@@ -519,7 +535,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     run_parallel(threads, [&](unsigned t) {
       uint64_t w = wsum[t], h = hsum[t];
       for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
-        const RawEntry * e = ent[order[k]];
+        const RawEntry * e = ent[order(k)];
         db->seq_off[k] = w;
         db->hdr_off[k] = h;
         w += (e->seqlen + 31u) >> 5;
@@ -535,7 +551,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   db->headers.resize(hoff + 1);
   run_parallel(threads, [&](unsigned t) {
     for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
-      const RawEntry * e = ent[order[k]];
+      const RawEntry * e = ent[order(k)];
       std::memcpy(&db->seqs[db->seq_off[k]], words_of(e), ((e->seqlen + 31u) >> 5) * 8ull);
       std::memcpy(&db->headers[db->hdr_off[k]], hdr_of(e), (size_t)e->hdr_len + 1);
       db->seqlen[k] = e->seqlen;
@@ -546,6 +562,9 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   });
   db->seqs[woff] = 0;
   timer.lap("gather into db order");
+  run_parallel(threads, [&](unsigned t) { Piece().entries.swap(pieces[t].entries); std::vector<char>().swap(pieces[t].hdr_pool);
+                                          std::vector<uint64_t>().swap(pieces[t].words); });
+  timer.lap("release parse buffers");
   return SWA_OK;
 }
 
