@@ -562,9 +562,18 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   });
   db->seqs[woff] = 0;
   timer.lap("gather into db order");
-  run_parallel(threads, [&](unsigned t) { Piece().entries.swap(pieces[t].entries); std::vector<char>().swap(pieces[t].hdr_pool);
-                                          std::vector<uint64_t>().swap(pieces[t].words); });
-  timer.lap("release parse buffers");
+  // The parse buffers, the sort records and the input mapping (≈ 3 GB at 10 M amplicons) are torn
+  // down by a detached thread: returning them to the kernel took as long as the sort.
+  struct Leftovers {
+    std::vector<Piece> pieces; swa_vec<const RawEntry *> ent; swa_vec<SortRec> recs; const char * data; size_t size; bool mapped;
+  };
+  auto * rest = new Leftovers{std::move(pieces), std::move(ent), std::move(recs), in.data, in.size, in.mapped};
+  in.mapped = false;                                         // the thread below unmaps
+  std::thread([rest] {
+    if (rest->mapped) { ::munmap(const_cast<char *>(rest->data), rest->size); }
+    delete rest;
+  }).detach();
+  timer.lap("hand-off of parse buffers");
   return SWA_OK;
 }
 
