@@ -9,17 +9,17 @@
 //     consecutive sequence positions [l*K, (l+1)*K).  The reference's serially
 //     incremental deletion / insertion hashes become three wave-wide XOR scans
 //     (exclusive prefix of Z[p][s_p], suffixes of Z[p-1][s_p] and Z[p+1][s_p]);
-//   * the 2-bit packed query, the Zobrist table and the 1024 Bloom patterns live in LDS;
-//   * every lane issues its Bloom-word loads 8 at a time (one position's substitutions,
-//     deletion and insertions) so a wave keeps up to 512 independent 8-byte HBM/L2
-//     reads in flight;
-//   * Bloom survivors (~2 % of the variants) are compacted with __ballot/__popcll into a
-//     per-wave LDS queue and drained 64 at a time, so the divergent part (table probe,
-//     abundance rule, exact verification) runs with full lanes;
+//   * default route (d1_anchor.inc): amplicons grouped by their first / last 32 nucleotides,
+//     a group's members in an LDS table + LDS Bloom, every probe answered from LDS;
+//   * plain route (k_d1_probe, this file: statistics, sequences the anchored passes cannot
+//     serve, the fastidious second level): the 2-bit packed query, the Zobrist table and the
+//     1024 Bloom patterns in LDS, Bloom-word loads issued 8 at a time per lane, survivors
+//     compacted with __ballot/__popcll into a per-wave LDS queue and drained 64 at a time so
+//     that table walk, abundance rule and exact verification run with full lanes;
 //   * the hash table is one 16-byte slot per entry (hash, amplicon id): one transaction
 //     per probe step instead of the reference's three arrays;
-//   * hits leave the wave as (source, target) edges through one atomicAdd per drain;
-//     a scan + scatter + per-row sort turns the edge list into the canonical CSR.
+//   * hits leave a wave through its own segment of the edge buffer (one writer per segment,
+//     no atomics); a scan + scatter + per-row sort turns the segments into the canonical CSR.
 //
 // All arithmetic is 64-bit integer XOR/shift/compare; results are bit-exact.
 #include "swa_internal.h"
