@@ -388,10 +388,24 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     };
     std::atomic<uint32_t> dup_entry{0xFFFFFFFFu};
     run_parallel(threads, [&](unsigned t) {
-      for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads; ++i) {
+      // entries and headers stream in file order; the table slot is the one random access per
+      // amplicon, so the slots of the next few identifiers are requested ahead of their turn
+      constexpr uint64_t kAhead = 8;
+      const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
+      uint64_t ring[kAhead];
+      auto slot_of = [&](uint64_t i) {
         const char * ids; uint32_t idl;
         id_span(ent[i], ids, idl);
-        uint64_t slot = bytes_hash(ids, idl) % tsize;
+        const uint64_t slot = bytes_hash(ids, idl) % tsize;
+        __builtin_prefetch(&idtab[slot], 1);
+        return slot;
+      };
+      for (uint64_t i = lo; i < std::min(hi, lo + kAhead); ++i) { ring[i % kAhead] = slot_of(i); }
+      for (uint64_t i = lo; i < hi; ++i) {
+        const char * ids; uint32_t idl;
+        id_span(ent[i], ids, idl);
+        uint64_t slot = ring[i % kAhead];
+        if (i + kAhead < hi) { ring[i % kAhead] = slot_of(i + kAhead); }
         for (;;) {
           uint32_t cur = idtab[slot].load(std::memory_order_acquire);
           if (cur == 0xFFFFFFFFu) {
@@ -484,11 +498,11 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   // touching the header text (equal prefixes fall through to strcmp: same order).
   // The sort moves compact records (the keys travel with the index, no pointer chasing);
   // inputs that are already in db order (swarm's own -w output, vsearch output) skip it.
-  struct SortRec { uint64_t abundance, key8; uint32_t entry; };
+  struct SortRec { uint64_t abundance, key8; uint32_t entry, words, hdr_bytes; };   // + what the offsets need
   swa_vec<SortRec> recs(n);
   run_parallel(threads, [&](unsigned t) {
     for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads; ++i) {
-      recs[i] = SortRec{ent[i]->abundance, ent[i]->key8, (uint32_t)i};
+      recs[i] = SortRec{ent[i]->abundance, ent[i]->key8, (uint32_t)i, (ent[i]->seqlen + 31u) >> 5, ent[i]->hdr_len + 1u};
     }
   });
   auto less = [&](const SortRec & a, const SortRec & b) {
@@ -524,22 +538,17 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     std::vector<uint64_t> wsum(threads + 1, 0), hsum(threads + 1, 0);
     run_parallel(threads, [&](unsigned t) {
       uint64_t w = 0, h = 0;
-      for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
-        const RawEntry * e = ent[order(k)];
-        w += (e->seqlen + 31u) >> 5;
-        h += (uint64_t)e->hdr_len + 1;
-      }
+      for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) { w += recs[k].words; h += recs[k].hdr_bytes; }
       wsum[t + 1] = w; hsum[t + 1] = h;
     });
     for (unsigned t = 0; t < threads; ++t) { wsum[t + 1] += wsum[t]; hsum[t + 1] += hsum[t]; }
     run_parallel(threads, [&](unsigned t) {
       uint64_t w = wsum[t], h = hsum[t];
       for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
-        const RawEntry * e = ent[order(k)];
         db->seq_off[k] = w;
         db->hdr_off[k] = h;
-        w += (e->seqlen + 31u) >> 5;
-        h += (uint64_t)e->hdr_len + 1;
+        w += recs[k].words;
+        h += recs[k].hdr_bytes;
       }
     });
     woff = wsum[threads];
@@ -550,7 +559,17 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   db->seqs.resize(woff + 1);
   db->headers.resize(hoff + 1);
   run_parallel(threads, [&](unsigned t) {
-    for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
+    // the entries, their words and their headers are three random reads per amplicon: keep a
+    // few of them in flight
+    const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
+    constexpr uint64_t kAheadEntry = 16, kAheadData = 8;
+    for (uint64_t k = lo; k < hi; ++k) {
+      if (k + kAheadEntry < hi) { __builtin_prefetch(ent[order(k + kAheadEntry)]); }
+      if (k + kAheadData < hi) {
+        const RawEntry * f = ent[order(k + kAheadData)];
+        __builtin_prefetch(words_of(f));
+        __builtin_prefetch(hdr_of(f));
+      }
       const RawEntry * e = ent[order(k)];
       std::memcpy(&db->seqs[db->seq_off[k]], words_of(e), ((e->seqlen + 31u) >> 5) * 8ull);
       std::memcpy(&db->headers[db->hdr_off[k]], hdr_of(e), (size_t)e->hdr_len + 1);
