@@ -117,6 +117,38 @@ def test_full_size_1m_properties(gpu_ctx, tmp_path):
         assert np.array_equal(nb2[lo:hi], wnb)
 
 
+def test_bench_size_10m_properties(gpu_ctx):
+    """The bench workload itself (10 M x 150, d=1: the size BASELINE.json's metric names), same
+    generator call as bench.py: the same size-independent properties as the 1 M test, plus sampled
+    row ranges against the oracle.  The database comes from the product's own reader here (the
+    independent Python packer needs minutes at this size; the reader is checked against it on the
+    fixtures in test_host_logic.py)."""
+    import bench
+    from swarm_amd import HostDb
+    hdb = HostDb(bench.gen_fasta(10_000_000, 150, 1))
+    db = S.Db(headers=[], seqs=hdb.seqs, seq_off=hdb.seq_off, seqlen=hdb.seqlen, abundance=hdb.abundance,
+              longest=hdb.longest)
+    _upload(gpu_ctx, db)
+    assert gpu_ctx.d1_index_build() is False
+    off, nb = gpu_ctx.d1_network(True)
+    rows = np.repeat(np.arange(db.n, dtype=np.uint64), np.diff(off).astype(np.int64))
+    fwd = (rows << np.uint64(32)) | nb.astype(np.uint64)
+    assert (np.diff(fwd) > 0).all()           # rows ascending, unique, in row order
+    assert (rows != nb).all()
+    rev = np.sort((nb.astype(np.uint64) << np.uint64(32)) | rows)
+    assert np.array_equal(fwd, rev)           # symmetric without the abundance rule
+    del rev
+    off2, nb2 = gpu_ctx.d1_network(False)
+    keep = db.abundance[rows.astype(np.int64)] >= db.abundance[nb.astype(np.int64)]
+    rows2 = np.repeat(np.arange(db.n, dtype=np.uint64), np.diff(off2).astype(np.int64))
+    assert np.array_equal(fwd[keep], (rows2 << np.uint64(32)) | nb2.astype(np.uint64))
+    rng = np.random.default_rng(5)
+    for first in rng.integers(0, db.n - 1000, size=3):
+        woff, wnb, _ = _oracle_sorted_rows(db, False, int(first), 1000)
+        lo, hi = int(off2[first]), int(off2[first + 1000])
+        assert np.array_equal(nb2[lo:hi], wnb)
+
+
 def _check_vs_oracle(ctx, db, ncb=False):
     _upload(ctx, db)
     assert ctx.d1_index_build() is False
