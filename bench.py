@@ -5,14 +5,17 @@ One "step" = one full pass of the hot path over the synthetic amplicon set, thro
 C ABI, with the packed database already resident in HBM and the CSR left in HBM:
     swa_d1_index_build   (sequence hashes, amplicon hash table, Bloom filter, duplicate check)
     swa_d1_network_device (microvariant hashes -> Bloom -> table probe -> verify -> CSR)
-and, for N > 1, a MAX all-reduce of the per-rank duplicate flags and the RCCL all-gather of the
-per-rank CSR slices (hit counts, then padded hit lists) over xGMI.
+and, for N > 1, a MAX all-reduce of the per-rank duplicate flags, the all-to-all merge of the
+ranks' partial rows and the RCCL all-gather of the per-rank CSR slices over xGMI.
 
 Workload at N = 1: the size BASELINE.json's metric string names — 10 M synthetic amplicons x
 150 bp, d = 1 (configs[1], 1 M x 150, is measured in the same run and reported under
 config.configs1).  For N > 1 the job is weak-scaled: the database holds N x 10 M amplicons
-(N = 8: 80 M, the order of configs[4]), replicated on every GPU (table + Bloom built per GPU),
-and rank r answers the queries of its contiguous 10 M slice.
+(N = 8: 80 M, the order of configs[4]), replicated on every GPU.  Default sharding ("owned"):
+rank r serves the anchor groups whose key maps to r — with all their members, so the per-group
+LDS tables are built once per job, not once per rank —, which leaves it partial rows over all
+amplicons; the rows travel all-to-all by seed range, are merged, and the slices are
+all-gathered.  `--shard range` is the older scheme (rank r answers its contiguous slice).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline"     — algorithmic bytes of the dominant kernel group (the d=1 network: the anchored
@@ -188,6 +191,10 @@ def main() -> None:
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="development aid: run rank 0's share of an N-GPU job on this one GPU (no collectives); "
                          "the JSON line is marked simulated and is not a result")
+    ap.add_argument("--shard", default="owned", choices=["owned", "range"],
+                    help="N > 1: 'owned' = every rank serves the anchor groups it owns (swa_d1_set_ownership) and the "
+                         "partial rows are merged all-to-all; 'range' = every rank answers its contiguous query slice "
+                         "against structures indexed for that slice")
     ap.add_argument("--dev-backend", default="nccl", choices=["nccl", "gloo"],
                     help="development aid: 'gloo' runs the N>1 flow with every rank on GPU 0 (collectives staged "
                          "through the host), to exercise the sharded step on a one-GPU box; marked simulated")
@@ -239,8 +246,16 @@ def main() -> None:
 
     parts = sharding.partition_even(n_total, sim_world or world)
     first, count = parts[rank]
+    counts = [c for _, c in parts]
+    owned = (sim_world or world) > 1 and args.shard == "owned"
+    if owned:
+        # this rank finds the links inside the anchor groups it owns: partial rows over ALL amplicons
+        ctx.d1_set_ownership(rank, sim_world or world)
+        q_first, q_count = 0, n_total
+    else:
+        q_first, q_count = first, count
     cap = 8 * count
-    d_offsets = torch.zeros(count + 1, dtype=torch.int64, device=dev)
+    d_offsets = torch.zeros(q_count + 1, dtype=torch.int64, device=dev)
     d_nb = torch.zeros(cap, dtype=torch.int32, device=dev)
 
     kernel_ms = []
@@ -257,12 +272,17 @@ def main() -> None:
             dist.all_reduce(dup_flag, op=dist.ReduceOp.MAX)
             dup = bool(dup_flag.item())
         assert not dup
-        total = ctx.d1_network_device(d_offsets, d_nb, cap, False, first, count)
+        total = ctx.d1_network_device(d_offsets, d_nb, cap, False, q_first, q_count)
         hits_seen[0] = total
         if world > 1:
+            if owned:
+                # partial rows travel all-to-all by seed range and are merged into this rank's slice
+                l_off, l_nb = sharding.exchange_owned_csr(d_offsets, d_nb, counts)
+            else:
+                l_off, l_nb = d_offsets, d_nb[:total]
             # exchange step named by the north star: all-gather hit counts, then row offsets and
             # hit lists padded to the largest slice, so every rank holds the whole CSR
-            gathered[0] = sharding.allgather_csr(d_offsets, d_nb, total, [c for _, c in parts])
+            gathered[0] = sharding.allgather_csr(l_off, l_nb, int(l_nb.numel()), counts)
         if record:
             kernel_ms.append(ctx.timing_read()[3])
 
@@ -290,6 +310,7 @@ def main() -> None:
         g_off, g_nb = gathered[0]
         w_off = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
         w_nb = torch.zeros(8 * n_total, dtype=torch.int32, device=dev)
+        ctx.d1_set_ownership(0, 1)
         assert not ctx.d1_index_build()
         w_total = ctx.d1_network_device(w_off, w_nb, 8 * n_total, False, 0, n_total)
         sharded_ok = bool(w_total == g_nb.numel() and torch.equal(w_off, g_off) and torch.equal(w_nb[:w_total], g_nb))
@@ -299,7 +320,10 @@ def main() -> None:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = n_total * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
-        abytes = algorithmic_bytes(hdb.seqlen[first:first + count], hits_seen[0])
+        if owned:   # this rank's share of the probes: the groups it owns, about 1 / world of everything
+            abytes = algorithmic_bytes(hdb.seqlen, 0) / (sim_world or world) + 4.0 * hits_seen[0]
+        else:
+            abytes = algorithmic_bytes(hdb.seqlen[first:first + count], hits_seen[0])
         achieved = abytes / (k_ms * 1e-3) / 1e9
         traffic = None
         pmc = ROOT / "profiles" / "d1_network_pmc.json"
@@ -329,7 +353,9 @@ def main() -> None:
                 "per_gpu_queries": count,
                 "db_amplicons": n_total,
                 "step": "swa_d1_index_build + swa_d1_network_device (B1 seam), db and CSR resident in HBM"
-                        + ("; RCCL all-gather of CSR slices" if world > 1 else ""),
+                        + ("; ownership by anchor group, partial rows merged all-to-all, RCCL all-gather of CSR slices"
+                           if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else ""),
+                "sharding": ("owned" if owned else "range") if (sim_world or world) > 1 else "none",
                 "neighbour_links": int(hits_seen[0]),
                 "phase_ms": {"seqhash": timings[0], "table_bloom_build": timings[1], "dup_check": timings[2],
                              "anchor_index_build": timings[7], "network_kernels": k_ms, "csr": timings[4]},

@@ -105,6 +105,16 @@ int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates);
    that gives every rank its slice and ORs the flags detects every duplicate exactly once more
    cheaply than every rank checking everything.  Returns SWA_E_DUPLICATES like the above. */
 int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates);
+/* Multi-GPU by ownership (no reference counterpart: src/algod1.cc:641-669 splits the seeds over
+   threads that share one table).  With world > 1 this context serves only its share of the
+   probes: the anchor groups (amplicons sharing their first / last 32 nucleotides) whose key maps
+   to `rank` — with ALL their members, so the groups' LDS tables are built once per job instead
+   of once per rank —, its share of the seeds only the plain kernel can serve, and, when the
+   anchored route is not in use, the seeds with id mod world == rank.  swa_d1_network[_device]
+   over a range then returns the PARTIAL rows of that range; over all ranks every link of the
+   network appears exactly once (the host merges the partial rows: swarm_amd/sharding.py).
+   world = 1 restores the complete network.  Takes effect at the next network call. */
+int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world);
 
 /* Neighbour lists of amplicons [first, first+count) as CSR: offsets[count+1],
    neighbours[offsets[count]]; row k = { j != first+k : seq_j is a microvariant of

@@ -37,7 +37,7 @@ class DbView(C.Structure):
 
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize",
-    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_network", "swa_d1_network_device",
+    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_network", "swa_d1_network_device",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
@@ -331,6 +331,14 @@ class Context:
         self.lib.swa_d1_index_build_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
         self._check(self.lib.swa_d1_index_build_range(self.h, first, count, C.byref(dup)), allow=(SWA_E_DUPLICATES,))
         return bool(dup.value)
+
+    def d1_set_ownership(self, rank: int = 0, world: int = 1) -> None:
+        """Multi-GPU by ownership: from the next network call on this context finds only its share of
+        the links (the anchor groups whose key maps to `rank`, its share of the plain-kernel seeds),
+        so a network call returns PARTIAL rows; sharding.exchange_owned_csr merges the ranks' rows.
+        world = 1 restores the complete network."""
+        self.lib.swa_d1_set_ownership.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        self._check(self.lib.swa_d1_set_ownership(self.h, rank, world))
 
     def d1_network(self, no_cluster_breaking: bool = False, first: int = 0, count: int | None = None):
         """CSR over [first, first+count): (offsets u64[count+1], neighbours u32[total]), rows ascending."""

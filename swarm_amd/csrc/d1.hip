@@ -66,6 +66,8 @@ struct NetArgs {
   const struct swa_fallback * fallback;
   const uint32_t * fallback_count;
   const struct swa_aux * aux;
+  // MODE 0 in a multi-GPU job (swa_d1_set_ownership, world > 1): only seeds with id mod world == rank
+  uint32_t owner_rank, owner_world;
   // MODE 1 (fastidious second level)
   const swa_task * tasks;
   uint32_t * graft;
@@ -348,7 +350,10 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
     uint64_t seed_ab = 0;
     if (MODE == 0 || MODE == 2) {
       if (MODE == 2) { seed = a.fallback[k].seed; range = a.fallback[k].range; }
-      else { seed = a.first + k; }
+      else {
+        seed = a.first + k;
+        if (a.owner_world > 1u && seed % a.owner_world != a.owner_rank) { continue; }   // another rank's seed (wave-uniform)
+      }
       len = a.seqlen[seed];
       nw = (len + 31u) >> 5;
       const uint64_t * gs = a.seqs + a.seq_off[seed];
@@ -787,8 +792,12 @@ static bool anchor_applicable(const swa_ctx * ctx) {
 static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   ctx->anchor_ready = false;
   const uint32_t n = ctx->db.n;
+  // load <= 0.5 for the anchors that get a slot: all of the range, or this rank's share of them
+  // (hashed ownership: 25 % headroom, and k_anchor_insert reports a table that is still too small)
+  const bool by_share = ctx->owner_world > 1 && ctx->anchor_slack == 0;
+  const uint64_t share = by_share ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count;
   uint64_t asize = 64;
-  while (asize < 2ull * count) { asize <<= 1; }
+  while (asize < 2ull * share) { asize <<= 1; }
   ctx->anchor_slots = asize;
   for (int which = 0; which < 2; ++which) {
     SWA_TRY(swa_reserve(ctx, ctx->d_akeys[which], asize * sizeof(uint64_t)));
@@ -803,6 +812,8 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
+  auto * overflow = static_cast<uint32_t *>(ctx->d_flags.ptr) + 2;
+  SWA_HIP(ctx, hipMemsetAsync(overflow, 0, sizeof(uint32_t), ctx->stream));
   for (int which = 0; which < 2; ++which) {
     auto * keys = static_cast<unsigned long long *>(ctx->d_akeys[which].ptr);
     auto * counts = static_cast<uint32_t *>(ctx->d_acounts[which].ptr);
@@ -814,6 +825,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n; b.which = which;
     b.first = first; b.count = count;
     b.keys = keys; b.counts = counts; b.amask = asize - 1; b.slot_of = slot_of;
+    b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.overflow = overflow;
     hipLaunchKernelGGL(k_anchor_insert, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
     if (count < n) {
       hipLaunchKernelGGL(k_anchor_lookup, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
@@ -897,7 +909,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
                      count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
                      static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
-                     static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2);
+                     static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world);
   NetArgs f{};
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
   f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
@@ -917,6 +929,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   f.fallback = static_cast<const swa_fallback *>(ctx->d_afallback.ptr);
   f.fallback_count = acounters + 2;
   f.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
+  f.owner_rank = 0; f.owner_world = 1;                       // the list already is this rank's share
   const size_t flds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull +
                                           kWaves * ((size_t)(maxwords + 2u) + kQueueCap + kQueueCap / 2));
   const int fgrid = grid_for(ctx, count, kWaves, 8);
@@ -1052,7 +1065,9 @@ static int launch_network(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count
   a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
   a.stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
   a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
+  a.owner_rank = ctx->owner_rank; a.owner_world = ctx->owner_world;
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));   // skipped seeds keep 0
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
   const size_t lds = network_lds_bytes(ctx, zlds);
   const int grid = grid_for(ctx, count, kWaves, 8);
@@ -1096,7 +1111,7 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
   constexpr uint32_t kLongRowCap = 1u << 16;
   SWA_TRY(swa_reserve(ctx, ctx->d_long_rows, (kLongRowCap + 1ull) * sizeof(uint32_t)));
   uint64_t n_edges = 0;
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  for (int attempt = 0; attempt < 4; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
     SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, uint64_t(nseg) * sizeof(uint32_t), ctx->stream));
     if (ctx->anchor_usable && !stats) {
@@ -1111,8 +1126,11 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
     hipLaunchKernelGGL(k_seg_reduce, dim3(1), dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
                        nseg, static_cast<unsigned long long *>(ctx->d_stats.ptr) + 8);
     uint64_t got[2] = {0, 0};
+    uint32_t anchor_overflow = 0;
     SWA_HIP(ctx, hipMemcpyAsync(got, static_cast<uint64_t *>(ctx->d_stats.ptr) + 8, sizeof(got), hipMemcpyDeviceToHost,
                                 ctx->stream));
+    SWA_HIP(ctx, hipMemcpyAsync(&anchor_overflow, static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
     // CSR assembly is enqueued right behind, before the host looks at the totals: every kernel
     // below guards its writes with `cap` / the segment capacity, so a run that turns out to
     // need bigger segments or a bigger neighbour buffer has only wasted these launches.
@@ -1139,12 +1157,31 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
     swa_t1(ctx, 4);
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     n_edges = got[0];
+    if (ctx->anchor_usable && !stats && anchor_overflow != 0) {
+      // this rank owns more anchors than its share-sized key tables hold (skewed ownership):
+      // size them for the whole range, which cannot overflow, and run again
+      ctx->anchor_slack = 1;
+      ctx->anchor_ready = false;
+      continue;
+    }
     if (got[1] <= ctx->seg_cap) { break; }
     // one wave found more hits than its segment holds: grow the segments and run again (rare)
     while (ctx->seg_cap < got[1]) { ctx->seg_cap <<= 1; }
   }
   *total = n_edges;
   if (n_edges > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network: neighbour buffer too small"); }
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (world == 0 || rank >= world) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_set_ownership: bad rank / world"); }
+  if (rank != ctx->owner_rank || world != ctx->owner_world) {
+    ctx->owner_rank = rank;
+    ctx->owner_world = world;
+    ctx->anchor_ready = false;                               // the next network call indexes this rank's groups
+    ctx->anchor_slack = 0;
+  }
   return SWA_OK;
 }
 

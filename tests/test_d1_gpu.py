@@ -159,9 +159,7 @@ def _check_vs_oracle(ctx, db, ncb=False):
     return off, nb
 
 
-def test_giant_anchor_groups_fall_back(gpu_ctx):
-    """> 2048 amplicons sharing the same first AND last 32 nt: the anchored passes hand those
-    seeds (per position range) to the plain kernel; the result must not change."""
+def _giant_group_db():
     rng = np.random.default_rng(99)
     head = "".join(rng.choice(list("ACGT"), size=40))
     tail = "".join(rng.choice(list("ACGT"), size=40))
@@ -178,12 +176,18 @@ def test_giant_anchor_groups_fall_back(gpu_ctx):
             seqs.append(base[:p] + "ACGT"[(("ACGT".index(base[p])) + 1 + j % 3) % 4] + base[p + 1:])
     seqs = sorted(set(seqs))
     db = S.build_db([(f"s{i}_{1 + (i * 13) % 40}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    return db
+
+
+def test_giant_anchor_groups_fall_back(gpu_ctx):
+    """> 2048 amplicons sharing the same first AND last 32 nt: the anchored passes hand those
+    seeds (per position range) to the plain kernel; the result must not change."""
+    db = _giant_group_db()
     off, nb = _check_vs_oracle(gpu_ctx, db)
     assert len(nb) > 1000
 
 
-def test_short_and_long_sequences_mix(gpu_ctx):
-    """lengths around the anchoring thresholds (32, 64/65) and far above"""
+def _length_mix_db():
     rng = np.random.default_rng(7)
     seqs = set()
     for L in (20, 31, 32, 33, 40, 63, 64, 65, 66, 70, 96, 97, 128, 129, 200):
@@ -201,6 +205,12 @@ def test_short_and_long_sequences_mix(gpu_ctx):
                     seqs.add(base[:p] + "ACGT"[int(rng.integers(0, 4))] + base[p:])
     seqs = sorted(seqs)
     db = S.build_db([(f"s{i}_{1 + (i * 7) % 9}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    return db
+
+
+def test_short_and_long_sequences_mix(gpu_ctx):
+    """lengths around the anchoring thresholds (32, 64/65) and far above"""
+    db = _length_mix_db()
     _check_vs_oracle(gpu_ctx, db)
     _check_vs_oracle(gpu_ctx, db, ncb=True)
 
@@ -295,3 +305,52 @@ def test_duplicate_check_by_slices(gpu_ctx, tmp_path):
     assert any(flags)
     _upload(gpu_ctx, S.db_from_fasta(fa))
     assert [gpu_ctx.d1_index_build(f, c) for f, c in [(0, 1500), (1500, 1500)]] == [False, False]
+
+
+def _link_keys(off, nb):
+    rows = np.repeat(np.arange(len(off) - 1, dtype=np.uint64), np.diff(off).astype(np.int64))
+    return (rows << np.uint64(32)) | nb.astype(np.uint64)
+
+
+@pytest.mark.parametrize("which", ["generated", "giant_groups", "length_mix"])
+@pytest.mark.parametrize("plain", [False, True])
+def test_ownership_partials_add_up_to_the_network(tmp_path, which, plain):
+    """swa_d1_set_ownership: with world = 2 and 3 every rank's network call returns partial rows;
+    over the ranks every link of the complete network appears exactly once — for the anchored
+    route (groups owned by key), its fallback seeds (oversized groups, short sequences) and the
+    plain route (seeds by id mod world)."""
+    import os
+    from swarm_amd import Context
+    if which == "generated":
+        fa = tmp_path / "in.fa"
+        S.gen_fasta(fa, 20000, 150, 41)
+        db = S.db_from_fasta(fa)
+    else:
+        db = _giant_group_db() if which == "giant_groups" else _length_mix_db()
+    ctx = Context(0)
+    try:
+        if plain:
+            os.environ["SWA_D1_PLAIN"] = "1"
+        _upload(ctx, db)
+        assert ctx.d1_index_build() is False
+        woff, wnb, _ = _oracle_sorted_rows(db)
+        whole = _link_keys(woff, wnb)
+        off, nb = ctx.d1_network()
+        assert np.array_equal(_link_keys(off, nb), whole)
+        for world in (2, 3):
+            parts = []
+            for rank in range(world):
+                ctx.d1_set_ownership(rank, world)
+                poff, pnb = ctx.d1_network()
+                keys = _link_keys(poff, pnb)
+                assert (np.diff(keys) > 0).all()              # partial rows ascending and unique, too
+                parts.append(keys)
+            merged = np.sort(np.concatenate(parts))
+            assert np.array_equal(merged, whole), (which, plain, world)
+            assert sum(len(p) > 0 for p in parts) == world    # nobody idles
+        ctx.d1_set_ownership(0, 1)
+        off, nb = ctx.d1_network()
+        assert np.array_equal(_link_keys(off, nb), whole)
+    finally:
+        os.environ.pop("SWA_D1_PLAIN", None)
+        ctx.close()

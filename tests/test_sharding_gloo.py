@@ -116,3 +116,59 @@ def test_combine_grafts_min_and_sum(tmp_path, world):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == world
+
+
+OWNED_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+    import support as S
+    from swarm_amd import sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    db = S.db_from_fasta(sys.argv[2])
+    full_off, full_nb, _ = S.oracle_d1_network(db)
+    full_nb = full_nb.copy()
+    for i in range(db.n):
+        full_nb[int(full_off[i]):int(full_off[i + 1])].sort()
+    # what a rank of an ownership-sharded job holds: partial rows over ALL amplicons, every link
+    # on exactly one rank (here: a hash of the link stands in for "the rank owning the anchor group")
+    rows = np.repeat(np.arange(db.n, dtype=np.uint64), np.diff(full_off).astype(np.int64))
+    owner = ((rows * np.uint64(2654435761) + full_nb.astype(np.uint64) * np.uint64(40503)) >> np.uint64(7)) % np.uint64(world)
+    keep = owner == rank
+    p_nb = full_nb[keep]
+    p_off = np.zeros(db.n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows[keep].astype(np.int64), minlength=db.n), out=p_off[1:])
+    parts = sharding.partition_by_length(db.seqlen, world) if sys.argv[3] == "length" else sharding.partition_even(db.n, world)
+    counts = [c for _, c in parts]
+    t_nb = torch.from_numpy(np.concatenate([p_nb, np.zeros(3, dtype=np.uint32)]).view(np.int32))     # capacity > total
+    l_off, l_nb = sharding.exchange_owned_csr(torch.from_numpy(p_off), t_nb, counts)
+    first, count = parts[rank]
+    lo, hi = int(full_off[first]), int(full_off[first + count])
+    assert np.array_equal(l_off.numpy().astype(np.uint64), full_off[first:first + count + 1] - full_off[first]), "slice offsets differ"
+    assert np.array_equal(l_nb.numpy().view(np.uint32), full_nb[lo:hi]), "slice neighbours differ"
+    g_off, g_nb = sharding.allgather_csr(l_off, l_nb, int(l_nb.numel()), counts)
+    assert np.array_equal(g_off.numpy().astype(np.uint64), full_off), "offsets differ"
+    assert np.array_equal(g_nb.numpy().view(np.uint32), full_nb), "neighbours differ"
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+''')
+
+
+@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "length")])
+def test_owned_partial_rows_merge_into_the_network(tmp_path, world, mode):
+    """Ownership sharding (swa_d1_set_ownership): partial rows over all amplicons on every rank,
+    all-to-all by seed range, merge, then the usual all-gather of the slices."""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 2503, 90, 78)
+    script = tmp_path / "worker.py"
+    script.write_text(OWNED_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), str(S.ROOT),
+                        str(fa), mode], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == world
