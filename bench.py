@@ -6,16 +6,16 @@ C ABI, with the packed database already resident in HBM and the CSR left in HBM:
     swa_d1_index_build   (sequence hashes, amplicon hash table, Bloom filter, duplicate check)
     swa_d1_network_device (microvariant hashes -> Bloom -> table probe -> verify -> CSR)
 and, for N > 1, a MAX all-reduce of the per-rank duplicate flags, the all-to-all merge of the
-ranks' partial rows and the RCCL all-gather of the per-rank CSR slices over xGMI.
+ranks' links by seed range and the RCCL all-gather of the per-rank CSR slices over xGMI.
 
 Workload at N = 1: the size BASELINE.json's metric string names — 10 M synthetic amplicons x
 150 bp, d = 1 (configs[1], 1 M x 150, is measured in the same run and reported under
 config.configs1).  For N > 1 the job is weak-scaled: the database holds N x 10 M amplicons
 (N = 8: 80 M, the order of configs[4]), replicated on every GPU.  Default sharding ("owned"):
 rank r serves the anchor groups whose key maps to r — with all their members, so the per-group
-LDS tables are built once per job, not once per rank —, which leaves it partial rows over all
-amplicons; the rows travel all-to-all by seed range, are merged, and the slices are
-all-gathered.  `--shard range` is the older scheme (rank r answers its contiguous slice).
+LDS tables are built once per job, not once per rank —, which leaves it a share of the
+links; they travel all-to-all by seed range, become the rank's slice of the CSR, and the slices
+are all-gathered.  `--shard range` is the older scheme (rank r answers its contiguous slice).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline"     — algorithmic bytes of the dominant kernel group (the d=1 network: the anchored
@@ -193,7 +193,7 @@ def main() -> None:
                          "the JSON line is marked simulated and is not a result")
     ap.add_argument("--shard", default="owned", choices=["owned", "range"],
                     help="N > 1: 'owned' = every rank serves the anchor groups it owns (swa_d1_set_ownership) and the "
-                         "partial rows are merged all-to-all; 'range' = every rank answers its contiguous query slice "
+                         "links are exchanged all-to-all by seed range; 'range' = every rank answers its contiguous query slice "
                          "against structures indexed for that slice")
     ap.add_argument("--dev-backend", default="nccl", choices=["nccl", "gloo"],
                     help="development aid: 'gloo' runs the N>1 flow with every rank on GPU 0 (collectives staged "
@@ -249,14 +249,17 @@ def main() -> None:
     counts = [c for _, c in parts]
     owned = (sim_world or world) > 1 and args.shard == "owned"
     if owned:
-        # this rank finds the links inside the anchor groups it owns: partial rows over ALL amplicons
+        # this rank finds the links inside the anchor groups it owns, whichever amplicons they belong to
         ctx.d1_set_ownership(rank, sim_world or world)
         q_first, q_count = 0, n_total
     else:
         q_first, q_count = first, count
     cap = 8 * count
-    d_offsets = torch.zeros(q_count + 1, dtype=torch.int64, device=dev)
-    d_nb = torch.zeros(cap, dtype=torch.int32, device=dev)
+    if owned and world > 1:
+        d_links = torch.zeros(cap, dtype=torch.int64, device=dev)   # flat list: source << 32 | target
+    else:
+        d_offsets = torch.zeros(q_count + 1, dtype=torch.int64, device=dev)
+        d_nb = torch.zeros(cap, dtype=torch.int32, device=dev)
 
     kernel_ms = []
     hits_seen = [0]
@@ -272,12 +275,15 @@ def main() -> None:
             dist.all_reduce(dup_flag, op=dist.ReduceOp.MAX)
             dup = bool(dup_flag.item())
         assert not dup
-        total = ctx.d1_network_device(d_offsets, d_nb, cap, False, q_first, q_count)
+        if owned and world > 1:
+            total = ctx.d1_network_edges_device(d_links, cap, False, q_first, q_count)
+        else:
+            total = ctx.d1_network_device(d_offsets, d_nb, cap, False, q_first, q_count)
         hits_seen[0] = total
         if world > 1:
             if owned:
-                # partial rows travel all-to-all by seed range and are merged into this rank's slice
-                l_off, l_nb = sharding.exchange_owned_csr(d_offsets, d_nb, counts)
+                # the links travel all-to-all by seed range and become this rank's slice of the CSR
+                l_off, l_nb = sharding.exchange_owned_links(d_links[:total], counts)
             else:
                 l_off, l_nb = d_offsets, d_nb[:total]
             # exchange step named by the north star: all-gather hit counts, then row offsets and
@@ -353,7 +359,7 @@ def main() -> None:
                 "per_gpu_queries": count,
                 "db_amplicons": n_total,
                 "step": "swa_d1_index_build + swa_d1_network_device (B1 seam), db and CSR resident in HBM"
-                        + ("; ownership by anchor group, partial rows merged all-to-all, RCCL all-gather of CSR slices"
+                        + ("; ownership by anchor group, links exchanged all-to-all by seed range, RCCL all-gather of CSR slices"
                            if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else ""),
                 "sharding": ("owned" if owned else "range") if (sim_world or world) > 1 else "none",
                 "neighbour_links": int(hits_seen[0]),

@@ -112,7 +112,8 @@ int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int 
    of once per rank —, its share of the seeds only the plain kernel can serve, and, when the
    anchored route is not in use, the seeds with id mod world == rank.  swa_d1_network[_device]
    over a range then returns the PARTIAL rows of that range; over all ranks every link of the
-   network appears exactly once (the host merges the partial rows: swarm_amd/sharding.py).
+   network appears exactly once (the host redistributes them: swarm_amd/sharding.py, and
+   swa_d1_network_edges_device below for the form that travels).
    world = 1 restores the complete network.  Takes effect at the next network call. */
 int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world);
 
@@ -127,6 +128,12 @@ int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint3
    enqueues + one 8-byte readback of *total */
 int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
                           uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap, uint64_t * total);
+/* same links as one flat list in HBM: d_edge_list[i] = source << 32 | target, each link once, in
+   no particular order (what the kernels emit before the CSR is assembled).  This is the form a
+   multi-GPU job exchanges (swa_d1_set_ownership): nothing in it is proportional to the database
+   size.  cap = capacity in entries; SWA_E_CAPACITY / *total as above. */
+int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
+                                uint64_t * d_edge_list, uint64_t cap, uint64_t * total);
 
 /* Introspection used by the parity tests (bit-exact against the oracle): copies to host.
    what: 0 seqhash u64[n] · 1 Bloom bitmap u64[table_size/8] · 2 Zobrist table

@@ -37,7 +37,7 @@ class DbView(C.Structure):
 
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize",
-    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_network", "swa_d1_network_device",
+    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
@@ -79,6 +79,9 @@ def load_library() -> C.CDLL:
     lib.swa_d1_network.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                    C.c_uint64, u64p]
     lib.swa_d1_network_device.argtypes = lib.swa_d1_network.argtypes
+    lib.swa_d1_network_edges_device.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                                C.POINTER(C.c_uint64)]
+    lib.swa_d1_set_ownership.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.swa_d1_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.swa_d1_table_size.argtypes = [C.c_void_p]
     lib.swa_d1_table_size.restype = C.c_uint64
@@ -335,9 +338,8 @@ class Context:
     def d1_set_ownership(self, rank: int = 0, world: int = 1) -> None:
         """Multi-GPU by ownership: from the next network call on this context finds only its share of
         the links (the anchor groups whose key maps to `rank`, its share of the plain-kernel seeds),
-        so a network call returns PARTIAL rows; sharding.exchange_owned_csr merges the ranks' rows.
+        so a network call returns PARTIAL rows; sharding.exchange_owned_links merges the ranks' links.
         world = 1 restores the complete network."""
-        self.lib.swa_d1_set_ownership.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         self._check(self.lib.swa_d1_set_ownership(self.h, rank, world))
 
     def d1_network(self, no_cluster_breaking: bool = False, first: int = 0, count: int | None = None):
@@ -364,6 +366,17 @@ class Context:
         total = C.c_uint64(0)
         self._check(self.lib.swa_d1_network_device(self.h, int(no_cluster_breaking), first, count,
                                                    _ptr(d_offsets), _ptr(d_neighbours), cap, C.byref(total)))
+        return int(total.value)
+
+    def d1_network_edges_device(self, d_edge_list, cap: int, no_cluster_breaking: bool = False,
+                                first: int = 0, count: int | None = None) -> int:
+        """The same links as one flat device list (int64 tensor): source << 32 | target, each once,
+        unordered.  Returns the number of links; raises SwaError(SWA_E_CAPACITY) if cap is too small."""
+        if count is None:
+            count = self.n - first
+        total = C.c_uint64(0)
+        self._check(self.lib.swa_d1_network_edges_device(self.h, int(no_cluster_breaking), first, count,
+                                                         _ptr(d_edge_list), cap, C.byref(total)))
         return int(total.value)
 
     def d1_table_size(self) -> int:

@@ -681,6 +681,39 @@ __global__ __launch_bounds__(256) void k_seg_reduce(const uint32_t * __restrict_
   if (threadIdx.x == 0) { out[0] = ssum[0]; out[1] = smax[0]; }
 }
 
+// start of every segment in the compacted edge list: exclusive prefix sum of the fills
+__global__ __launch_bounds__(256) void k_seg_bases(const uint32_t * __restrict__ seg_fill, uint32_t nseg,
+                                                   unsigned long long * __restrict__ bases) {
+  __shared__ unsigned long long part[256];
+  const uint32_t chunk = (nseg + 255u) / 256u;
+  const uint32_t lo = threadIdx.x * chunk, hi = min(nseg, lo + chunk);
+  unsigned long long sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) { sum += seg_fill[i]; }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int t = 0; t < 256; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; }
+  }
+  __syncthreads();
+  unsigned long long at = part[threadIdx.x];
+  for (uint32_t i = lo; i < hi; ++i) { bases[i] = at; at += seg_fill[i]; }
+}
+
+// per-wave segments -> one flat list of (source << 32 | target) links, in no particular order
+__global__ __launch_bounds__(256) void k_seg_compact(const uint64_t * __restrict__ edges,
+                                                     const uint32_t * __restrict__ seg_fill, uint32_t nseg, uint64_t seg_cap,
+                                                     const unsigned long long * __restrict__ bases,
+                                                     uint64_t * __restrict__ out, uint64_t cap) {
+  for (uint32_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const uint64_t fill = min((uint64_t)seg_fill[s], seg_cap);
+    const uint64_t base = bases[s];
+    for (uint64_t i = threadIdx.x; i < fill; i += blockDim.x) {
+      if (base + i < cap) { out[base + i] = edges[(uint64_t)s * seg_cap + i]; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_scatter_edges(const uint64_t * __restrict__ edges,
                                                        const uint32_t * __restrict__ seg_fill, uint32_t nseg,
                                                        uint64_t seg_cap, uint32_t first,
@@ -1086,14 +1119,10 @@ static int launch_network(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count
   return SWA_OK;
 }
 
-extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
-                                     uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap, uint64_t * total) {
-  if (ctx == nullptr) { return SWA_E_ARG; }
-  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: call swa_d1_index_build first"); }
-  if (count == 0 || (uint64_t)first + count > ctx->db.n || d_offsets == nullptr || total == nullptr ||
-      (d_neighbours == nullptr && cap != 0)) {
-    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: bad range or null buffer");
-  }
+// The network over [first, first + count), left in HBM either as CSR (d_offsets / d_neighbours)
+// or, when d_edge_list != nullptr, as one flat list of (source << 32 | target) links.
+static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count, uint64_t * d_offsets,
+                       uint32_t * d_neighbours, uint64_t * d_edge_list, uint64_t cap, uint64_t * total) {
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   const char * env_stats = getenv("SWA_D1_STATS");
   const bool stats = env_stats != nullptr && env_stats[0] == '1';
@@ -1136,22 +1165,31 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
     // need bigger segments or a bigger neighbour buffer has only wasted these launches.
     // Offsets are always complete; neighbours only if they fit.
     swa_t0(ctx, 4);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
-                       static_cast<const uint32_t *>(ctx->d_counts.ptr), count, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
-                       static_cast<const uint32_t *>(ctx->d_counts.ptr), count,
-                       static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), d_offsets);
-    if (d_neighbours != nullptr && cap > 0) {
-      SWA_HIP(ctx, hipMemsetAsync(ctx->d_cursor.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
-      SWA_HIP(ctx, hipMemsetAsync(ctx->d_long_rows.ptr, 0, sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(k_scatter_edges, dim3(std::min<uint32_t>(nseg, (uint32_t)ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
+    if (d_edge_list != nullptr) {
+      SWA_TRY(swa_reserve(ctx, ctx->d_seg_base, uint64_t(nseg) * sizeof(uint64_t)));
+      hipLaunchKernelGGL(k_seg_bases, dim3(1), dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seg_fill.ptr), nseg,
+                         static_cast<unsigned long long *>(ctx->d_seg_base.ptr));
+      hipLaunchKernelGGL(k_seg_compact, dim3(std::min<uint32_t>(nseg, (uint32_t)ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
                          static_cast<const uint64_t *>(ctx->d_edges.ptr), static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
-                         nseg, ctx->seg_cap, first, d_offsets, static_cast<uint32_t *>(ctx->d_cursor.ptr), d_neighbours, cap);
-      hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, d_offsets, count,
-                         d_neighbours, cap, static_cast<uint32_t *>(ctx->d_long_rows.ptr), kLongRowCap);
-      hipLaunchKernelGGL(k_sort_long_rows, dim3(ctx->num_cus), dim3(64), 0, ctx->stream, d_offsets, count, d_neighbours, cap,
-                         static_cast<const uint32_t *>(ctx->d_long_rows.ptr), kLongRowCap);
+                         nseg, ctx->seg_cap, static_cast<const unsigned long long *>(ctx->d_seg_base.ptr), d_edge_list, cap);
+    } else {
+      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+                         static_cast<const uint32_t *>(ctx->d_counts.ptr), count, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
+      hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+                         static_cast<const uint32_t *>(ctx->d_counts.ptr), count,
+                         static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), d_offsets);
+      if (d_neighbours != nullptr && cap > 0) {
+        SWA_HIP(ctx, hipMemsetAsync(ctx->d_cursor.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
+        SWA_HIP(ctx, hipMemsetAsync(ctx->d_long_rows.ptr, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_scatter_edges, dim3(std::min<uint32_t>(nseg, (uint32_t)ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
+                           static_cast<const uint64_t *>(ctx->d_edges.ptr), static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
+                           nseg, ctx->seg_cap, first, d_offsets, static_cast<uint32_t *>(ctx->d_cursor.ptr), d_neighbours, cap);
+        hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, d_offsets, count,
+                           d_neighbours, cap, static_cast<uint32_t *>(ctx->d_long_rows.ptr), kLongRowCap);
+        hipLaunchKernelGGL(k_sort_long_rows, dim3(ctx->num_cus), dim3(64), 0, ctx->stream, d_offsets, count, d_neighbours, cap,
+                           static_cast<const uint32_t *>(ctx->d_long_rows.ptr), kLongRowCap);
+      }
     }
     SWA_HIP(ctx, hipGetLastError());
     swa_t1(ctx, 4);
@@ -1171,6 +1209,27 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
   *total = n_edges;
   if (n_edges > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network: neighbour buffer too small"); }
   return SWA_OK;
+}
+
+extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
+                                     uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap, uint64_t * total) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: call swa_d1_index_build first"); }
+  if (count == 0 || (uint64_t)first + count > ctx->db.n || d_offsets == nullptr || total == nullptr ||
+      (d_neighbours == nullptr && cap != 0)) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: bad range or null buffer");
+  }
+  return network_run(ctx, no_cluster_breaking, first, count, d_offsets, d_neighbours, nullptr, cap, total);
+}
+
+extern "C" int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
+                                           uint64_t * d_edge_list, uint64_t cap, uint64_t * total) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: call swa_d1_index_build first"); }
+  if (count == 0 || (uint64_t)first + count > ctx->db.n || d_edge_list == nullptr || total == nullptr) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network_edges: bad range or null buffer");
+  }
+  return network_run(ctx, no_cluster_breaking, first, count, nullptr, nullptr, d_edge_list, cap, total);
 }
 
 extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world) {

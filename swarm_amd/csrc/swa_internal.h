@@ -68,6 +68,7 @@ struct swa_ctx {
   swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_acursor[2], d_aoffsets[2], d_aslot[2], d_amembers[2], d_aitems[2];
   swa_dbuf d_acounters, d_afallback, d_arank;
   swa_dbuf d_seg_fill;           // u32 fill of every per-wave edge segment
+  swa_dbuf d_seg_base;           // u64 start of every segment in the compacted edge list (swa_d1_network_edges_device)
   uint64_t seg_cap = 0;          // entries per segment
 
   // q-gram / alignment state

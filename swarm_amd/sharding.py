@@ -88,57 +88,45 @@ def allgather_csr(local_offsets: torch.Tensor, local_nb: torch.Tensor, local_tot
     return offsets, neighbours
 
 
-def exchange_owned_csr(part_offsets: torch.Tensor, part_nb: torch.Tensor, counts: list, group=None):
-    """Ownership sharding (swa_d1_set_ownership): every rank holds PARTIAL rows for all n
-    amplicons — the links it found in the anchor groups it owns — and every link of the network is
-    held by exactly one rank.  Rows are redistributed by contiguous seed range and merged.
+def exchange_owned_links(links: torch.Tensor, counts: list, group=None):
+    """Ownership sharding (swa_d1_set_ownership): every rank holds the links it found in the anchor
+    groups it owns, as one flat list (swa_d1_network_edges_device), and every link of the network
+    is held by exactly one rank.  The links are redistributed by contiguous seed range and turned
+    into this rank's slice of the CSR.  Nothing here is proportional to the database size.
 
-    part_offsets : int64 [n + 1]  row offsets of this rank's partial CSR over all n amplicons
-    part_nb      : int32 [>= part_offsets[n]]
-    counts       : per-rank row counts of the final partition (from partition_*), sum = n
-    Returns this rank's slice of the complete network: (offsets int64 [counts[rank] + 1] starting
-    at 0, neighbours int32, rows ascending) on the tensors' device — what allgather_csr takes.
+    links  : int64 [m]  source << 32 | target (ids < 2^31), any order
+    counts : per-rank row counts of the final partition (from partition_*), sum = n
+    Returns (offsets int64 [counts[rank] + 1] starting at 0, neighbours int32, rows ascending) on
+    the links' device — what allgather_csr takes.
 
-    Collectives: all-to-all of the per-row link counts (4 bytes per amplicon and rank), all-to-all
-    of the split sizes, all-to-all of the links (4 bytes each); no link travels twice.
+    Collectives: all-to-all of the split sizes (8 bytes per pair of ranks), all-to-all of the
+    links (8 bytes each); no link travels twice.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = part_offsets.device
-    n = sum(counts)
-    assert part_offsets.numel() == n + 1
+    dev = links.device
     bounds = [0]
     for c in counts:
         bounds.append(bounds[-1] + c)
-    mine = counts[rank]
+    assert bounds[-1] < (1 << 31)
+    mine, first = counts[rank], bounds[rank]
 
-    # per-row link counts: destination q receives the rows of its range from every rank
-    row_counts = (part_offsets[1:] - part_offsets[:-1]).to(torch.int32)
-    got_counts = torch.empty(world * mine, dtype=torch.int32, device=dev)
-    dist.all_to_all_single(got_counts, row_counts, output_split_sizes=[mine] * world, input_split_sizes=list(counts),
-                           group=group)
-
-    # links: the rows of a destination's range are contiguous in the partial CSR
-    cuts = part_offsets[torch.tensor(bounds, device=dev)]
-    send_sizes = (cuts[1:] - cuts[:-1])
+    keys, _ = torch.sort(links)                               # by source: destinations become contiguous
+    cuts = torch.searchsorted(keys, torch.tensor(bounds, dtype=torch.int64, device=dev) << 32)
+    send_sizes = cuts[1:] - cuts[:-1]
     recv_sizes = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv_sizes, send_sizes, group=group)
     send_list = [int(x) for x in send_sizes.tolist()]
     recv_list = [int(x) for x in recv_sizes.tolist()]
-    total_out = int(cuts[-1])
-    got_nb = torch.empty(sum(recv_list), dtype=torch.int32, device=dev)
-    dist.all_to_all_single(got_nb, part_nb[:total_out].contiguous(), output_split_sizes=recv_list,
-                           input_split_sizes=send_list, group=group)
+    got = torch.empty(sum(recv_list), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(got, keys, output_split_sizes=recv_list, input_split_sizes=send_list, group=group)
 
-    # merge: a row's links are the union over the source ranks (disjoint), ascending
-    per_src = got_counts.view(world, mine).to(torch.int64)
+    got, _ = torch.sort(got)                                  # rows ascending, links ascending within a row
+    rows = (got >> 32) - first
     offsets = torch.zeros(mine + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(per_src.sum(dim=0), dim=0, out=offsets[1:])
-    local_rows = torch.arange(mine, dtype=torch.int64, device=dev)
-    rows = torch.cat([torch.repeat_interleave(local_rows, per_src[p]) for p in range(world)])
-    keys = (rows << 32) | (got_nb.to(torch.int64) & 0xFFFFFFFF)
-    keys, _ = torch.sort(keys)
-    neighbours = (keys & 0xFFFFFFFF).to(torch.int32)
+    if got.numel() > 0:
+        torch.cumsum(torch.bincount(rows, minlength=mine), dim=0, out=offsets[1:])
+    neighbours = (got & 0xFFFFFFFF).to(torch.int32)
     return offsets, neighbours
 
 

@@ -26,3 +26,48 @@ def test_two_ranks_gather_the_whole_network():
     assert out["n_gpus"] == 2 and out["config"]["db_amplicons"] == 300000
     assert out["sharded_csr_equals_whole"] is True
     assert out["config"]["neighbour_links"] > 0
+
+
+EDGE_LIST_SCRIPT = """
+import sys
+import numpy as np
+import torch
+torch.zeros(1, device="cuda:0")            # torch initialises the GPU first (as in bench.py)
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import support as S
+from swarm_amd import Context
+db = S.db_from_fasta(sys.argv[2])
+ctx = Context(0, torch.cuda.current_stream().cuda_stream)
+ctx.upload_db(db.seqs, db.seq_off, db.seqlen, db.abundance, db.longest)
+assert ctx.d1_index_build() is False
+def keys_of(off, nb):
+    rows = np.repeat(np.arange(len(off) - 1, dtype=np.uint64), np.diff(off).astype(np.int64))
+    return (rows << np.uint64(32)) | nb.astype(np.uint64)
+for world in (1, 2):
+    for rank in range(world):
+        ctx.d1_set_ownership(rank, world)
+        want = keys_of(*ctx.d1_network())
+        buf = torch.zeros(len(want) + 5, dtype=torch.int64, device="cuda:0")
+        total = ctx.d1_network_edges_device(buf, buf.numel())
+        got = np.sort(buf[:total].cpu().numpy().view(np.uint64))
+        assert total == len(want) and np.array_equal(got, want), (world, rank)
+        small = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+        try:
+            ctx.d1_network_edges_device(small, small.numel())
+            raise SystemExit("capacity error expected")
+        except Exception as e:
+            assert "too small" in str(e), e
+ctx.close()
+print("edge lists ok")
+"""
+
+
+def test_edge_list_holds_the_links_of_the_csr(tmp_path):
+    """swa_d1_network_edges_device (the form a multi-GPU job exchanges) against the CSR of the same
+    call, complete and per owner; a too-small buffer is reported, not overrun."""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 20000, 150, 43)
+    r = subprocess.run([sys.executable, "-c", EDGE_LIST_SCRIPT, str(S.ROOT), str(fa)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "edge lists ok" in r.stdout

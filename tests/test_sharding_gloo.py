@@ -133,18 +133,16 @@ OWNED_WORKER = textwrap.dedent('''
     full_nb = full_nb.copy()
     for i in range(db.n):
         full_nb[int(full_off[i]):int(full_off[i + 1])].sort()
-    # what a rank of an ownership-sharded job holds: partial rows over ALL amplicons, every link
+    # what a rank of an ownership-sharded job holds: a flat list of links, every link of the network
     # on exactly one rank (here: a hash of the link stands in for "the rank owning the anchor group")
     rows = np.repeat(np.arange(db.n, dtype=np.uint64), np.diff(full_off).astype(np.int64))
     owner = ((rows * np.uint64(2654435761) + full_nb.astype(np.uint64) * np.uint64(40503)) >> np.uint64(7)) % np.uint64(world)
     keep = owner == rank
-    p_nb = full_nb[keep]
-    p_off = np.zeros(db.n + 1, dtype=np.int64)
-    np.cumsum(np.bincount(rows[keep].astype(np.int64), minlength=db.n), out=p_off[1:])
+    links = ((rows[keep] << np.uint64(32)) | full_nb[keep].astype(np.uint64)).astype(np.int64)
+    links = links[np.random.default_rng(rank).permutation(len(links))]        # the kernels emit them unordered
     parts = sharding.partition_by_length(db.seqlen, world) if sys.argv[3] == "length" else sharding.partition_even(db.n, world)
     counts = [c for _, c in parts]
-    t_nb = torch.from_numpy(np.concatenate([p_nb, np.zeros(3, dtype=np.uint32)]).view(np.int32))     # capacity > total
-    l_off, l_nb = sharding.exchange_owned_csr(torch.from_numpy(p_off), t_nb, counts)
+    l_off, l_nb = sharding.exchange_owned_links(torch.from_numpy(links), counts)
     first, count = parts[rank]
     lo, hi = int(full_off[first]), int(full_off[first + count])
     assert np.array_equal(l_off.numpy().astype(np.uint64), full_off[first:first + count + 1] - full_off[first]), "slice offsets differ"
@@ -159,9 +157,9 @@ OWNED_WORKER = textwrap.dedent('''
 
 
 @pytest.mark.parametrize("world,mode", [(2, "even"), (3, "length")])
-def test_owned_partial_rows_merge_into_the_network(tmp_path, world, mode):
-    """Ownership sharding (swa_d1_set_ownership): partial rows over all amplicons on every rank,
-    all-to-all by seed range, merge, then the usual all-gather of the slices."""
+def test_owned_links_merge_into_the_network(tmp_path, world, mode):
+    """Ownership sharding (swa_d1_set_ownership): every rank holds some of the links (flat list),
+    all-to-all by seed range, CSR slice per rank, then the usual all-gather of the slices."""
     fa = tmp_path / "in.fa"
     S.gen_fasta(fa, 2503, 90, 78)
     script = tmp_path / "worker.py"
