@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
                                                  const uint32_t * __restrict__ seqlen,
                                                  const uint64_t * __restrict__ zobrist, uint32_t zlen,
                                                  uint32_t n, uint64_t * __restrict__ seqhash,
-                                                 swa_aux * __restrict__ aux) {
+                                                 swa_aux * __restrict__ aux, const uint32_t * __restrict__ slot_p,
+                                                 const uint32_t * __restrict__ slot_s) {
   extern __shared__ uint64_t lds[];
   const uint64_t * zob = zobrist;
   if (ZLDS) {
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
     zob = lds;
   }
   for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+    // ownership (multi-GPU): only members of this rank's anchor groups are ever looked at
+    if (slot_p != nullptr && slot_p[a] == kEmpty && slot_s[a] == kEmpty) { continue; }
     const uint64_t * s = seqs + seq_off[a];
     const uint32_t len = seqlen[a];
     uint64_t h = 0, dall = 0, iall = 0;
@@ -815,6 +818,12 @@ static bool anchored_enabled() {
   return !(e != nullptr && e[0] == '1');
 }
 
+// SWA_D1_OWNED_FULL=1: a rank of a multi-GPU job builds the full index like a single GPU (test hook)
+static bool owned_index_enabled() {
+  const char * e = getenv("SWA_D1_OWNED_FULL");
+  return !(e != nullptr && e[0] == '1');
+}
+
 // whether the anchored passes may be used at all for this database (decided at index build)
 static bool anchor_applicable(const swa_ctx * ctx) {
   // (the anchored kernel prefetches a seed's words into kPrefetchWords registers per lane)
@@ -966,7 +975,10 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   const size_t flds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull +
                                           kWaves * ((size_t)(maxwords + 2u) + kQueueCap + kQueueCap / 2));
   const int fgrid = grid_for(ctx, count, kWaves, 8);
-  if (zlds) { hipLaunchKernelGGL((k_d1_probe<true, false, 2>), dim3(fgrid), dim3(kThreads), flds, ctx->stream, f); }
+  // (a rank that built only its owned groups has no table: by construction its fallback list is
+  // empty — network_run checks the count and builds the full index if that ever fails to hold)
+  if (!ctx->full_index) { /* nothing to probe against */ }
+  else if (zlds) { hipLaunchKernelGGL((k_d1_probe<true, false, 2>), dim3(fgrid), dim3(kThreads), flds, ctx->stream, f); }
   else { hipLaunchKernelGGL((k_d1_probe<false, false, 2>), dim3(fgrid), dim3(kThreads), flds, ctx->stream, f); }
   swa_t1(ctx, 3);
   SWA_HIP(ctx, hipGetLastError());
@@ -975,13 +987,13 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
 
 // Zobrist table + per-amplicon sequence hashes (src/db.cc:761, src/zobrist.cc:89-112) and the
 // anchored-index metadata; shared by the d = 1 index and the d = 0 dereplication
-int swa_hash_sequences(swa_ctx * ctx) {
+// Zobrist table in HBM (it only depends on its length: uploaded once) + room for the hashes
+static int prepare_hashing(swa_ctx * ctx) {
   const uint32_t n = ctx->db.n;
   ctx->zobrist_len = ctx->db.longest + 2;                  // db.cc:652-653 (sequence part)
   SWA_TRY(swa_reserve(ctx, ctx->d_seqhash, uint64_t(n) * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_aux, uint64_t(n) * sizeof(swa_aux)));
-  const size_t zbytes = 4ull * ctx->zobrist_len * sizeof(uint64_t);
-  if (ctx->zobrist_resident != ctx->zobrist_len) {         // the table only depends on its length: upload once
+  if (ctx->zobrist_resident != ctx->zobrist_len) {
     std::vector<uint64_t> zob;
     swa_zobrist_table(ctx->zobrist_len, zob);
     SWA_TRY(swa_reserve(ctx, ctx->d_zobrist, zob.size() * sizeof(uint64_t)));
@@ -989,25 +1001,112 @@ int swa_hash_sequences(swa_ctx * ctx) {
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));      // zob is a host temporary
     ctx->zobrist_resident = ctx->zobrist_len;
   }
+  return SWA_OK;
+}
+
+// sequence hashes + the XOR streams of the anchored passes; members_only: just the amplicons that
+// have a slot in one of the two anchor indexes (a rank that serves only the groups it owns)
+static int launch_seqhash(swa_ctx * ctx, bool members_only) {
+  const uint32_t n = ctx->db.n;
+  const size_t zbytes = 4ull * ctx->zobrist_len * sizeof(uint64_t);
+  const uint32_t * slot_p = members_only ? static_cast<const uint32_t *>(ctx->d_aslot[0].ptr) : nullptr;
+  const uint32_t * slot_s = members_only ? static_cast<const uint32_t *>(ctx->d_aslot[1].ptr) : nullptr;
   const int hgrid = grid_for(ctx, n, 256, 8);
   swa_t0(ctx, 0);
   if (zbytes <= kMaxZobristLds) {
     hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                        ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr));
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), slot_p, slot_s);
   } else {
     hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                        ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr));
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), slot_p, slot_s);
   }
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 0);
   return SWA_OK;
 }
 
+// Zobrist table + per-amplicon sequence hashes (src/db.cc:761, src/zobrist.cc:89-112) and the
+// anchored-index metadata; shared by the d = 1 index and the d = 0 dereplication
+int swa_hash_sequences(swa_ctx * ctx) {
+  SWA_TRY(prepare_hashing(ctx));
+  return launch_seqhash(ctx, false);
+}
+
 extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
   if (ctx == nullptr) { return SWA_E_ARG; }
   return swa_d1_index_build_range(ctx, 0, ctx->db.n, has_duplicates);
+}
+
+// hashes of ALL amplicons + the database-wide table and Bloom filter (src/algod1.cc:188-208,
+// src/bloompat.cc): what the plain kernel, the fastidious pass and the debug readers work on.
+// Always built by a single-GPU index build; a rank that serves only the anchor groups it owns
+// builds it on demand (rarely: see build_owned_index).
+static int ensure_full_index(swa_ctx * ctx) {
+  if (ctx->full_index) { return SWA_OK; }
+  SWA_TRY(swa_reserve(ctx, ctx->d_table, ctx->table_size * sizeof(swa_slot)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_bloom, ctx->bloom_words * sizeof(uint64_t)));
+  SWA_TRY(swa_hash_sequences(ctx));
+  swa_t0(ctx, 1);
+  SWA_TRY(swa_d1_rebuild_table(ctx, nullptr));
+  swa_t1(ctx, 1);
+  ctx->full_index = true;
+  return SWA_OK;
+}
+
+// Index build of a rank that serves only the anchor groups it owns (swa_d1_set_ownership,
+// world > 1), without anything proportional to the database except streaming passes: abundance
+// ranks, the anchor indexes of the owned groups (all their members), hashes and XOR streams of
+// those members only, duplicates inside the owned prefix groups.  *needs_table is set when some
+// seed can only be served by the plain kernel (a sequence shorter than 65 nt anywhere, a group
+// too large for LDS) or the db order does not hold: the caller then builds the full index.
+static int build_owned_index(swa_ctx * ctx, bool * needs_table) {
+  const uint32_t n = ctx->db.n;
+  auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
+  SWA_TRY(prepare_hashing(ctx));
+  SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
+  hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
+                     static_cast<uint32_t *>(ctx->d_arank.ptr), dflags);
+  swa_t0(ctx, 7);
+  SWA_TRY(build_anchor_index(ctx, 0, n));
+  swa_t1(ctx, 7);
+  const uint64_t asize = ctx->anchor_slots;
+  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
+  hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, std::max<uint64_t>(n, asize), 256, 8)), dim3(256), 0, ctx->stream,
+                     ctx->db.seqlen, n, static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
+                     static_cast<const uint32_t *>(ctx->d_acounts[1].ptr), asize, dflags);
+  SWA_TRY(launch_seqhash(ctx, true));
+  // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
+  swa_t0(ctx, 2);
+  hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                     static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
+                     asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
+                     static_cast<swa_item *>(ctx->d_aitems[0].ptr) + (n / 2 + 64), acounters + 3);
+  DupArgs da{};
+  da.seqs = ctx->db.seqs; da.seq_off = ctx->db.seq_off; da.seqlen = ctx->db.seqlen;
+  da.seqhash = static_cast<const uint64_t *>(ctx->d_seqhash.ptr);
+  da.members = static_cast<const uint32_t *>(ctx->d_amembers[0].ptr);
+  da.flag = dflags;
+  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + (n / 2 + 64);
+  da.item_count = acounters + 3;
+  hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
+  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);
+  da.item_count = acounters + 0;
+  hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
+  SWA_HIP(ctx, hipGetLastError());
+  swa_t1(ctx, 2);
+  uint32_t flags[5] = {};     // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence [4] oversized group
+  SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (flags[2] != 0) {                                      // skewed ownership: share-sized key tables too small
+    ctx->anchor_slack = 1;
+    ctx->anchor_ready = false;
+    *needs_table = true;                                     // (rare) take the full route for this build
+    return SWA_OK;
+  }
+  *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
+  return SWA_OK;
 }
 
 extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates) {
@@ -1018,6 +1117,8 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   const uint32_t n = ctx->db.n;
   ctx->d1_ready = false;
   ctx->anchor_ready = false;
+  ctx->full_index = false;
+  for (int slot : {0, 1, 2, 7}) { ctx->ev_used[slot] = false; }   // phases this build does not run report 0
   ctx->table_size = swa_hashtable_size(n);
   const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
   ctx->bloom_words = bloom_bytes >> 3;
@@ -1030,38 +1131,47 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));       // pat is a host temporary
     ctx->patterns_resident = true;
   }
-  SWA_TRY(swa_reserve(ctx, ctx->d_table, ctx->table_size * sizeof(swa_slot)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_bloom, ctx->bloom_words * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
-  SWA_TRY(swa_hash_sequences(ctx));
-  swa_t0(ctx, 1);
-  SWA_TRY(swa_d1_rebuild_table(ctx, nullptr));
-  swa_t1(ctx, 1);
-  swa_t0(ctx, 2);
-  if (count > 0) {
-  hipLaunchKernelGGL(k_dup_check, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                     ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_seqhash.ptr), first, count,
-                     static_cast<const swa_slot *>(ctx->d_table.ptr), ctx->table_size - 1,
-                     static_cast<uint32_t *>(ctx->d_flags.ptr));
-  }
-  SWA_HIP(ctx, hipGetLastError());
-  swa_t1(ctx, 2);
-  // the anchored index itself is built by the first network call, for that call's query range
-  ctx->anchor_ready = false;
   ctx->anchor_usable = anchor_applicable(ctx);
-  if (ctx->anchor_usable) {
-    SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
-                       static_cast<uint32_t *>(ctx->d_arank.ptr), static_cast<uint32_t *>(ctx->d_flags.ptr));
-    SWA_HIP(ctx, hipGetLastError());
+
+  bool owned_ok = false;                                    // served without the database-wide table
+  uint32_t group_dups = 0;
+  if (ctx->owner_world > 1 && ctx->anchor_usable && owned_index_enabled()) {
+    bool needs_table = false;
+    SWA_TRY(build_owned_index(ctx, &needs_table));
+    owned_ok = !needs_table;
+    SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!owned_ok) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream)); }
   }
-  uint32_t flags[2] = {0, 0};                               // [0] duplicates [1] abundances not in descending order
-  SWA_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags.ptr, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t flag = flags[0];
-  if (flags[1] != 0) { ctx->anchor_usable = false; }        // the anchored passes rely on the db order
+  uint32_t flag = group_dups;
+  if (!owned_ok) {
+    SWA_TRY(ensure_full_index(ctx));
+    swa_t0(ctx, 2);
+    if (count > 0) {
+      hipLaunchKernelGGL(k_dup_check, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                         ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_seqhash.ptr), first, count,
+                         static_cast<const swa_slot *>(ctx->d_table.ptr), ctx->table_size - 1,
+                         static_cast<uint32_t *>(ctx->d_flags.ptr));
+    }
+    SWA_HIP(ctx, hipGetLastError());
+    swa_t1(ctx, 2);
+    // the anchored index itself is built by the first network call, for that call's query range
+    ctx->anchor_ready = false;
+    if (ctx->anchor_usable) {
+      SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
+      hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
+                         static_cast<uint32_t *>(ctx->d_arank.ptr), static_cast<uint32_t *>(ctx->d_flags.ptr));
+      SWA_HIP(ctx, hipGetLastError());
+    }
+    uint32_t flags[2] = {0, 0};                             // [0] duplicates [1] abundances not in descending order
+    SWA_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags.ptr, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    flag |= flags[0];
+    if (flags[1] != 0) { ctx->anchor_usable = false; }      // the anchored passes rely on the db order
+  }
   ctx->d1_ready = true;
   if (has_duplicates != nullptr) { *has_duplicates = flag != 0 ? 1 : 0; }
   if (flag != 0) {
@@ -1151,7 +1261,10 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
       }
       SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count));
     }
-    else { SWA_TRY(launch_network(ctx, no_cluster_breaking, first, count, stats)); }
+    else {
+      SWA_TRY(ensure_full_index(ctx));
+      SWA_TRY(launch_network(ctx, no_cluster_breaking, first, count, stats));
+    }
     hipLaunchKernelGGL(k_seg_reduce, dim3(1), dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
                        nseg, static_cast<unsigned long long *>(ctx->d_stats.ptr) + 8);
     uint64_t got[2] = {0, 0};
@@ -1160,6 +1273,12 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
                                 ctx->stream));
     SWA_HIP(ctx, hipMemcpyAsync(&anchor_overflow, static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t unserved = 0;                                   // fallback seeds listed while there is no table to serve them
+    const bool check_unserved = ctx->anchor_usable && !stats && !ctx->full_index;
+    if (check_unserved) {
+      SWA_HIP(ctx, hipMemcpyAsync(&unserved, static_cast<uint32_t *>(ctx->d_acounters.ptr) + 2, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    }
     // CSR assembly is enqueued right behind, before the host looks at the totals: every kernel
     // below guards its writes with `cap` / the segment capacity, so a run that turns out to
     // need bigger segments or a bigger neighbour buffer has only wasted these launches.
@@ -1202,6 +1321,10 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
       ctx->anchor_ready = false;
       continue;
     }
+    if (check_unserved && unserved != 0) {                   // should not happen (build_owned_index looks for such seeds)
+      SWA_TRY(ensure_full_index(ctx));
+      continue;
+    }
     if (got[1] <= ctx->seg_cap) { break; }
     // one wave found more hits than its segment holds: grow the segments and run again (rare)
     while (ctx->seg_cap < got[1]) { ctx->seg_cap <<= 1; }
@@ -1240,6 +1363,7 @@ extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world
     ctx->owner_world = world;
     ctx->anchor_ready = false;                               // the next network call indexes this rank's groups
     ctx->anchor_slack = 0;
+    if (!ctx->full_index) { ctx->d1_ready = false; }         // hashes exist for the previous owner's groups only
   }
   return SWA_OK;
 }
@@ -1267,6 +1391,7 @@ extern "C" int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t f
 extern "C" int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out_bytes) {
   if (ctx == nullptr || out == nullptr) { return SWA_E_ARG; }
   if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: no index"); }
+  SWA_TRY(ensure_full_index(ctx));
   const void * src = nullptr;
   size_t bytes = 0;
   switch (what) {
@@ -1305,6 +1430,7 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
   if (ctx == nullptr) { return SWA_E_ARG; }
   if (nshards == 0 || shard >= nshards) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious_shard: bad shard"); }
   if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: call swa_d1_index_build first"); }
+  SWA_TRY(ensure_full_index(ctx));                           // the passes hash every light / heavy amplicon
   if (is_light == nullptr || graft_cand == nullptr || counters == nullptr || bloom_bits < 2 || bloom_bits > 64) {
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: bad argument");
   }
@@ -1354,6 +1480,7 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_bloomflex.ptr, 0xFF, fsize * sizeof(uint64_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_fcounters.ptr, 0, 8 * sizeof(uint64_t), ctx->stream));
   ctx->d1_ready = false;                                     // the table now holds light amplicons only
+  ctx->full_index = false;
   SWA_TRY(swa_d1_rebuild_table(ctx, static_cast<const uint8_t *>(ctx->d_light.ptr)));
 
   auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);   // [0] light var [1] heavy var [2] cand [3] tasks

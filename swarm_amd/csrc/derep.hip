@@ -96,6 +96,7 @@ extern "C" int swa_derep(swa_ctx * ctx, uint32_t * first_identical) {
   SWA_TRY(swa_reserve(ctx, ctx->d_list_b, uint64_t(n) * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
   ctx->d1_ready = false;                                   // d_table is re-purposed
+  ctx->full_index = false;
   ctx->anchor_ready = false;
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_table.ptr, 0, tsize * sizeof(unsigned long long), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0xFF, tsize * sizeof(uint32_t), ctx->stream));

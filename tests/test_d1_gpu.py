@@ -337,10 +337,14 @@ def test_ownership_partials_add_up_to_the_network(tmp_path, which, plain):
         whole = _link_keys(woff, wnb)
         off, nb = ctx.d1_network()
         assert np.array_equal(_link_keys(off, nb), whole)
-        for world in (2, 3):
+        for world, rebuild in ((2, False), (2, True), (3, True)):
             parts = []
             for rank in range(world):
                 ctx.d1_set_ownership(rank, world)
+                if rebuild:
+                    # the index build of a rank that serves only its groups (no database-wide table
+                    # unless a seed needs the plain kernel: short sequences, oversized groups)
+                    assert ctx.d1_index_build() is False
                 poff, pnb = ctx.d1_network()
                 keys = _link_keys(poff, pnb)
                 assert (np.diff(keys) > 0).all()              # partial rows ascending and unique, too
@@ -349,8 +353,34 @@ def test_ownership_partials_add_up_to_the_network(tmp_path, which, plain):
             assert np.array_equal(merged, whole), (which, plain, world)
             assert sum(len(p) > 0 for p in parts) == world    # nobody idles
         ctx.d1_set_ownership(0, 1)
+        assert ctx.d1_index_build() is False
         off, nb = ctx.d1_network()
         assert np.array_equal(_link_keys(off, nb), whole)
     finally:
         os.environ.pop("SWA_D1_PLAIN", None)
+        ctx.close()
+
+
+def test_owner_ranks_find_duplicates_without_the_table(tmp_path):
+    """Index build under ownership: identical sequences share a prefix group, so exactly the rank
+    that owns it reports them; a clean database is clean on every rank."""
+    from swarm_amd import Context
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 5000, 150, 44)
+    recs = S.read_fasta(fa)
+    clean = S.build_db(recs)
+    twin = (b"twin_1", recs[1234][1])                           # a second copy of one sequence
+    dirty = S.build_db(recs + [twin])
+    ctx = Context(0)
+    try:
+        for world in (2, 3):
+            found = []
+            for rank in range(world):
+                ctx.d1_set_ownership(rank, world)
+                _upload(ctx, clean)
+                assert ctx.d1_index_build() is False
+                _upload(ctx, dirty)
+                found.append(ctx.d1_index_build())
+            assert sum(found) == 1, found
+    finally:
         ctx.close()
