@@ -50,8 +50,9 @@ def allgather_csr(local_offsets: torch.Tensor, local_nb: torch.Tensor, local_tot
     counts        : per-rank query counts (from partition_*), identical on all ranks
     Returns (offsets int64 [n + 1], neighbours int32 [total]) on the tensors' device.
 
-    Collectives: one all_gather of the hit counts (8 bytes per rank), one of the row offsets
-    padded to the largest slice, one of the hit lists padded to the largest hit count.
+    Collectives: one all_gather of the hit counts (8 bytes per rank), one of the per-row link
+    counts (4 bytes per amplicon — not the 64-bit offsets: they are a prefix sum away) padded to the
+    largest slice, one of the hit lists padded to the largest hit count.
     """
     world = dist.get_world_size(group)
     dev = local_offsets.device
@@ -59,13 +60,14 @@ def allgather_csr(local_offsets: torch.Tensor, local_nb: torch.Tensor, local_tot
     totals = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(totals, mine, group=group)
     totals_host = [int(x) for x in totals.tolist()]
-    max_rows = max(counts) + 1
+    max_rows = max(max(counts), 1)
     max_hits = max(max(totals_host), 1)
 
-    pad_off = torch.zeros(max_rows, dtype=torch.int64, device=dev)
-    pad_off[: local_offsets.numel()] = local_offsets
-    all_off = torch.empty(world * max_rows, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_off, pad_off, group=group)
+    rows_here = local_offsets.numel() - 1
+    pad_cnt = torch.zeros(max_rows, dtype=torch.int32, device=dev)
+    pad_cnt[:rows_here] = (local_offsets[1:] - local_offsets[:-1]).to(torch.int32)
+    all_cnt = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_cnt, pad_cnt, group=group)
 
     pad_nb = torch.zeros(max_hits, dtype=torch.int32, device=dev)
     pad_nb[:local_total] = local_nb[:local_total]
@@ -73,17 +75,13 @@ def allgather_csr(local_offsets: torch.Tensor, local_nb: torch.Tensor, local_tot
     dist.all_gather_into_tensor(all_nb, pad_nb, group=group)
 
     n = sum(counts)
-    offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    pieces = []
-    row = 0
-    base = 0
-    for r in range(world):
-        c = counts[r]
-        offsets[row: row + c] = all_off[r * max_rows: r * max_rows + c] + base
-        pieces.append(all_nb[r * max_hits: r * max_hits + totals_host[r]])
-        row += c
-        base += totals_host[r]
-    offsets[n] = base
+    if all(c == max_rows for c in counts):
+        row_counts = all_cnt                                   # equal slices: already contiguous
+    else:
+        row_counts = torch.cat([all_cnt[r * max_rows: r * max_rows + counts[r]] for r in range(world)])
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(row_counts, dim=0, dtype=torch.int64, out=offsets[1:])
+    pieces = [all_nb[r * max_hits: r * max_hits + totals_host[r]] for r in range(world)]
     neighbours = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.int32, device=dev)
     return offsets, neighbours
 
