@@ -114,7 +114,12 @@ int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int 
    over a range then returns the PARTIAL rows of that range; over all ranks every link of the
    network appears exactly once (the host redistributes them: swarm_amd/sharding.py, and
    swa_d1_network_edges_device below for the form that travels).
-   world = 1 restores the complete network.  Takes effect at the next network call. */
+   world = 1 restores the complete network.  Takes effect at the next network call.
+   An index build made under ownership contains only what the rank's groups need: hashes of their
+   members, duplicates found inside the owned prefix groups (identical sequences share one, so
+   over all ranks every duplicate pair is reported by exactly one of them — OR the flags), and
+   the database-wide table + Bloom only if some seed needs the plain kernel; after changing the
+   owner call swa_d1_index_build[_range] again. */
 int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world);
 
 /* Neighbour lists of amplicons [first, first+count) as CSR: offsets[count+1],
