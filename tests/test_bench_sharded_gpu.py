@@ -4,6 +4,7 @@ gloo — the same code the driver launches over RCCL, minus the transport.  Rank
 whole network alone and compares it with the gathered CSR."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -14,10 +15,16 @@ import support as S
 pytestmark = pytest.mark.gpu
 
 
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_ranks_gather_the_whole_network():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", str(S.ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "127.0.0.1", "--master-port", str(_free_port()), str(S.ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--per-gpu", "150000", "--seed", "5", "--dev-backend", "gloo"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
