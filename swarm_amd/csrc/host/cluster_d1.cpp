@@ -50,6 +50,18 @@ void for_each_member(const swa_d1_result * r, const swa_d1_result::Swarm & s, F 
   }
 }
 
+constexpr uint32_t kParallelOutputFrom = 200000;   // amplicons from which the writers format on several threads
+constexpr uint32_t kParallelUclustFrom = 200;      // -u aligns every member against its seed: worth it much earlier
+
+// number of every swarm in the output files (attached = grafted swarms have none: they are printed
+// with the swarm they were grafted to)
+std::vector<uint32_t> output_numbers(const swa_d1_result * r) {
+  std::vector<uint32_t> number(r->swarms.size());
+  uint32_t next = 0;
+  for (size_t k = 0; k < r->swarms.size(); ++k) { number[k] = next; if (!r->swarms[k].attached) { ++next; } }
+  return number;
+}
+
 }  // namespace
 
 // ---- the same clustering, computed without the serial walk --------------------------------
@@ -361,22 +373,7 @@ extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * d
       if (!mothur) { sink.put('\n'); }
     }
   };
-  // big outputs (tens of MB at 10 M amplicons) are formatted by several threads, one range of
-  // swarms each, and written in order
-  const size_t ns = r->swarms.size();
-  const int threads = std::min(omp_get_max_threads(), 64);
-  if (r->n < 200000 || threads < 2) {
-    format_range(o, 0, ns);
-  } else {
-    std::vector<std::string> pieces((size_t)threads);
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
-    for (int t = 0; t < threads; ++t) {
-      BufOut sink;
-      format_range(sink, ns * (size_t)t / (size_t)threads, ns * (size_t)(t + 1) / (size_t)threads);
-      pieces[(size_t)t] = sink.take();
-    }
-    for (const auto & piece : pieces) { o.write(piece.data(), piece.size()); }
-  }
+  swa_format_in_pieces(o, r->swarms.size(), r->n >= kParallelOutputFrom, format_range);
   if (mothur) { o.put('\n'); }
   return SWA_OK;
 }
@@ -399,28 +396,33 @@ extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db
 extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
-  uint32_t cluster_no = 0;
-  for (const auto & s : r->swarms) {
-    if (s.attached) { continue; }
-    for_each_member(r, s, [&](uint32_t a) {
-      if (a == s.seed) { return; }
-      const uint32_t gp = r->graft_cand[a];
-      if (gp != SWA_NO_AMPLICON) {
-        swa_out::id_noabundance(o, db, gp, usearch != 0);
-        o.put('\t');
-        swa_out::id_noabundance(o, db, a, usearch != 0);
-        o.put('\t'); o.u64(2); o.put('\t'); o.u64(cluster_no + 1); o.put('\t'); o.u64(r->generation[gp] + 1); o.put('\n');
-      }
-      const uint32_t p = r->parent[a];
-      if (p != SWA_NO_AMPLICON) {
-        swa_out::id_noabundance(o, db, p, usearch != 0);
-        o.put('\t');
-        swa_out::id_noabundance(o, db, a, usearch != 0);
-        o.put('\t'); o.u64(1); o.put('\t'); o.u64(cluster_no + 1); o.put('\t'); o.u64(r->generation[a]); o.put('\n');
-      }
-    });
-    ++cluster_no;
-  }
+  const std::vector<uint32_t> number = output_numbers(r);
+  swa_format_in_pieces(o, r->swarms.size(), r->n >= kParallelOutputFrom, [&](BufOut & sink, size_t begin, size_t end) {
+    for (size_t k = begin; k < end; ++k) {
+      const auto & s = r->swarms[k];
+      if (s.attached) { continue; }
+      const uint32_t cluster_no = number[k];
+      for_each_member(r, s, [&](uint32_t a) {
+        if (a == s.seed) { return; }
+        const uint32_t gp = r->graft_cand[a];
+        if (gp != SWA_NO_AMPLICON) {
+          swa_out::id_noabundance(sink, db, gp, usearch != 0);
+          sink.put('\t');
+          swa_out::id_noabundance(sink, db, a, usearch != 0);
+          sink.put('\t'); sink.u64(2); sink.put('\t'); sink.u64(cluster_no + 1); sink.put('\t'); sink.u64(r->generation[gp] + 1);
+          sink.put('\n');
+        }
+        const uint32_t p = r->parent[a];
+        if (p != SWA_NO_AMPLICON) {
+          swa_out::id_noabundance(sink, db, p, usearch != 0);
+          sink.put('\t');
+          swa_out::id_noabundance(sink, db, a, usearch != 0);
+          sink.put('\t'); sink.u64(1); sink.put('\t'); sink.u64(cluster_no + 1); sink.put('\t'); sink.u64(r->generation[a]);
+          sink.put('\n');
+        }
+      });
+    }
+  });
   return SWA_OK;
 }
 
@@ -436,15 +438,17 @@ extern "C" int swa_d1_write_seeds(const swa_d1_result * r, const swa_hostdb * db
     if (a.mass != b.mass) { return a.mass > b.mass; }
     return std::strcmp(swa_out::hdr(db, a.seed), swa_out::hdr(db, b.seed)) < 0;
   });
-  std::string line;
-  for (uint32_t k : idx) {
-    const auto & s = r->swarms[k];
-    if (s.attached) { continue; }
-    o.put('>');
-    swa_out::id_new_abundance(o, db, s.seed, s.mass, usearch != 0);
-    o.put('\n');
-    swa_out::sequence(o, db, s.seed, line);
-  }
+  swa_format_in_pieces(o, idx.size(), r->n >= kParallelOutputFrom, [&](BufOut & sink, size_t begin, size_t end) {
+    std::string line;
+    for (size_t i = begin; i < end; ++i) {
+      const auto & s = r->swarms[idx[i]];
+      if (s.attached) { continue; }
+      sink.put('>');
+      swa_out::id_new_abundance(sink, db, s.seed, s.mass, usearch != 0);
+      sink.put('\n');
+      swa_out::sequence(sink, db, s.seed, line);
+    }
+  });
   return SWA_OK;
 }
 
@@ -472,34 +476,38 @@ extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * d
                                    int64_t append_abundance, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend) {
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
-  swa_nw_scratch scratch;
-  uint32_t cluster_no = 0;
-  for (const auto & s : r->swarms) {
-    if (s.attached) { continue; }
-    o.str("C\t"); o.u64(cluster_no); o.put('\t'); o.u64(s.size); o.str("\t*\t*\t*\t*\t*\t");
-    swa_out::id(o, db, s.seed, usearch != 0, append_abundance);
-    o.str("\t*\n");
-    o.str("S\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[s.seed]); o.str("\t*\t*\t*\t*\t*\t");
-    swa_out::id(o, db, s.seed, usearch != 0, append_abundance);
-    o.str("\t*\n");
-    for_each_member(r, s, [&](uint32_t a) {
-      if (a == s.seed) { return; }
-      const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[a], db->seqlen[a],
-                                           db->seqs.data() + db->seq_off[s.seed], db->seqlen[s.seed], mismatch, gapopen,
-                                           gapextend, scratch);
-      const double columns = (double)scratch.ops.size();
-      const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
-      o.str("H\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[a]); o.put('\t'); o.fixed1(percentid);
-      o.str("\t+\t0\t0\t");
-      if (nwdiff > 0) { const std::string cigar = swa_cigar(scratch.ops); o.write(cigar.data(), cigar.size()); }
-      else { o.put('='); }
-      o.put('\t');
-      swa_out::id(o, db, a, usearch != 0, append_abundance);
-      o.put('\t');
-      swa_out::id(o, db, s.seed, usearch != 0, append_abundance);
-      o.put('\n');
-    });
-    ++cluster_no;
-  }
+  const std::vector<uint32_t> number = output_numbers(r);
+  // one alignment per member: by far the most expensive writer, and every swarm is independent
+  swa_format_in_pieces(o, r->swarms.size(), r->n >= kParallelUclustFrom, [&](BufOut & sink, size_t begin, size_t end) {
+    swa_nw_scratch scratch;
+    for (size_t k = begin; k < end; ++k) {
+      const auto & s = r->swarms[k];
+      if (s.attached) { continue; }
+      const uint32_t cluster_no = number[k];
+      sink.str("C\t"); sink.u64(cluster_no); sink.put('\t'); sink.u64(s.size); sink.str("\t*\t*\t*\t*\t*\t");
+      swa_out::id(sink, db, s.seed, usearch != 0, append_abundance);
+      sink.str("\t*\n");
+      sink.str("S\t"); sink.u64(cluster_no); sink.put('\t'); sink.u64(db->seqlen[s.seed]); sink.str("\t*\t*\t*\t*\t*\t");
+      swa_out::id(sink, db, s.seed, usearch != 0, append_abundance);
+      sink.str("\t*\n");
+      for_each_member(r, s, [&](uint32_t a) {
+        if (a == s.seed) { return; }
+        const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[a], db->seqlen[a],
+                                             db->seqs.data() + db->seq_off[s.seed], db->seqlen[s.seed], mismatch, gapopen,
+                                             gapextend, scratch);
+        const double columns = (double)scratch.ops.size();
+        const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
+        sink.str("H\t"); sink.u64(cluster_no); sink.put('\t'); sink.u64(db->seqlen[a]); sink.put('\t'); sink.fixed1(percentid);
+        sink.str("\t+\t0\t0\t");
+        if (nwdiff > 0) { const std::string cigar = swa_cigar(scratch.ops); sink.write(cigar.data(), cigar.size()); }
+        else { sink.put('='); }
+        sink.put('\t');
+        swa_out::id(sink, db, a, usearch != 0, append_abundance);
+        sink.put('\t');
+        swa_out::id(sink, db, s.seed, usearch != 0, append_abundance);
+        sink.put('\n');
+      });
+    }
+  });
   return SWA_OK;
 }

@@ -215,34 +215,37 @@ extern "C" int swa_dn_write_uclust(const swa_dn_result * r, const swa_hostdb * d
                                    int64_t append_abundance) {
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
-  swa_nw_scratch scratch;
-  uint32_t cluster_no = 0;
-  for (const auto & s : r->swarms) {
-    const uint32_t seed = r->order[s.begin].id;
-    o.str("C\t"); o.u64(cluster_no); o.put('\t'); o.u64(s.end - s.begin); o.str("\t*\t*\t*\t*\t*\t");
-    swa_out::id(o, db, seed, usearch != 0, append_abundance);
-    o.str("\t*\n");
-    o.str("S\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[seed]); o.str("\t*\t*\t*\t*\t*\t");
-    swa_out::id(o, db, seed, usearch != 0, append_abundance);
-    o.str("\t*\n");
-    for (uint32_t k = s.link_begin; k < s.link_end; ++k) {
-      const uint32_t hit = r->links[k].child;
-      const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[hit], db->seqlen[hit],
-                                           db->seqs.data() + db->seq_off[seed], db->seqlen[seed], r->pen_mismatch,
-                                           r->pen_gapopen, r->pen_gapextend, scratch);
-      const double columns = (double)scratch.ops.size();
-      const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
-      o.str("H\t"); o.u64(cluster_no); o.put('\t'); o.u64(db->seqlen[hit]); o.put('\t'); o.fixed1(percentid);
-      o.str("\t+\t0\t0\t");
-      if (nwdiff > 0) { const std::string cigar = swa_cigar(scratch.ops); o.write(cigar.data(), cigar.size()); }
-      else { o.put('='); }
-      o.put('\t');
-      swa_out::id(o, db, hit, usearch != 0, append_abundance);
-      o.put('\t');
-      swa_out::id(o, db, seed, usearch != 0, append_abundance);
-      o.put('\n');
+  // one alignment per member — the most expensive writer by far (the reference's is serial, too),
+  // and every swarm is independent: formatted by several threads, written in order
+  swa_format_in_pieces(o, r->swarms.size(), r->order.size() >= 200, [&](BufOut & sink, size_t begin, size_t end) {
+    swa_nw_scratch scratch;
+    for (size_t cluster_no = begin; cluster_no < end; ++cluster_no) {
+      const auto & s = r->swarms[cluster_no];
+      const uint32_t seed = r->order[s.begin].id;
+      sink.str("C\t"); sink.u64(cluster_no); sink.put('\t'); sink.u64(s.end - s.begin); sink.str("\t*\t*\t*\t*\t*\t");
+      swa_out::id(sink, db, seed, usearch != 0, append_abundance);
+      sink.str("\t*\n");
+      sink.str("S\t"); sink.u64(cluster_no); sink.put('\t'); sink.u64(db->seqlen[seed]); sink.str("\t*\t*\t*\t*\t*\t");
+      swa_out::id(sink, db, seed, usearch != 0, append_abundance);
+      sink.str("\t*\n");
+      for (uint32_t k = s.link_begin; k < s.link_end; ++k) {
+        const uint32_t hit = r->links[k].child;
+        const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[hit], db->seqlen[hit],
+                                             db->seqs.data() + db->seq_off[seed], db->seqlen[seed], r->pen_mismatch,
+                                             r->pen_gapopen, r->pen_gapextend, scratch);
+        const double columns = (double)scratch.ops.size();
+        const double percentid = 100.0 * (columns - (double)nwdiff) / columns;
+        sink.str("H\t"); sink.u64(cluster_no); sink.put('\t'); sink.u64(db->seqlen[hit]); sink.put('\t'); sink.fixed1(percentid);
+        sink.str("\t+\t0\t0\t");
+        if (nwdiff > 0) { const std::string cigar = swa_cigar(scratch.ops); sink.write(cigar.data(), cigar.size()); }
+        else { sink.put('='); }
+        sink.put('\t');
+        swa_out::id(sink, db, hit, usearch != 0, append_abundance);
+        sink.put('\t');
+        swa_out::id(sink, db, seed, usearch != 0, append_abundance);
+        sink.put('\n');
+      }
     }
-    ++cluster_no;
-  }
+  });
   return SWA_OK;
 }

@@ -3,10 +3,14 @@
 // src/db.cc:946-1026.
 #pragma once
 
+#include <algorithm>
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
+
+#include <omp.h>
 
 #include "hostdb.h"
 
@@ -57,6 +61,25 @@ class BufOut {
   bool memory_only_ = false;
   std::string buf_;
 };
+
+// Big outputs are formatted by several threads — `format(sink, begin, end)` writes items
+// [begin, end) into a memory sink — and the pieces are emitted in order, so the bytes are those of
+// the single-threaded loop.  More pieces than threads (dynamic schedule): items differ in cost
+// (swarm sizes; an alignment per member for -u).
+template <class F>
+void swa_format_in_pieces(BufOut & o, size_t items, bool parallel, F && format) {
+  const int threads = std::min(omp_get_max_threads(), 64);
+  if (!parallel || threads < 2 || items < 2) { format(o, (size_t)0, items); return; }
+  const size_t npieces = std::min<size_t>(items, (size_t)threads * 8);
+  std::vector<std::string> pieces(npieces);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (size_t p = 0; p < npieces; ++p) {
+    BufOut sink;
+    format(sink, items * p / npieces, items * (p + 1) / npieces);
+    pieces[p] = sink.take();
+  }
+  for (const auto & piece : pieces) { o.write(piece.data(), piece.size()); }
+}
 
 namespace swa_out {
 

@@ -146,9 +146,10 @@ def test_d1_uclust_byte_identical(tmp_path):
     assert filecmp.cmp(tmp_path / "o", G / "d1_uclust.o", shallow=False)
 
 
-def test_parallel_swarm_writer_equals_serial(tmp_path):
-    """-o of a big result is formatted by several threads (ranges of swarms) and written in
-    order: byte-identical to the single-threaded path (OMP_NUM_THREADS=1 in a child process)."""
+def test_parallel_writers_equal_serial(tmp_path):
+    """-o / -r / -i / -w / -u of a big result are formatted by several threads (ranges of swarms)
+    and written in order: byte-identical to the single-threaded path (OMP_NUM_THREADS=1 in a
+    child process)."""
     import subprocess
     import sys
     fa = tmp_path / "big.fa"
@@ -156,7 +157,7 @@ def test_parallel_swarm_writer_equals_serial(tmp_path):
     code = (
         "import sys, numpy as np\n"
         f"sys.path.insert(0, {str(S.ROOT)!r})\n"
-        "from swarm_amd import D1Clusters, HostDb\n"
+        "from swarm_amd import D1Clusters, HostDb, d1_write_uclust\n"
         f"hdb = HostDb({str(fa)!r})\n"
         "rng = np.random.default_rng(1)\n"
         "# a synthetic network: chains i -> i+1 inside blocks of random length (valid for the host\n"
@@ -167,7 +168,8 @@ def test_parallel_swarm_writer_equals_serial(tmp_path):
         "off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum(deg)\n"
         "nb = (np.arange(n, dtype=np.uint32) + 1)[deg == 1]\n"
         "cl = D1Clusters(hdb, off, nb)\n"
-        "cl.write_swarms(sys.argv[1]); cl.write_swarms(sys.argv[1] + '.r', mothur=True)\n")
+        "cl.write_swarms(sys.argv[1]); cl.write_swarms(sys.argv[1] + '.r', mothur=True)\n"
+        "cl.write_structure(sys.argv[1] + '.i'); cl.write_seeds(sys.argv[1] + '.w'); d1_write_uclust(cl, sys.argv[1] + '.u')\n")
     outs = []
     for threads in ("1", "4"):
         out = tmp_path / f"o{threads}"
@@ -177,7 +179,9 @@ def test_parallel_swarm_writer_equals_serial(tmp_path):
         outs.append(out)
     assert outs[0].stat().st_size > 2_000_000
     assert filecmp.cmp(outs[0], outs[1], shallow=False)
-    assert filecmp.cmp(str(outs[0]) + ".r", str(outs[1]) + ".r", shallow=False)
+    for ext in (".r", ".i", ".w", ".u"):
+        assert os.path.getsize(str(outs[0]) + ext) > 1_000_000, ext
+        assert filecmp.cmp(str(outs[0]) + ext, str(outs[1]) + ext, shallow=False), ext
 
 
 def _cluster_both_ways(hdb, off, nb, tmp_path):
