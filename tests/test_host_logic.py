@@ -52,6 +52,37 @@ def test_hostdb_matches_independent_packing(name):
     assert (hdb.nucleotides, hdb.n, hdb.longest) == tuple(int(x) for x in info.groups())
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hostdb_line_shapes_fuzz(tmp_path, seed):
+    """Sequences of every length 1..300 wrapped at random widths (the reader packs eight
+    nucleotides per turn on clean stretches and byte by byte elsewhere), lower case, U for T,
+    CR LF line ends, blank-free: against the independent Python packer."""
+    rng = np.random.default_rng(seed)
+    lines = []
+    for i in range(600):
+        L = 1 + (i % 300)
+        seq = "".join(rng.choice(list("ACGT"), size=L))
+        if rng.random() < 0.3:
+            seq = seq.lower()
+        if rng.random() < 0.3:
+            seq = seq.replace("T", "U").replace("t", "u")
+        eol = "\r\n" if rng.random() < 0.2 else "\n"
+        lines.append(f">r{i}x{seed}_{1 + int(rng.integers(0, 50))} some description{eol}")
+        width = int(rng.choice([1, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 60, 70, 1000]))
+        for at in range(0, L, width):
+            lines.append(seq[at:at + width] + eol)
+    fa = tmp_path / "shapes.fa"
+    fa.write_bytes("".join(lines).encode())
+    hdb = HostDb(fa)
+    db = S.db_from_fasta(fa)
+    assert (hdb.n, hdb.longest) == (db.n, db.longest) == (600, 300)
+    assert np.array_equal(hdb.seq_off, db.seq_off)
+    assert np.array_equal(hdb.seqs, db.seqs[:len(hdb.seqs)])
+    assert np.array_equal(hdb.seqlen, db.seqlen)
+    assert np.array_equal(hdb.abundance, db.abundance)
+    assert [hdb.header(i) for i in range(db.n)] == db.headers
+
+
 def test_hostdb_usearch_and_append_abundance():
     hdb = HostDb(G / "d1_usearch.fasta", usearch_abundance=True, append_abundance=2)
     db = S.build_db([(h, s) for h, s in S.read_fasta(G / "d1_short.fasta")])
