@@ -4,8 +4,8 @@
 // Behaviour mirrors algo_d1_run's host part (src/algod1.cc:1185-1280 clustering,
 // 214-336 grafting, 755-1095 writers) so that every output file is byte-identical.
 // Shape is this repo's own: swarms are contiguous ranges of one discovery-order array
-// (the reference threads a linked list through ampinfo[].next); a grafted light swarm
-// is a range appended to its heavy swarm's piece list.
+// (the reference threads a linked list through ampinfo[].next); the light swarms grafted onto a
+// heavy one form a chain through the swarm table.
 #include "hostdb.h"
 #include "nw_host.h"
 #include "out.h"
@@ -23,17 +23,23 @@
 
 struct swa_d1_result {
   uint32_t n = 0;
-  std::vector<uint32_t> swarmid, parent, generation;
-  std::vector<uint32_t> order;              // amplicons in discovery order, swarm after swarm
-  struct Swarm {
-    uint64_t mass = 0, sumlen = 0;
-    uint32_t seed = 0, size = 0, singletons = 0, maxgen = 0;
-    uint32_t begin = 0, end = 0;            // own members = order[begin, end)
-    bool attached = false;
-    std::vector<uint32_t> grafted;          // light swarm ids appended, in graft order
+  swa_vec<uint32_t> swarmid, parent, generation;   // (swa_vec: sized without a serial fill, see hostdb.h)
+  swa_vec<uint32_t> order;                  // amplicons in discovery order, swarm after swarm
+  struct Swarm {                            // plain data: the table of 1.6 M swarms (10 M amplicons) is filled by all threads
+    uint64_t mass, sumlen;
+    uint32_t seed, size, singletons, maxgen;
+    uint32_t begin, end;                    // own members = order[begin, end)
+    // light swarms grafted onto this one, in graft order: a chain through the swarm table
+    // (head / tail on the heavy swarm, next on each light one; the reference threads a similar
+    // list through ampinfo[].next)
+    uint32_t graft_head, graft_tail, graft_next;
+    uint32_t attached;                      // this (light) swarm hangs on another one
   };
-  std::vector<Swarm> swarms;
-  std::vector<uint32_t> graft_cand;         // per amplicon, after swa_d1_graft
+  static constexpr Swarm empty_swarm() {
+    return Swarm{0, 0, 0, 0, 0, 0, 0, 0, SWA_NO_AMPLICON, SWA_NO_AMPLICON, SWA_NO_AMPLICON, 0};
+  }
+  swa_vec<Swarm> swarms;
+  swa_vec<uint32_t> graft_cand;             // per amplicon, after swa_d1_graft
   uint64_t swarmcount_adjusted = 0;
   uint32_t largest = 0, maxgen = 0;
   std::string error;
@@ -41,10 +47,19 @@ struct swa_d1_result {
 
 namespace {
 
+// v[i] = value for all i, by all threads (first touch of a freshly sized array included)
+template <class V, class T>
+void fill_parallel(V & v, size_t n, T value) {
+  v.resize(n);
+  auto * p = v.data();
+#pragma omp parallel for schedule(static) if (n >= 100000)
+  for (int64_t i = 0; i < (int64_t)n; ++i) { p[i] = value; }
+}
+
 template <typename F>
 void for_each_member(const swa_d1_result * r, const swa_d1_result::Swarm & s, F && f) {
   for (uint32_t k = s.begin; k < s.end; ++k) { f(r->order[k]); }
-  for (uint32_t g : s.grafted) {
+  for (uint32_t g = s.graft_head; g != SWA_NO_AMPLICON; g = r->swarms[g].graft_next) {
     const auto & l = r->swarms[g];
     for (uint32_t k = l.begin; k < l.end; ++k) { f(r->order[k]); }
   }
@@ -58,7 +73,7 @@ constexpr uint32_t kParallelUclustFrom = 200;      // -u aligns every member aga
 std::vector<uint32_t> output_numbers(const swa_d1_result * r) {
   std::vector<uint32_t> number(r->swarms.size());
   uint32_t next = 0;
-  for (size_t k = 0; k < r->swarms.size(); ++k) { number[k] = next; if (!r->swarms[k].attached) { ++next; } }
+  for (size_t k = 0; k < r->swarms.size(); ++k) { number[k] = next; if (r->swarms[k].attached == 0) { ++next; } }
   return number;
 }
 
@@ -90,9 +105,19 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   const uint32_t n = db->n;
   const int64_t n64 = (int64_t)n;
   constexpr uint32_t kUnset = SWA_NO_AMPLICON;
+  const bool timing = std::getenv("SWARM_AMD_CLUSTER_TIMING") != nullptr;
+  double t_last = omp_get_wtime();
+  auto lap = [&](const char * what) {
+    if (!timing) { return; }
+    const double now = omp_get_wtime();
+    std::fprintf(stderr, "[cluster] %-24s %8.3f ms\n", what, 1000.0 * (now - t_last));
+    t_last = now;
+  };
   // 1. seed(v): push the smaller label along every edge until nothing changes
-  std::vector<uint32_t> label(n);
-  std::vector<uint8_t> active(n, 1), next_active(n, 0);
+  swa_vec<uint32_t> label(n);
+  swa_vec<uint8_t> active, next_active;
+  fill_parallel(active, n, (uint8_t)1);
+  fill_parallel(next_active, n, (uint8_t)0);
 #pragma omp parallel for schedule(static)
   for (int64_t v = 0; v < n64; ++v) { label[(size_t)v] = (uint32_t)v; }
   for (bool changed = true; changed;) {
@@ -113,42 +138,56 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
     }
     active.swap(next_active);              // (next_active is all zero again: every visited flag was cleared)
   }
+  lap("labels");
   // 2. generation(v): level-synchronous distances from the seeds inside their swarms;
   //    parent(v): smallest id of the previous level that points at v
-  std::vector<uint32_t> & gen = r->generation;
-  std::vector<uint32_t> & parent = r->parent;
+  auto & gen = r->generation;
+  auto & parent = r->parent;
 #pragma omp parallel for schedule(static)
   for (int64_t v = 0; v < n64; ++v) { gen[(size_t)v] = label[(size_t)v] == (uint32_t)v ? 0u : kUnset; parent[(size_t)v] = kUnset; }
   for (uint32_t level = 1;; ++level) {
     bool grew = false;
+    // one sweep per level: a node reached from level - 1 gets this level (possibly from several
+    // threads at once, all writing the same value) and keeps the smallest id that reached it
 #pragma omp parallel for schedule(dynamic, 8192) reduction(|| : grew)
     for (int64_t u = 0; u < n64; ++u) {
-      if (gen[(size_t)u] != level - 1) { continue; }
+      if (__atomic_load_n(&gen[(size_t)u], __ATOMIC_RELAXED) != level - 1) { continue; }   // (others may be assigning `level` right now)
       const uint32_t lu = label[(size_t)u];
       for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
         const uint32_t v = neighbours[e];
-        if (label[v] == lu && __atomic_load_n(&gen[v], __ATOMIC_RELAXED) == kUnset) {
-          __atomic_store_n(&gen[v], level, __ATOMIC_RELAXED);
+        if (label[v] != lu) { continue; }
+        const uint32_t gv = __atomic_load_n(&gen[v], __ATOMIC_RELAXED);
+        if (gv == kUnset || gv == level) {
+          if (gv == kUnset) { __atomic_store_n(&gen[v], level, __ATOMIC_RELAXED); }
+          atomic_min_u32(&parent[v], (uint32_t)u);
           grew = true;
         }
       }
     }
     if (!grew) { break; }
-#pragma omp parallel for schedule(dynamic, 8192)
-    for (int64_t u = 0; u < n64; ++u) {
-      if (gen[(size_t)u] != level - 1) { continue; }
-      const uint32_t lu = label[(size_t)u];
-      for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
-        const uint32_t v = neighbours[e];
-        if (label[v] == lu && gen[v] == level) { atomic_min_u32(&parent[v], (uint32_t)u); }
-      }
+  }
+  lap("generations + parents");
+  // 3. swarms in seed order, members by (generation, id)
+  // swarm number of every seed = number of seeds before it: per-block counts, prefix, numbering
+  swa_vec<uint32_t> sid_of_seed(n);
+  const int blocks = std::max(1, omp_get_max_threads());
+  std::vector<uint32_t> seeds_before((size_t)blocks + 1, 0);
+#pragma omp parallel for schedule(static, 1)
+  for (int b = 0; b < blocks; ++b) {
+    uint32_t c = 0;
+    for (int64_t v = n64 * b / blocks; v < n64 * (b + 1) / blocks; ++v) { c += label[(size_t)v] == (uint32_t)v ? 1u : 0u; }
+    seeds_before[(size_t)b + 1] = c;
+  }
+  for (int b = 0; b < blocks; ++b) { seeds_before[(size_t)b + 1] += seeds_before[(size_t)b]; }
+  const uint32_t nswarms = seeds_before[(size_t)blocks];
+#pragma omp parallel for schedule(static, 1)
+  for (int b = 0; b < blocks; ++b) {
+    uint32_t next = seeds_before[(size_t)b];
+    for (int64_t v = n64 * b / blocks; v < n64 * (b + 1) / blocks; ++v) {
+      if (label[(size_t)v] == (uint32_t)v) { sid_of_seed[(size_t)v] = next++; }
     }
   }
-  // 3. swarms in seed order, members by (generation, id)
-  std::vector<uint32_t> sid_of_seed(n, 0);
-  uint32_t nswarms = 0;
-  for (uint32_t v = 0; v < n; ++v) { if (label[v] == v) { sid_of_seed[v] = nswarms++; } }
-  r->swarms.resize(nswarms);
+  fill_parallel(r->swarms, nswarms, swa_d1_result::empty_swarm());
   std::vector<uint32_t> size(nswarms, 0);
 #pragma omp parallel for schedule(static)
   for (int64_t v = 0; v < n64; ++v) {
@@ -163,12 +202,14 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
     at += size[s];
     sw.end = sw.begin;                      // filled below (used as the cursor)
   }
+  lap("swarm table");
   r->order.resize(n);
 #pragma omp parallel for schedule(static)
   for (int64_t v = 0; v < n64; ++v) {
     auto & sw = r->swarms[r->swarmid[(size_t)v]];
     r->order[__atomic_fetch_add(&sw.end, 1u, __ATOMIC_RELAXED)] = (uint32_t)v;
   }
+  lap("placement");
   uint32_t largest = 0, maxgen = 0;
 #pragma omp parallel for schedule(dynamic, 1024) reduction(max : largest) reduction(max : maxgen)
   for (int64_t s = 0; s < (int64_t)nswarms; ++s) {
@@ -190,6 +231,7 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   }
   r->largest = largest;
   r->maxgen = maxgen;
+  lap("member order + sums");
 }
 
 }  // namespace
@@ -202,10 +244,10 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
   *out = r;
   const uint32_t n = db->n;
   r->n = n;
-  r->swarmid.assign(n, SWA_NO_AMPLICON);
-  r->parent.assign(n, SWA_NO_AMPLICON);
-  r->generation.assign(n, 0);
-  r->graft_cand.assign(n, SWA_NO_AMPLICON);
+  fill_parallel(r->swarmid, n, (uint32_t)SWA_NO_AMPLICON);
+  fill_parallel(r->parent, n, (uint32_t)SWA_NO_AMPLICON);
+  fill_parallel(r->generation, n, 0u);
+  fill_parallel(r->graft_cand, n, (uint32_t)SWA_NO_AMPLICON);
   // large inputs on a many-core host: the order-free formulation (SWARM_AMD_CLUSTER=serial|parallel
   // overrides the choice)
   {
@@ -231,7 +273,7 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
   for (uint32_t seed = 0; seed < n; ++seed) {
     if (r->swarmid[seed] != SWA_NO_AMPLICON) { continue; }
     const uint32_t sid = (uint32_t)r->swarms.size();
-    swa_d1_result::Swarm sw;
+    swa_d1_result::Swarm sw = swa_d1_result::empty_swarm();
     sw.seed = seed;
     sw.begin = (uint32_t)r->order.size();
     r->swarmid[seed] = sid;
@@ -272,7 +314,7 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
     sw.maxgen = gen;
     r->largest = std::max(r->largest, sw.size);
     r->maxgen = std::max(r->maxgen, sw.maxgen);
-    r->swarms.push_back(std::move(sw));
+    r->swarms.push_back(sw);
   }
   // per-amplicon results and per-swarm sums: independent gathers / scatters over `order`
   for (uint32_t k = 0; k < n; ++k) {
@@ -334,17 +376,20 @@ extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand)
   for (const uint64_t packed : pairs) {
     const uint32_t parent = (uint32_t)(packed >> 32), child = (uint32_t)packed;
     auto & light = r->swarms[r->swarmid[child]];
-    if (light.attached) {
+    if (light.attached != 0) {
       r->graft_cand[child] = SWA_NO_AMPLICON;       // this light swarm already hangs somewhere
       continue;
     }
     auto & heavy = r->swarms[r->swarmid[parent]];
-    heavy.grafted.push_back(r->swarmid[child]);
+    const uint32_t light_id = r->swarmid[child];
+    if (heavy.graft_head == SWA_NO_AMPLICON) { heavy.graft_head = light_id; }
+    else { r->swarms[heavy.graft_tail].graft_next = light_id; }
+    heavy.graft_tail = light_id;
     heavy.size += light.size;
     heavy.singletons += light.singletons;
     heavy.mass += light.mass;
     heavy.sumlen += light.sumlen;                   // maxgen untouched, like the reference
-    light.attached = true;
+    light.attached = 1;
     r->largest = std::max(r->largest, heavy.size);
     --r->swarmcount_adjusted;
     ++grafts;
@@ -362,7 +407,7 @@ extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * d
   auto format_range = [&](BufOut & sink, size_t begin, size_t end) {
     for (size_t k = begin; k < end; ++k) {
       const auto & s = r->swarms[k];
-      if (s.attached) { continue; }
+      if (s.attached != 0) { continue; }
       bool first = true;
       for_each_member(r, s, [&](uint32_t a) {
         if (mothur) { sink.put(first ? '\t' : ','); }
@@ -383,7 +428,7 @@ extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   for (const auto & s : r->swarms) {
-    if (s.attached) { continue; }
+    if (s.attached != 0) { continue; }
     o.u64(s.size); o.put('\t'); o.u64(s.mass); o.put('\t');
     swa_out::id_noabundance(o, db, s.seed, usearch != 0);
     o.put('\t'); o.u64(db->abundance[s.seed]); o.put('\t'); o.u64(s.singletons);
@@ -400,7 +445,7 @@ extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb 
   swa_format_in_pieces(o, r->swarms.size(), r->n >= kParallelOutputFrom, [&](BufOut & sink, size_t begin, size_t end) {
     for (size_t k = begin; k < end; ++k) {
       const auto & s = r->swarms[k];
-      if (s.attached) { continue; }
+      if (s.attached != 0) { continue; }
       const uint32_t cluster_no = number[k];
       for_each_member(r, s, [&](uint32_t a) {
         if (a == s.seed) { return; }
@@ -442,7 +487,7 @@ extern "C" int swa_d1_write_seeds(const swa_d1_result * r, const swa_hostdb * db
     std::string line;
     for (size_t i = begin; i < end; ++i) {
       const auto & s = r->swarms[idx[i]];
-      if (s.attached) { continue; }
+      if (s.attached != 0) { continue; }
       sink.put('>');
       swa_out::id_new_abundance(sink, db, s.seed, s.mass, usearch != 0);
       sink.put('\n');
@@ -482,7 +527,7 @@ extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * d
     swa_nw_scratch scratch;
     for (size_t k = begin; k < end; ++k) {
       const auto & s = r->swarms[k];
-      if (s.attached) { continue; }
+      if (s.attached != 0) { continue; }
       const uint32_t cluster_no = number[k];
       sink.str("C\t"); sink.u64(cluster_no); sink.put('\t'); sink.u64(s.size); sink.str("\t*\t*\t*\t*\t*\t");
       swa_out::id(sink, db, s.seed, usearch != 0, append_abundance);
