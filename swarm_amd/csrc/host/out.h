@@ -31,7 +31,11 @@ class BufOut {
   BufOut & operator=(const BufOut &) = delete;
   bool ok() const { return fp_ != nullptr; }
   void put(char c) { buf_.push_back(c); maybe_flush(); }
-  void write(const char * p, size_t n) { buf_.append(p, n); maybe_flush(); }
+  void write(const char * p, size_t n) {
+    if (!memory_only_ && n >= kFlush) { flush(); std::fwrite(p, 1, n, fp_); return; }   // big pieces go straight out
+    buf_.append(p, n);
+    maybe_flush();
+  }
   void str(const char * s) { write(s, std::strlen(s)); }
   void u64(uint64_t v) {
     char tmp[24];
