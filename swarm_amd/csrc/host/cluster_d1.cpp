@@ -366,10 +366,26 @@ extern "C" void swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, ui
 extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand) {
   // (parent << 32 | child): sorting the packed pairs is the (parent, child) order of
   // src/algod1.cc:263-271, and a plain integer sort runs on all cores
-  std::vector<uint64_t> pairs;
-  for (uint32_t i = 0; i < r->n; ++i) {
-    r->graft_cand[i] = graft_cand[i];
-    if (graft_cand[i] != SWA_NO_AMPLICON) { pairs.push_back(((uint64_t)graft_cand[i] << 32) | i); }
+  const int64_t n64 = (int64_t)r->n;
+  const int blocks = std::max(1, omp_get_max_threads());
+  std::vector<uint64_t> before((size_t)blocks + 1, 0);        // candidates in the blocks before each block
+#pragma omp parallel for schedule(static, 1)
+  for (int b = 0; b < blocks; ++b) {
+    uint64_t c = 0;
+    for (int64_t i = n64 * b / blocks; i < n64 * (b + 1) / blocks; ++i) {
+      r->graft_cand[(size_t)i] = graft_cand[i];
+      c += graft_cand[i] != SWA_NO_AMPLICON ? 1u : 0u;
+    }
+    before[(size_t)b + 1] = c;
+  }
+  for (int b = 0; b < blocks; ++b) { before[(size_t)b + 1] += before[(size_t)b]; }
+  swa_vec<uint64_t> pairs(before[(size_t)blocks]);
+#pragma omp parallel for schedule(static, 1)
+  for (int b = 0; b < blocks; ++b) {
+    uint64_t at = before[(size_t)b];
+    for (int64_t i = n64 * b / blocks; i < n64 * (b + 1) / blocks; ++i) {
+      if (graft_cand[i] != SWA_NO_AMPLICON) { pairs[at++] = ((uint64_t)graft_cand[i] << 32) | (uint64_t)i; }
+    }
   }
   __gnu_parallel::sort(pairs.begin(), pairs.end());
   uint32_t grafts = 0;
