@@ -32,7 +32,7 @@ class BufOut {
   bool ok() const { return fp_ != nullptr; }
   void put(char c) { buf_.push_back(c); maybe_flush(); }
   void write(const char * p, size_t n) {
-    if (!memory_only_ && n >= kFlush) { flush(); std::fwrite(p, 1, n, fp_); return; }   // big pieces go straight out
+    if (!memory_only_ && n >= kDirect) { flush(); std::fwrite(p, 1, n, fp_); return; }   // big pieces go straight out
     buf_.append(p, n);
     maybe_flush();
   }
@@ -58,6 +58,7 @@ class BufOut {
 
  private:
   static constexpr size_t kFlush = 1 << 20;
+  static constexpr size_t kDirect = 64 << 10;
   void maybe_flush() { if (!memory_only_ && buf_.size() >= kFlush) { flush(); } }
   void flush() { if (!buf_.empty()) { std::fwrite(buf_.data(), 1, buf_.size(), fp_); buf_.clear(); } }
   FILE * fp_ = nullptr;
