@@ -14,7 +14,8 @@ from pathlib import Path
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "lib" / "libswarm_amd.so"
+# SWARM_AMD_LIB=<path>: another build of the library (triage: tools/gpu_selfcheck.py; `make asan`)
+LIB_PATH = Path(os.environ.get("SWARM_AMD_LIB") or PKG / "lib" / "libswarm_amd.so")
 
 SWA_OK, SWA_E_DEVICE, SWA_E_ARG, SWA_E_NOMEM, SWA_E_CAPACITY, SWA_E_DUPLICATES = range(6)
 NO_AMPLICON = 0xFFFFFFFF

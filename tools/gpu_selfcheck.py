@@ -21,11 +21,8 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import support as S  # noqa: E402
-from swarm_amd import Context, capi  # noqa: E402
+from swarm_amd import Context  # noqa: E402  (SWARM_AMD_LIB is honoured by swarm_amd.capi)
 
-if os.environ.get("SWARM_AMD_LIB"):                       # triage: another build of the library
-    from pathlib import Path
-    capi.LIB_PATH = Path(os.environ["SWARM_AMD_LIB"])
 
 
 def main() -> None:
