@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+namespace { constexpr size_t kParallelOutputFrom = 200000; }   // amplicons from which -o / -w are formatted by several threads
+
 struct swa_d0_result {
   struct Cluster {
     uint64_t mass = 0;
@@ -81,14 +83,17 @@ extern "C" int swa_d0_write_swarms(const swa_d0_result * r, const swa_hostdb * d
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   if (mothur) { o.str("swarm_"); o.u64((uint64_t)differences); o.put('\t'); o.u64(r->clusters.size()); }
-  for (const auto & c : r->clusters) {
-    for (uint32_t k = 0; k < c.size; ++k) {
-      if (mothur) { o.put(k == 0 ? '\t' : ','); }
-      else if (k != 0) { o.put(' '); }
-      swa_out::id(o, db, r->members[c.begin + k], usearch != 0, append_abundance);
+  swa_format_in_pieces(o, r->clusters.size(), r->members.size() >= kParallelOutputFrom, [&](BufOut & sink, size_t begin, size_t end) {
+    for (size_t ci = begin; ci < end; ++ci) {
+      const auto & c = r->clusters[ci];
+      for (uint32_t k = 0; k < c.size; ++k) {
+        if (mothur) { sink.put(k == 0 ? '\t' : ','); }
+        else if (k != 0) { sink.put(' '); }
+        swa_out::id(sink, db, r->members[c.begin + k], usearch != 0, append_abundance);
+      }
+      if (!mothur) { sink.put('\n'); }
     }
-    if (!mothur) { o.put('\n'); }
-  }
+  });
   if (mothur) { o.put('\n'); }
   return SWA_OK;
 }
@@ -97,13 +102,16 @@ extern "C" int swa_d0_write_swarms(const swa_d0_result * r, const swa_hostdb * d
 extern "C" int swa_d0_write_seeds(const swa_d0_result * r, const swa_hostdb * db, const char * path, int usearch) {
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
-  std::string line;
-  for (const auto & c : r->clusters) {
-    o.put('>');
-    swa_out::id_new_abundance(o, db, c.seed, c.mass, usearch != 0);
-    o.put('\n');
-    swa_out::sequence(o, db, c.seed, line);
-  }
+  swa_format_in_pieces(o, r->clusters.size(), r->members.size() >= kParallelOutputFrom, [&](BufOut & sink, size_t begin, size_t end) {
+    std::string line;
+    for (size_t ci = begin; ci < end; ++ci) {
+      const auto & c = r->clusters[ci];
+      sink.put('>');
+      swa_out::id_new_abundance(sink, db, c.seed, c.mass, usearch != 0);
+      sink.put('\n');
+      swa_out::sequence(sink, db, c.seed, line);
+    }
+  });
   return SWA_OK;
 }
 

@@ -188,7 +188,7 @@ def test_parallel_writers_equal_serial(tmp_path):
     code = (
         "import sys, numpy as np\n"
         f"sys.path.insert(0, {str(S.ROOT)!r})\n"
-        "from swarm_amd import D1Clusters, HostDb, d1_write_uclust\n"
+        "from swarm_amd import D0Clusters, D1Clusters, HostDb, d1_write_uclust\n"
         f"hdb = HostDb({str(fa)!r})\n"
         "rng = np.random.default_rng(1)\n"
         "# a synthetic network: chains i -> i+1 inside blocks of random length (valid for the host\n"
@@ -200,7 +200,12 @@ def test_parallel_writers_equal_serial(tmp_path):
         "nb = (np.arange(n, dtype=np.uint32) + 1)[deg == 1]\n"
         "cl = D1Clusters(hdb, off, nb)\n"
         "cl.write_swarms(sys.argv[1]); cl.write_swarms(sys.argv[1] + '.r', mothur=True)\n"
-        "cl.write_structure(sys.argv[1] + '.i'); cl.write_seeds(sys.argv[1] + '.w'); d1_write_uclust(cl, sys.argv[1] + '.u')\n")
+        "cl.write_structure(sys.argv[1] + '.i'); cl.write_seeds(sys.argv[1] + '.w'); d1_write_uclust(cl, sys.argv[1] + '.u')\n"
+        "# d = 0 writers on a synthetic (valid) first-identical array: runs of 1..4 equal neighbours\n"
+        "first = np.arange(n, dtype=np.uint32); first -= (first % np.uint32(4)) * (rng.random(n) < 0.5)\n"
+        "first = first[first]            # idempotent: every non-seed points at a seed\n"
+        "d0 = D0Clusters(hdb, first)\n"
+        "d0.write_swarms(sys.argv[1] + '.d0o'); d0.write_seeds(sys.argv[1] + '.d0w')\n")
     outs = []
     for threads in ("1", "4"):
         out = tmp_path / f"o{threads}"
@@ -210,7 +215,7 @@ def test_parallel_writers_equal_serial(tmp_path):
         outs.append(out)
     assert outs[0].stat().st_size > 2_000_000
     assert filecmp.cmp(outs[0], outs[1], shallow=False)
-    for ext in (".r", ".i", ".w", ".u"):
+    for ext in (".r", ".i", ".w", ".u", ".d0o", ".d0w"):
         assert os.path.getsize(str(outs[0]) + ext) > 1_000_000, ext
         assert filecmp.cmp(str(outs[0]) + ext, str(outs[1]) + ext, shallow=False), ext
 
