@@ -60,10 +60,19 @@ def gen_tool() -> Path:
     return out
 
 
-def gen_fasta(n: int, length: int, seed: int) -> Path:
+def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0) -> Path:
     """The synthetic amplicon set (SURVEY.md section 8d shapes; tools/gen_amplicons.c), cached in
     the temp dir.  Sets above 2 M are generated as independent blocks of <= 2 M amplicons by
-    parallel processes (disjoint header numbers, seeds derived from `seed`) and concatenated."""
+    parallel processes (disjoint header numbers, seeds derived from `seed`) and concatenated.
+    edits > 1 (the d >= 2 sets) or light > 0 (the --fastidious sets: that fraction of abundance-1
+    amplicons 2-3 edits away from a heavy one) are one generator call whatever the size."""
+    if edits != 1 or light != 0.0:
+        fasta = Path(tempfile.gettempdir()) / f"swa_cfg_{n}x{length}_s{seed}_e{edits}_l{light}.fa"
+        if not fasta.exists():
+            tmp = fasta.with_suffix(f".tmp{os.getpid()}")
+            subprocess.run([str(gen_tool()), str(n), str(length), str(seed), str(edits), str(light), str(tmp)], check=True)
+            os.replace(tmp, fasta)
+        return fasta
     fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{length}_s{seed}.fa"
     if fasta.exists():
         return fasta

@@ -1246,11 +1246,14 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
   if (ctx->seg_cap == 0) {
     ctx->seg_cap = 512;
     while (ctx->seg_cap < 8ull * count / nseg) { ctx->seg_cap <<= 1; }
+    const char * env_cap = getenv("SWA_D1_SEG_CAP");          // test hook: start small, exercise the regrow path
+    if (env_cap != nullptr && atoi(env_cap) > 0) { ctx->seg_cap = (uint64_t)atoi(env_cap); }
   }
   constexpr uint32_t kLongRowCap = 1u << 16;
   SWA_TRY(swa_reserve(ctx, ctx->d_long_rows, (kLongRowCap + 1ull) * sizeof(uint32_t)));
   uint64_t n_edges = 0;
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  bool clean = false;                                        // the last attempt ran to the end without a retry condition
+  for (int attempt = 0; attempt < 8 && !clean; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
     SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, uint64_t(nseg) * sizeof(uint32_t), ctx->stream));
     if (ctx->anchor_usable && !stats) {
@@ -1325,9 +1328,15 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
       SWA_TRY(ensure_full_index(ctx));
       continue;
     }
-    if (got[1] <= ctx->seg_cap) { break; }
-    // one wave found more hits than its segment holds: grow the segments and run again (rare)
-    while (ctx->seg_cap < got[1]) { ctx->seg_cap <<= 1; }
+    if (got[1] <= ctx->seg_cap) { clean = true; break; }
+    // one wave found more hits than its segment holds: grow the segments and run again (rare).
+    // The small-group passes hand out work dynamically, so a wave's fill differs from run to run:
+    // twice the observed maximum, not just the maximum
+    while (ctx->seg_cap < 2 * got[1]) { ctx->seg_cap <<= 1; }
+  }
+  if (!clean) {
+    // counts[] / offsets include links the segment guards dropped: never hand that out as a result
+    return swa_fail_msg(ctx, SWA_E_DEVICE, "swa_d1_network: per-wave link segments still overflowed after 8 attempts");
   }
   *total = n_edges;
   if (n_edges > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network: neighbour buffer too small"); }

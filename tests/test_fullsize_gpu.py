@@ -1,0 +1,136 @@
+"""Full-size parity on the GPU: the bench sets (1 M x 150 = BASELINE configs[1], 10 M x 150 = the
+metric's size / configs[2]) against golden data derived from the UNMODIFIED reference
+(tests/golden/fullsize.json, written by tests/golden/make_fullsize.py in the build container).
+
+What is pinned: the md5 of the reference's -j file — every link of the d=1 network, by header, in db
+order (src/algod1.cc:755-788), i.e. the COMPLETE B1 result, not sampled rows —, the md5 of -o / -s
+(d=1) and of -o / -s / -i under --fastidious, and the fastidious counters of the log
+(src/algod1.cc:1436-1438, 1469-1472).  Plus a repeat test: the same network 20 times from reused and
+from fresh contexts, once behind deliberately poisoned device memory."""
+import hashlib
+import json
+import subprocess
+
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.gpu
+GOLD = json.loads((S.GOLDEN / "fullsize.json").read_text())
+BIN = S.ROOT / "swarm_amd" / "bin" / "swarm"
+FLAG = {"o": "-o", "s": "-s", "i": "-i", "j": "-j"}
+SIZES = [1_000_000, 10_000_000]
+
+
+def md5_of(path) -> str:
+    h = hashlib.md5()
+    with open(path, "rb") as fh:
+        while True:
+            chunk = fh.read(64 << 20)
+            if not chunk:
+                break
+            h.update(chunk)
+    return h.hexdigest()
+
+
+_fasta_checked = {}
+LIGHT = {"d1": 0.0, "d1_f": 0.3}        # the --fastidious sets carry 30 % light amplicons (BASELINE configs[2])
+
+
+def bench_fasta(n: int, run: str = "d1"):
+    """bench.py's own generator call; the file must be the one the golden data was made from."""
+    import bench
+    path = bench.gen_fasta(n, 150, 1, 1, LIGHT[run])
+    if (n, run) not in _fasta_checked:
+        _fasta_checked[(n, run)] = md5_of(path)
+    assert _fasta_checked[(n, run)] == GOLD[str(n)]["runs"][run]["fasta"]["md5"], "the generator produced a different set on this box"
+    return path
+
+
+@pytest.mark.parametrize("run", ["d1", "d1_f"])
+@pytest.mark.parametrize("n", SIZES)
+def test_cli_output_files_equal_the_reference(tmp_path, n, run):
+    gold = GOLD[str(n)]["runs"][run]
+    cmd = [str(BIN)] + gold["args"]
+    for k in gold["files"]:
+        cmd += [FLAG[k], str(tmp_path / k)]
+    cmd += ["-l", str(tmp_path / "log"), str(bench_fasta(n, run))]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for k, want in gold["files"].items():
+        assert (tmp_path / k).stat().st_size == want["bytes"], k
+        assert md5_of(tmp_path / k) == want["md5"], k
+    log = (tmp_path / "log").read_text()
+    for line in gold["log"]:                      # swarm counts; light / heavy statistics; Bloom m and k; the
+        assert line in log, line                  # variant, candidate and graft counters of the fastidious pass
+
+
+def link_checksum(off: np.ndarray, nb: np.ndarray):
+    rows = np.repeat(np.arange(len(off) - 1, dtype=np.uint64), np.diff(off).astype(np.int64))
+    v = (rows << np.uint64(32)) | nb.astype(np.uint64)
+    m = v * np.uint64(0x9E3779B97F4A7C15)
+    m ^= m >> np.uint64(29)
+    m *= np.uint64(0xBF58476D1CE4E5B9)
+    return int(len(nb)), int(np.bitwise_xor.reduce(m)) if len(m) else 0, int(m.sum(dtype=np.uint64)) if len(m) else 0
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_complete_network_equals_the_reference(tmp_path, n):
+    """B1 through the C ABI: the whole CSR, written as the -j file by the host writer, has the md5 of
+    the reference's -j file; then repeated builds (reused context, fresh contexts, one behind
+    poisoned device memory) all give that same network."""
+    import torch
+    from swarm_amd import Context, D1Clusters, HostDb
+    hdb = HostDb(bench_fasta(n))
+    ctx = Context(0)
+    ctx.upload_hostdb(hdb)
+    assert ctx.d1_index_build() is False
+    off, nb = ctx.d1_network()
+    want = link_checksum(off, nb)
+    net = D1Clusters(hdb, off, nb)
+    net.write_network(tmp_path / "j")
+    net.close()
+    gold = GOLD[str(n)]["runs"]["d1"]["files"]["j"]
+    assert (tmp_path / "j").stat().st_size == gold["bytes"]
+    assert md5_of(tmp_path / "j") == gold["md5"]
+    repeats = 20 if n <= 1_000_000 else 6
+    for r in range(repeats):                                  # the same context, index rebuilt every time
+        assert ctx.d1_index_build() is False
+        assert link_checksum(*ctx.d1_network()) == want, f"reused context, repeat {r}"
+    ctx.close()
+    for r in range(repeats):                                  # fresh contexts (fresh allocations)
+        if r == repeats // 2:
+            # poison: whatever the allocator hands out next has been 0xA5 / 0xFF, not zero
+            junk = [torch.full((1 << 28,), v, dtype=torch.uint8, device="cuda:0") for v in (0xA5, 0xFF, 0x01, 0x5A) * 8]
+            torch.cuda.synchronize()
+            del junk
+            torch.cuda.empty_cache()
+        c = Context(0)
+        c.upload_hostdb(hdb)
+        assert c.d1_index_build() is False
+        assert link_checksum(*c.d1_network()) == want, f"fresh context, repeat {r}"
+        c.close()
+
+
+def test_regrown_link_segments_give_the_same_network(tmp_path, monkeypatch):
+    """network_run's retry path: per-wave link segments that start far too small are regrown until a
+    run completes cleanly (and an unfinished retry loop is an error, never a truncated network)."""
+    from swarm_amd import Context
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 200_000, 150, 77)
+    db = S.db_from_fasta(fa)
+    ref = Context(0)
+    ref.upload_db(db.seqs, db.seq_off, db.seqlen, db.abundance, db.longest)
+    assert ref.d1_index_build() is False
+    want = ref.d1_network()
+    ref.close()
+    monkeypatch.setenv("SWA_D1_SEG_CAP", "1")
+    c = Context(0)
+    c.upload_db(db.seqs, db.seq_off, db.seqlen, db.abundance, db.longest)
+    assert c.d1_index_build() is False
+    got = c.d1_network()
+    c.close()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    woff, wnb, _ = S.oracle_d1_network(db)
+    assert np.array_equal(got[0], woff)

@@ -35,13 +35,8 @@ class Timer:
 
 
 def gen(n, length, seed, edits, light):
-    tool = ROOT / "tools" / "gen_amplicons"
-    if not tool.exists():
-        subprocess.run(["gcc", "-O2", "-o", str(tool), str(ROOT / "tools" / "gen_amplicons.c"), "-lm"], check=True)
-    fa = Path(tempfile.gettempdir()) / f"swa_cfg_{n}x{length}_s{seed}_e{edits}_l{light}.fa"
-    if not fa.exists():
-        subprocess.run([str(tool), str(n), str(length), str(seed), str(edits), str(light), str(fa)], check=True)
-    return fa
+    import bench
+    return bench.gen_fasta(n, length, seed, edits, float(light))
 
 
 def reference(fa, args, threads):
