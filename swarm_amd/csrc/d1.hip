@@ -72,6 +72,7 @@ struct NetArgs {
   const swa_task * tasks;
   uint32_t * graft;
   unsigned long long * cand_counter;
+  uint32_t fast_min_len;        // a (heavy, light) pair with both lengths >= this belongs to the pair route (d1_fast.inc)
 };
 
 #define SWA_ANCHOR_TYPES_ONLY
@@ -295,8 +296,11 @@ __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64
     if (s.hash == h) {
       ++n_match;
       const uint32_t amp = s.amp;
-      const bool allowed = SECOND || (amp != seed && (a.no_cluster_breaking != 0 || seed_abundance >= a.abundance[amp]));
-      if (allowed && a.seqlen[amp] == vlen) {
+      const uint32_t alen = a.seqlen[amp];
+      bool allowed;
+      if (SECOND) { allowed = min(a.seqlen[seed], alen) < a.fast_min_len; }
+      else { allowed = amp != seed && (a.no_cluster_breaking != 0 || seed_abundance >= a.abundance[amp]); }
+      if (allowed && alen == vlen) {
         const uint64_t * y = a.seqs + a.seq_off[amp];
         bool same = true;
         for (uint32_t w = 0; w < vnw; ++w) {
@@ -785,6 +789,8 @@ __global__ __launch_bounds__(64) void k_sort_long_rows(const uint64_t * __restri
     }
   }
 }
+
+#include "d1_fast.inc"
 
 int grid_for(const swa_ctx * ctx, uint64_t items, int per_block, int max_per_cu) {
   uint64_t blocks = (items + per_block - 1) / per_block;
@@ -1418,81 +1424,51 @@ extern "C" int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out
 }
 
 // ---- seam B2: the fastidious second pass --------------------------------------------------
-// Orchestration of algo_d1_run's fastidious branch (src/algod1.cc:1337-1467) on the GPU:
-//   pass A  table + amplicon Bloom rebuilt with the light-swarm amplicons only (1411-1412,
-//           mark_light_var's hash_insert), then every microvariant of every light amplicon
-//           clears its k pattern bits in the flexible Bloom with atomicAnd (the reference's
-//           plain `&=` from many threads can lose a bit; -t 1 is the specification);
-//   pass B  first level: every microvariant of every heavy amplicon is tested against the
-//           flexible Bloom; survivors become 16-byte tasks in HBM (batched so the task
-//           buffer can never overflow silently);
-//           second level: one wave per task re-runs the d=1 probe kernel on the materialised
-//           microvariant (k_d1_probe<MODE 1>) and atomicMin's graft_cand of each verified
-//           light amplicon — the reference's add_graft_candidate under a mutex.
+// algo_d1_run's fastidious branch (src/algod1.cc:1337-1467).  Two routes, chosen per PAIR of
+// (heavy, light) amplicons by the shorter of the two lengths:
+//   pair route  (both >= kFastMinLen; d1_fast.inc): groups by shared 32-nt windows, exact
+//               "within two edits" test per pair, exact |V1(h) ∩ V1(x)| per surviving pair;
+//   Bloom route (a sequence shorter than that; the reference's own scheme): light-only table + Bloom,
+//               every microvariant of every light amplicon clears its k pattern bits in the flexible
+//               Bloom (atomicAnd: the reference's plain `&=` from many threads can lose a bit; -t 1 is
+//               the specification), every microvariant of every heavy amplicon is tested, survivors
+//               become 16-byte tasks, one wave per task re-runs the d=1 probe (k_d1_probe<MODE 1>).
+// Both end in atomicMin on graft_cand = add_graft_candidate (src/algod1.cc:244-258) and one counter.
 extern "C" int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
                                  uint32_t * graft_cand, uint64_t * counters) {
   return swa_d1_fastidious_shard(ctx, is_light, light_nt, bloom_bits, 0, 1, graft_cand, counters);
 }
 
-extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
-                                       uint32_t shard, uint32_t nshards, uint32_t * graft_cand, uint64_t * counters) {
-  if (ctx == nullptr) { return SWA_E_ARG; }
-  if (nshards == 0 || shard >= nshards) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious_shard: bad shard"); }
-  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: call swa_d1_index_build first"); }
-  SWA_TRY(ensure_full_index(ctx));                           // the passes hash every light / heavy amplicon
-  if (is_light == nullptr || graft_cand == nullptr || counters == nullptr || bloom_bits < 2 || bloom_bits > 64) {
-    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: bad argument");
-  }
-  SWA_HIP(ctx, hipSetDevice(ctx->device));
+// fc layout (d_fcounters, u64[16]): [0] light variants [1] heavy variants [2] candidates [3] tasks of the
+// current batch [4] variants of the current batch [5] pairs found [6] short light amplicons [7] short heavy
+// amplicons [8] nucleotides of the short light amplicons [9] scratch
+static int fastidious_bloom_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_heavy, uint64_t light_nt, uint32_t bloom_bits,
+                                  uint32_t pair_route_min_len) {
   const uint32_t n = ctx->db.n;
-  // sizing: src/algod1.cc:1337-1357, 1383-1403; bloomflex.cc:91-115
+  SWA_TRY(ensure_full_index(ctx));                           // hashes of every amplicon, room for the table
   uint32_t k = static_cast<uint32_t>(0.4 * static_cast<double>(bloom_bits));
   if (k < 1) { k = 1; }
   uint64_t m = light_nt * 7ull * bloom_bits;
   if (m < 64) { m = 64; }
   const uint64_t n_bytes = ((m - 1) / 8) + 1;
   const uint64_t fsize = n_bytes >> 3;
-
-  std::vector<uint32_t> light_ids, heavy_ids;
-  for (uint32_t i = 0; i < n; ++i) { (is_light[i] != 0 ? light_ids : heavy_ids).push_back(i); }
-  if (nshards > 1) {                       // this shard's contiguous slice of the heavy amplicons
-    const uint64_t h = heavy_ids.size();
-    const uint64_t lo = h * shard / nshards, hi = h * (shard + 1ull) / nshards;
-    heavy_ids.assign(heavy_ids.begin() + (ptrdiff_t)lo, heavy_ids.begin() + (ptrdiff_t)hi);
-  }
   std::vector<uint64_t> fpat;
   swa_bloom_patterns(65536, k, fpat);
-
-  SWA_TRY(swa_reserve(ctx, ctx->d_light, n));
-  SWA_TRY(swa_reserve(ctx, ctx->d_graft, uint64_t(n) * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_bloomflex, fsize * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_fpatterns, fpat.size() * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_list_a, (light_ids.size() + 1) * sizeof(uint32_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_list_b, (heavy_ids.size() + 1) * sizeof(uint32_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_fcounters, 8 * sizeof(uint64_t)));
   const uint64_t maxv = 7ull * ctx->db.longest + 4ull;
-  uint64_t task_cap = heavy_ids.size() * maxv;
+  uint64_t task_cap = uint64_t(n_heavy) * maxv;
   const uint64_t cap_limit = (1ull << 30) / sizeof(swa_task);            // 1 GiB of tasks
   if (task_cap > cap_limit) { task_cap = cap_limit; }
   if (task_cap < maxv) { task_cap = maxv; }
   SWA_TRY(swa_reserve(ctx, ctx->d_queue, task_cap * sizeof(swa_task)));
-
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_light.ptr, is_light, n, hipMemcpyHostToDevice, ctx->stream));
   SWA_HIP(ctx, hipMemcpyAsync(ctx->d_fpatterns.ptr, fpat.data(), fpat.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-  if (!light_ids.empty()) {
-    SWA_HIP(ctx, hipMemcpyAsync(ctx->d_list_a.ptr, light_ids.data(), light_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  }
-  if (!heavy_ids.empty()) {
-    SWA_HIP(ctx, hipMemcpyAsync(ctx->d_list_b.ptr, heavy_ids.data(), heavy_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  }
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_graft.ptr, 0xFF, uint64_t(n) * sizeof(uint32_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_bloomflex.ptr, 0xFF, fsize * sizeof(uint64_t), ctx->stream));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_fcounters.ptr, 0, 8 * sizeof(uint64_t), ctx->stream));
-  ctx->d1_ready = false;                                     // the table now holds light amplicons only
+  ctx->d1_ready = false;                                     // the table now holds (short) light amplicons only
   ctx->full_index = false;
   SWA_TRY(swa_d1_rebuild_table(ctx, static_cast<const uint8_t *>(ctx->d_light.ptr)));
 
-  auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);   // [0] light var [1] heavy var [2] cand [3] tasks
+  auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);
   FlexArgs f{};
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen;
   f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
@@ -1508,21 +1484,17 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
   const size_t flex_lds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + kWaves * (size_t)(f.maxwords + 2u)) +
                           kWaves * 256 * sizeof(swa_task);
-
-  // pass A
-  swa_t0(ctx, 5);
-  if (!light_ids.empty()) {
-    f.list = static_cast<const uint32_t *>(ctx->d_list_a.ptr);
-    f.count = static_cast<uint32_t>(light_ids.size());
-    f.variant_counter = fc + 0;
+  // light side
+  f.list = static_cast<const uint32_t *>(ctx->d_list_a.ptr);
+  f.count = n_light;
+  f.variant_counter = fc + 9;                                // (the reported totals are computed for all amplicons, not here)
+  {
     const int grid = grid_for(ctx, f.count, kWaves, 8);
     if (zlds) { hipLaunchKernelGGL((k_d1_flex<true, 0>), dim3(grid), dim3(kThreads), flex_lds, ctx->stream, f); }
     else { hipLaunchKernelGGL((k_d1_flex<false, 0>), dim3(grid), dim3(kThreads), flex_lds, ctx->stream, f); }
     SWA_HIP(ctx, hipGetLastError());
   }
-  swa_t1(ctx, 5);
-
-  // pass B
+  // heavy side
   NetArgs a{};
   a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen; a.abundance = ctx->db.abundance;
   a.zobrist = f.zobrist; a.zlen = ctx->zobrist_len;
@@ -1536,21 +1508,20 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
   a.tasks = f.tasks;
   a.graft = static_cast<uint32_t *>(ctx->d_graft.ptr);
   a.cand_counter = fc + 2;
+  a.fast_min_len = pair_route_min_len;
   const size_t probe_lds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull +
                                                kWaves * ((size_t)(a.maxwords + 2u) + kQueueCap + kQueueCap / 2));
-  swa_t0(ctx, 6);
   uint64_t done = 0;
-  uint64_t heavy_variants = 0;
   uint64_t batch = task_cap / maxv;                          // cannot overflow
   double rate = -1.0;                                        // observed tasks per heavy amplicon
-  while (done < heavy_ids.size()) {
+  while (done < n_heavy) {
     uint64_t want = batch;
     if (rate >= 0.0) {                                       // optimistic sizing, overflow is detected below
       const double est = static_cast<double>(task_cap) / (4.0 * rate + 1.0);
       want = est > 4.0e9 ? 4000000000ull : static_cast<uint64_t>(est);
       if (want < batch) { want = batch; }
     }
-    if (want > heavy_ids.size() - done) { want = heavy_ids.size() - done; }
+    if (want > n_heavy - done) { want = n_heavy - done; }
     SWA_HIP(ctx, hipMemsetAsync(fc + 3, 0, 2 * sizeof(uint64_t), ctx->stream));    // tasks + batch variants
     f.list = static_cast<const uint32_t *>(ctx->d_list_b.ptr) + done;
     f.count = static_cast<uint32_t>(want);
@@ -1562,12 +1533,8 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
     uint64_t got[2] = {0, 0};
     SWA_HIP(ctx, hipMemcpyAsync(got, fc + 3, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (got[0] > task_cap) {                                 // optimistic batch did not fit: redo it smaller
-      rate = static_cast<double>(got[0]) / static_cast<double>(want);
-      continue;
-    }
     rate = static_cast<double>(got[0]) / static_cast<double>(want);
-    heavy_variants += got[1];
+    if (got[0] > task_cap) { continue; }                     // optimistic batch did not fit: redo it smaller
     if (got[0] > 0) {
       a.count = static_cast<uint32_t>(got[0]);
       const int pgrid = grid_for(ctx, a.count, kWaves, 8);
@@ -1577,14 +1544,186 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
     }
     done += want;
   }
+  return SWA_OK;
+}
+
+// LDS of k_fast_count for `waves` waves per block; 0 = does not fit
+static size_t fast_count_lds(const swa_ctx * ctx, uint32_t slots, int waves) {
+  const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
+  const size_t bytes = sizeof(uint64_t) * (4ull * ctx->zobrist_len + (size_t)waves * (2ull * (maxwords + 3u) + slots));
+  return bytes <= 160u * 1024u ? bytes : 0;
+}
+
+static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_heavy, uint32_t slots, int count_waves) {
+  const uint32_t n = ctx->db.n;
+  auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);
+  if (n_light == 0 || n_heavy == 0) { return SWA_OK; }
+  uint64_t asize = 64;
+  while (asize < 6ull * n_light) { asize <<= 1; }            // load <= 0.5 with three memberships per light amplicon
+  const uint64_t member_cap = 3ull * n_light + n_heavy;
+  const uint64_t item_cap64 = 3ull * n_light + (3ull * n_light + n_heavy) / 2 + 64;
+  const uint32_t item_cap = item_cap64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)item_cap64;
+  const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
+  SWA_TRY(swa_reserve(ctx, ctx->d_fkeys, asize * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_fcnt, asize * 5 * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_foff, (asize + 1) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_fslot, uint64_t(n) * 4 * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_fmembers, member_cap * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_fitems, uint64_t(item_cap) * sizeof(swa_fitem)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
+  if (ctx->fast_pair_cap == 0) { ctx->fast_pair_cap = 4ull * n_light + (1ull << 20); }
+  auto * keys = static_cast<unsigned long long *>(ctx->d_fkeys.ptr);
+  auto * cnt_l = static_cast<uint32_t *>(ctx->d_fcnt.ptr);
+  auto * cnt_h = cnt_l + asize, * cur_l = cnt_h + asize, * cur_h = cur_l + asize, * tot = cur_h + asize;
+  auto * offsets = static_cast<uint64_t *>(ctx->d_foff.ptr);
+  auto * lslot = static_cast<uint32_t *>(ctx->d_fslot.ptr);
+  auto * hslot = lslot + 3ull * n;
+  auto * members = static_cast<uint32_t *>(ctx->d_fmembers.ptr);
+  auto * items = static_cast<swa_fitem *>(ctx->d_fitems.ptr);
+  auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
+  auto * item_counter = dflags + 8;                          // [8] item counter, [9] key table overflow
+  uint64_t npairs = 0;
+  swa_t0(ctx, 5);
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_fpairs, ctx->fast_pair_cap * sizeof(uint64_t)));
+    SWA_HIP(ctx, hipMemsetAsync(fc + 5, 0, sizeof(uint64_t), ctx->stream));
+    SWA_HIP(ctx, hipMemsetAsync(dflags + 9, 0, sizeof(uint32_t), ctx->stream));
+    for (int type = 0; type < 3; ++type) {
+      FastGroupArgs g{};
+      g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
+      g.role = static_cast<const uint8_t *>(ctx->d_frole.ptr); g.n = n;
+      g.keys = keys; g.cnt_l = cnt_l; g.cnt_h = cnt_h; g.amask = asize - 1; g.lslot = lslot; g.hslot = hslot; g.overflow = dflags + 9;
+      const dim3 gn(grid_for(ctx, n, 256, 8)), ga(grid_for(ctx, asize, 256, 8)), b(256);
+      hipLaunchKernelGGL(k_fg_clear, ga, b, 0, ctx->stream, keys, cnt_l, cnt_h, cur_l, cur_h, asize);
+      if (type == 0) { hipLaunchKernelGGL(k_fg_light<0>, gn, b, 0, ctx->stream, g); hipLaunchKernelGGL(k_fg_heavy<0>, gn, b, 0, ctx->stream, g); }
+      else if (type == 1) { hipLaunchKernelGGL(k_fg_light<1>, gn, b, 0, ctx->stream, g); hipLaunchKernelGGL(k_fg_heavy<1>, gn, b, 0, ctx->stream, g); }
+      else { hipLaunchKernelGGL(k_fg_light<2>, gn, b, 0, ctx->stream, g); hipLaunchKernelGGL(k_fg_heavy<2>, gn, b, 0, ctx->stream, g); }
+      hipLaunchKernelGGL(k_fg_totals, ga, b, 0, ctx->stream, cnt_l, cnt_h, asize, tot);
+      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, tot, (uint32_t)asize, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
+      hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, tot, (uint32_t)asize,
+                         static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), offsets);
+      if (type == 0) { hipLaunchKernelGGL(k_fg_scatter<0>, gn, b, 0, ctx->stream, g, offsets, cur_l, cur_h, members); }
+      else if (type == 1) { hipLaunchKernelGGL(k_fg_scatter<1>, gn, b, 0, ctx->stream, g, offsets, cur_l, cur_h, members); }
+      else { hipLaunchKernelGGL(k_fg_scatter<2>, gn, b, 0, ctx->stream, g, offsets, cur_l, cur_h, members); }
+      SWA_HIP(ctx, hipMemsetAsync(item_counter, 0, sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(k_fg_items, ga, b, 0, ctx->stream, cnt_l, cnt_h, offsets, asize, items, item_counter, item_cap);
+      FastPairArgs p{};
+      p.seqs = ctx->db.seqs; p.seq_off = ctx->db.seq_off; p.seqlen = ctx->db.seqlen; p.members = members;
+      p.items = items; p.item_count = item_counter; p.item_cap = item_cap;
+      p.pairs = static_cast<unsigned long long *>(ctx->d_fpairs.ptr); p.pair_counter = fc + 5; p.pair_cap = ctx->fast_pair_cap;
+      const dim3 gp(ctx->num_cus * 8);
+      if (type == 0) { hipLaunchKernelGGL(k_fast_pairs<0>, gp, dim3(kThreads), 0, ctx->stream, p); }
+      else if (type == 1) { hipLaunchKernelGGL(k_fast_pairs<1>, gp, dim3(kThreads), 0, ctx->stream, p); }
+      else { hipLaunchKernelGGL(k_fast_pairs<2>, gp, dim3(kThreads), 0, ctx->stream, p); }
+      SWA_HIP(ctx, hipGetLastError());
+    }
+    uint64_t got = 0;
+    uint32_t fl[2] = {0, 0};
+    SWA_HIP(ctx, hipMemcpyAsync(&got, fc + 5, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipMemcpyAsync(fl, dflags + 8, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (fl[1] != 0) { return swa_fail_msg(ctx, SWA_E_DEVICE, "swa_d1_fastidious: group key table overflow"); }   // cannot happen: load <= 0.5
+    if (got <= ctx->fast_pair_cap) { npairs = got; break; }
+    if (attempt == 5) { return swa_fail_msg(ctx, SWA_E_NOMEM, "swa_d1_fastidious: pair list keeps overflowing"); }
+    ctx->fast_pair_cap = got + got / 8 + 1024;               // the count of a complete run: size for it (+ slack: none needed, it is exact)
+  }
+  swa_t1(ctx, 5);
+  swa_t0(ctx, 6);
+  if (npairs != 0) {
+    FastCountArgs c{};
+    c.seqs = ctx->db.seqs; c.seq_off = ctx->db.seq_off; c.seqlen = ctx->db.seqlen;
+    c.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
+    c.zlen = ctx->zobrist_len; c.maxwords = (ctx->db.longest + 31u) >> 5; c.slots = slots;
+    c.pairs = static_cast<const unsigned long long *>(ctx->d_fpairs.ptr); c.npairs = npairs;
+    c.graft = static_cast<uint32_t *>(ctx->d_graft.ptr); c.cand_counter = fc + 2;
+    const size_t lds = fast_count_lds(ctx, slots, count_waves);
+    uint64_t blocks = (npairs + count_waves - 1) / count_waves;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cus * 8;
+    if (blocks > max_blocks) { blocks = max_blocks; }
+    hipLaunchKernelGGL(k_fast_count, dim3((uint32_t)blocks), dim3(64 * count_waves), lds, ctx->stream, c);
+    SWA_HIP(ctx, hipGetLastError());
+  }
   swa_t1(ctx, 6);
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
+                                       uint32_t shard, uint32_t nshards, uint32_t * graft_cand, uint64_t * counters) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (nshards == 0 || shard >= nshards) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious_shard: bad shard"); }
+  if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: call swa_d1_index_build first"); }
+  if (is_light == nullptr || graft_cand == nullptr || counters == nullptr || bloom_bits < 2 || bloom_bits > 64) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_fastidious: bad argument");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_TRY(prepare_hashing(ctx));                             // the Zobrist table
+  const uint32_t n = ctx->db.n;
+  // the numbers of the reference's log line (src/algod1.cc:1337-1357, 1383-1403; bloomflex.cc:91-115)
+  uint32_t k = static_cast<uint32_t>(0.4 * static_cast<double>(bloom_bits));
+  if (k < 1) { k = 1; }
+  uint64_t m = light_nt * 7ull * bloom_bits;
+  if (m < 64) { m = 64; }
+
+  // role of every amplicon: 0 light, 1 heavy and in this shard's contiguous slice of the heavy ones, 2 neither
+  std::vector<uint8_t> role(n);
+  uint64_t n_light = 0, n_heavy_all = 0;
+  for (uint32_t i = 0; i < n; ++i) { if (is_light[i] != 0) { ++n_light; } else { ++n_heavy_all; } }
+  const uint64_t lo = n_heavy_all * shard / nshards, hi = n_heavy_all * (shard + 1ull) / nshards;
+  {
+    uint64_t seen = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (is_light[i] != 0) { role[i] = 0; }
+      else { role[i] = (seen >= lo && seen < hi) ? 1 : 2; ++seen; }
+    }
+  }
+  const uint64_t n_heavy = hi - lo;
+
+  // which pairs the pair route can take: k_fast_count's LDS set must hold the microvariants of the longest sequence
+  uint32_t slots = 1024;
+  { const uint64_t v = 7ull * ctx->db.longest + 4ull; while (slots < v + v / 2) { slots <<= 1; } }
+  int count_waves = 0;
+  for (int w : {4, 2, 1}) { if (count_waves == 0 && fast_count_lds(ctx, slots, w) != 0) { count_waves = w; } }
+  const char * env_route = getenv("SWA_FAST_BLOOM");          // test hook: the reference's scheme for every pair
+  const bool pair_route = count_waves != 0 && ctx->db.longest >= kFastMinLen && !(env_route != nullptr && env_route[0] == '1');
+  const uint32_t min_len = pair_route ? kFastMinLen : 0xFFFFFFFFu;
+
+  SWA_TRY(swa_reserve(ctx, ctx->d_frole, n));
+  SWA_TRY(swa_reserve(ctx, ctx->d_light, n));
+  SWA_TRY(swa_reserve(ctx, ctx->d_graft, uint64_t(n) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_a, (uint64_t(n) + 1) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_list_b, (uint64_t(n) + 1) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_fcounters, 16 * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_frole.ptr, role.data(), n, hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_graft.ptr, 0xFF, uint64_t(n) * sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_fcounters.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
+  auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);
+  for (int slot : {5, 6}) { ctx->ev_used[slot] = false; }
+
+  // the log's variant totals, and the amplicons that can be part of a pair with a short sequence
+  hipLaunchKernelGGL(k_fast_variant_totals, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->db.seqlen, static_cast<const uint8_t *>(ctx->d_frole.ptr), n, fc);
+  const uint32_t short_cut = pair_route ? kFastMinLen + 1u : 0xFFFFFFFFu;   // len <= cut: may pair with a sequence < kFastMinLen
+  hipLaunchKernelGGL(k_fast_short_lists, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen,
+                     static_cast<const uint8_t *>(ctx->d_frole.ptr), n, short_cut, static_cast<uint8_t *>(ctx->d_light.ptr),
+                     static_cast<uint32_t *>(ctx->d_list_a.ptr), static_cast<uint32_t *>(ctx->d_list_b.ptr), fc + 6);
+  SWA_HIP(ctx, hipGetLastError());
+  uint64_t shorts[3] = {0, 0, 0};
+  SWA_HIP(ctx, hipMemcpyAsync(shorts, fc + 6, sizeof(shorts), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (role is a host temporary, too)
+
+  if (pair_route) { SWA_TRY(fastidious_pair_route(ctx, (uint32_t)n_light, (uint32_t)n_heavy, slots, count_waves)); }
+  if (shorts[0] != 0 && shorts[1] != 0) {
+    SWA_TRY(fastidious_bloom_route(ctx, (uint32_t)shorts[0], (uint32_t)shorts[1], shorts[2], bloom_bits, min_len));
+  }
 
   uint64_t host_fc[8] = {};
   SWA_HIP(ctx, hipMemcpyAsync(host_fc, fc, sizeof(host_fc), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipMemcpyAsync(graft_cand, ctx->d_graft.ptr, uint64_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   counters[0] = host_fc[0];
-  counters[1] = heavy_variants;
+  counters[1] = host_fc[1];
   counters[2] = host_fc[2];
   counters[3] = m;
   counters[4] = k;

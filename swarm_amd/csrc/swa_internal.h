@@ -95,6 +95,10 @@ struct swa_ctx {
 
   // fastidious state
   swa_dbuf d_light, d_graft, d_bloomflex, d_fpatterns, d_queue, d_fcounters;
+  // pair route (d1_fast.inc): roles, group key table + counters, offsets, slot of every amplicon, member lists,
+  // work items, the (heavy, light) pairs within two edits
+  swa_dbuf d_frole, d_fkeys, d_fcnt, d_foff, d_fslot, d_fmembers, d_fitems, d_fpairs;
+  uint64_t fast_pair_cap = 0;
 };
 
 int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e);

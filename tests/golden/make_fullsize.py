@@ -14,7 +14,7 @@ src/algod1.cc:755-788), so its md5 pins the COMPLETE network, not a sample of ro
 
 Runs only where /root/reference was compiled (this container); minutes of CPU at 10 M.
 
-    python tests/golden/make_fullsize.py [1000000 10000000]
+    python tests/golden/make_fullsize.py [1000000 10000000] [d1 d1_f]
 """
 from __future__ import annotations
 
@@ -36,8 +36,11 @@ import support as S  # noqa: E402
 
 KEEP = re.compile(r"^(Database info|Number of swarms|Largest swarm|Max generations|Heavy swarms|Light swarms|"
                   r"Total length|Bloom filter|Generated|Heavy variants|Got|Made|Results before)")
-# run -> (swarm arguments, files kept, generator's light fraction)
-RUNS = {"d1": (["-d", "1"], "osj", 0.0), "d1_f": (["-d", "1", "-f"], "osi", 0.3)}
+# run -> (swarm arguments, files kept, generator's light fraction, reference threads).  The fastidious
+# runs use ONE thread: the reference clears Bloom bits with a plain `&=` from all its threads
+# (src/bloomflex.cc:61-64), an update can be lost, and then a candidate is missed — "Got N graft
+# candidates" (and, rarely, a graft) depends on thread timing.  -t 1 is the specification.
+RUNS = {"d1": (["-d", "1"], "osj", 0.0, 8), "d1_f": (["-d", "1", "-f"], "osi", 0.3, 1)}
 FLAG = {"o": "-o", "s": "-s", "i": "-i", "j": "-j"}
 
 
@@ -53,15 +56,19 @@ def md5_of(path: Path) -> dict:
 
 
 def main() -> None:
-    sizes = [int(a) for a in sys.argv[1:]] or [1_000_000, 10_000_000]
+    sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1_000_000, 10_000_000]
+    only = [a for a in sys.argv[1:] if a in RUNS] or list(RUNS)
     out_path = HERE / "fullsize.json"
     data = json.loads(out_path.read_text()) if out_path.exists() else {}
     for n in sizes:
-        rec = data.get(str(n), {"threads": 8, "runs": {}})
-        for name, (args, keep, light) in RUNS.items():
+        rec = data.get(str(n), {"runs": {}})
+        rec.pop("threads", None)
+        for name, (args, keep, light, threads) in RUNS.items():
+            if name not in only:
+                continue
             fasta = bench.gen_fasta(n, 150, 1, 1, light)
             with tempfile.TemporaryDirectory() as tmp:
-                cmd = list(args) + ["-t", "8"]
+                cmd = list(args) + ["-t", str(threads)]
                 for k in keep:
                     cmd += [FLAG[k], f"{tmp}/{k}"]
                 cmd += ["-l", f"{tmp}/log", str(fasta)]
@@ -71,7 +78,7 @@ def main() -> None:
                 assert r.returncode == 0, r.stderr
                 log = [ln for ln in Path(f"{tmp}/log").read_text().splitlines() if KEEP.match(ln)]
                 rec["runs"][name] = {"args": args, "generator": f"bench.gen_fasta({n}, 150, 1, 1, {light})",
-                                     "fasta": md5_of(fasta), "reference_seconds_t8_here": round(dt, 2),
+                                     "fasta": md5_of(fasta), "reference_threads": threads, "reference_seconds_here": round(dt, 2),
                                      "files": {k: md5_of(Path(f"{tmp}/{k}")) for k in keep}, "log": log}
                 print(n, name, f"{dt:.1f} s", flush=True)
         data[str(n)] = rec

@@ -1,0 +1,102 @@
+"""The identities the GPU's pair route for --fastidious rests on (swarm_amd/csrc/d1_fast.inc), checked
+on the CPU against the oracle (which is pinned to the reference):
+
+  * generate_variants (src/variants.cc:184-249) lists DISTINCT sequences: exactly the set V1(s) of
+    sequences one edit away from s, |V1(s)| = 6 L + 4 + runs(s);
+  * graft candidates (src/algod1.cc:244-258, 339-450) = sum over (heavy h, light x) of |V1(h) & V1(x)|,
+    graft_cand[x] = the smallest h with a non-empty intersection, non-empty <=> edit distance <= 2;
+  * two sequences of >= 112 nt within two edits share their first 32 nt, or their last 32, or the window
+    [40, 72) of one equals the window at 39 / 40 / 41 of the other."""
+import numpy as np
+
+import support as S
+
+
+def v1(s: str) -> set:
+    out = set()
+    for p in range(len(s)):
+        for b in "ACGT":
+            if b != s[p]:
+                out.add(s[:p] + b + s[p + 1:])
+        out.add(s[:p] + s[p + 1:])
+    for p in range(len(s) + 1):
+        for b in "ACGT":
+            out.add(s[:p] + b + s[p:])
+    out.discard(s)
+    return out
+
+
+def runs(s: str) -> int:
+    return 1 + sum(1 for p in range(1, len(s)) if s[p] != s[p - 1])
+
+
+def test_generate_variants_lists_distinct_sequences():
+    rng = np.random.default_rng(5)
+    lib = S.oracle()
+    tab = S.oracle_zobrist(80)
+    for t in range(400):
+        L = int(rng.integers(1, 60))
+        s = "".join(rng.choice(list("AC" if t % 2 else "ACGT"), L))
+        w = S.pack_seq(s.encode())
+        h = lib.orc_zobrist_hash(S._p(tab, S.u64p), S._p(w, S.u64p), L)
+        got = S.oracle_variants(tab, w, L, h)
+        assert len(got) == len(v1(s)) == 6 * L + 4 + runs(s)
+        assert len({g[0] for g in got}) == len(got)
+
+
+def test_candidates_are_intersections_of_microvariant_sets(tmp_path):
+    fa = tmp_path / "f.fa"
+    S.gen_fasta(fa, 600, 36, 91, 1, 0.4)
+    recs = S.read_fasta(fa)
+    db = S.build_db(recs)
+    seqs = ["".join("ACGT"[int(c)] for c in ((db.words(i)[p >> 5] >> np.uint64((p & 31) * 2)) & np.uint64(3)
+                                            for p in range(int(db.seqlen[i])))) for i in range(db.n)]
+    rng = np.random.default_rng(1)
+    is_light = (db.abundance <= 1).astype(np.uint8)
+    is_light[rng.integers(0, db.n, 20)] ^= 1            # any split is a valid input of the seam
+    graft, counters = S.oracle_fastidious(db, is_light)
+    sets = [v1(s) for s in seqs]
+    want = np.full(db.n, 0xFFFFFFFF, dtype=np.uint32)
+    cand = 0
+    for x in np.flatnonzero(is_light):
+        for h in np.flatnonzero(is_light == 0):
+            if abs(len(seqs[x]) - len(seqs[h])) > 2:
+                continue
+            c = len(sets[x] & sets[h])
+            if c:
+                cand += c
+                want[x] = min(want[x], h)
+    assert cand == int(counters[2]) and cand > 0
+    assert np.array_equal(want, graft)
+    assert int(counters[0]) == sum(len(sets[i]) for i in np.flatnonzero(is_light))
+    assert int(counters[1]) == sum(len(sets[i]) for i in np.flatnonzero(is_light == 0))
+
+
+def test_two_edits_leave_a_shared_window():
+    rng = np.random.default_rng(9)
+
+    def edit(s):
+        p = int(rng.integers(0, len(s) + 1))
+        k = int(rng.integers(0, 3))
+        if k == 0 and p < len(s):
+            return s[:p] + str(rng.choice(list("ACGT"))) + s[p + 1:]
+        if k == 1 and p < len(s):
+            return s[:p] + s[p + 1:]
+        return s[:p] + str(rng.choice(list("ACGT"))) + s[p:]
+
+    seen_classes = set()
+    for t in range(20000):
+        L = int(rng.integers(114, 200))
+        alphabet = "ACGT" if t % 3 else "AC"
+        h = "".join(rng.choice(list(alphabet), L))
+        x = edit(edit(h))
+        if len(x) < 112 or len(h) < 112:
+            continue
+        if h[:32] == x[:32]:
+            seen_classes.add("P")
+        elif h[-32:] == x[-32:]:
+            seen_classes.add("S")
+        else:
+            seen_classes.add("M")
+            assert h[40:72] in (x[39:71], x[40:72], x[41:73]), (h, x)
+    assert seen_classes == {"P", "S", "M"}
