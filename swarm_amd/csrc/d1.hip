@@ -836,6 +836,12 @@ static bool anchor_applicable(const swa_ctx * ctx) {
   return anchored_enabled() && ctx->db.longest >= kMinAnchoredLen && ctx->db.longest <= 64u * kPrefetchWords * 32u - 64u;
 }
 
+// work items of an index: big ones (64-seed chunks of groups of 65..2048: fewer than n / 32) at the start of
+// d_aitems, small ones (chunks of groups of 2..64: at most n / 2 + n / kSmallChunkPrefix) from here on
+static uint64_t small_items_at(uint32_t n) { return uint64_t(n) / 8 + 32; }
+constexpr uint32_t kSmallChunkPrefix = 16;  // prefix pass: seeds per small item (a seed walks its whole sequence)
+constexpr uint32_t kSmallChunkSuffix = 64;  // suffix pass: 32 positions per seed, the table build dominates: no split
+
 // (re)builds the two anchor indexes for the query range [first, first + count)
 static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   ctx->anchor_ready = false;
@@ -854,7 +860,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     SWA_TRY(swa_reserve(ctx, ctx->d_aoffsets[which], (asize + 1) * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aslot[which], uint64_t(n) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_amembers[which], uint64_t(n) * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], (uint64_t(n) + 128) * sizeof(swa_item)));   // big | small halves
+    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], (uint64_t(n) + 128) * sizeof(swa_item)));   // big (n/8 + 32) | small
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
   const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
@@ -914,7 +920,8 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
                        static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
                        static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr), acounters + which,
-                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + (ctx->db.n / 2 + 64), acounters + 3 + which);
+                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + small_items_at(ctx->db.n), acounters + 3 + which,
+                       which == 0 ? kSmallChunkPrefix : kSmallChunkSuffix);
   }
   SWA_HIP(ctx, hipGetLastError());
   for (int pass = 0; pass < 2; ++pass) {
@@ -937,9 +944,10 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + 2 * kPend);   // in u64 units
     const int grid = ctx->num_cus * 8;
     // small groups: one wave per group
-    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr) + (ctx->db.n / 2 + 64);
+    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr) + small_items_at(ctx->db.n);
     a.item_count = acounters + 3 + pass;
     a.sched = acounters + 16 + 8 * pass;
+    a.small_chunk = pass == 0 ? kSmallChunkPrefix : kSmallChunkSuffix;
     a.table_slots = 2 * kSmallGroup;
     const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom
     if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
@@ -1088,13 +1096,13 @@ static int build_owned_index(swa_ctx * ctx, bool * needs_table) {
   hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                      static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
                      asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
-                     static_cast<swa_item *>(ctx->d_aitems[0].ptr) + (n / 2 + 64), acounters + 3);
+                     static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
   DupArgs da{};
   da.seqs = ctx->db.seqs; da.seq_off = ctx->db.seq_off; da.seqlen = ctx->db.seqlen;
   da.seqhash = static_cast<const uint64_t *>(ctx->d_seqhash.ptr);
   da.members = static_cast<const uint32_t *>(ctx->d_amembers[0].ptr);
   da.flag = dflags;
-  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + (n / 2 + 64);
+  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n);
   da.item_count = acounters + 3;
   hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
   da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);
@@ -1144,7 +1152,9 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
 
   bool owned_ok = false;                                    // served without the database-wide table
   uint32_t group_dups = 0;
-  if (ctx->owner_world > 1 && ctx->anchor_usable && owned_index_enabled()) {
+  // The lean build (no database-wide table / Bloom / table-based duplicate check) serves a single GPU as well
+  // as a rank of a multi-GPU job: with world = 1 this GPU owns every anchor group.
+  if (ctx->anchor_usable && owned_index_enabled()) {
     bool needs_table = false;
     SWA_TRY(build_owned_index(ctx, &needs_table));
     owned_ok = !needs_table;
@@ -1444,7 +1454,6 @@ extern "C" int swa_d1_fastidious(swa_ctx * ctx, const uint8_t * is_light, uint64
 // amplicons [8] nucleotides of the short light amplicons [9] scratch
 static int fastidious_bloom_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_heavy, uint64_t light_nt, uint32_t bloom_bits,
                                   uint32_t pair_route_min_len) {
-  const uint32_t n = ctx->db.n;
   SWA_TRY(ensure_full_index(ctx));                           // hashes of every amplicon, room for the table
   uint32_t k = static_cast<uint32_t>(0.4 * static_cast<double>(bloom_bits));
   if (k < 1) { k = 1; }
