@@ -134,6 +134,7 @@ static int check_view(swa_ctx * ctx, const swa_db_view * v) {
 static void invalidate(swa_ctx * ctx) {
   ctx->d1_ready = false;
   ctx->full_index = false;
+  ctx->aux_complete = false;
   ctx->anchor_ready = false;
   ctx->qgram_ready = false;
   ctx->scan_ready = false;

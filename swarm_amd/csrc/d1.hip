@@ -1075,7 +1075,7 @@ static int ensure_full_index(swa_ctx * ctx) {
 // those members only, duplicates inside the owned prefix groups.  *needs_table is set when some
 // seed can only be served by the plain kernel (a sequence shorter than 65 nt anywhere, a group
 // too large for LDS) or the db order does not hold: the caller then builds the full index.
-static int build_owned_index(swa_ctx * ctx, bool * needs_table) {
+static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool * needs_table) {
   const uint32_t n = ctx->db.n;
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
   SWA_TRY(prepare_hashing(ctx));
@@ -1102,6 +1102,10 @@ static int build_owned_index(swa_ctx * ctx, bool * needs_table) {
   da.seqhash = static_cast<const uint64_t *>(ctx->d_seqhash.ptr);
   da.members = static_cast<const uint32_t *>(ctx->d_amembers[0].ptr);
   da.flag = dflags;
+  // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair is
+  // seen by exactly one rank); a single GPU honours the slice it was asked about
+  da.first = ctx->owner_world > 1 ? 0u : first;
+  da.count = ctx->owner_world > 1 ? n : count;
   da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n);
   da.item_count = acounters + 3;
   hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
@@ -1132,6 +1136,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   ctx->d1_ready = false;
   ctx->anchor_ready = false;
   ctx->full_index = false;
+  ctx->aux_complete = false;
   for (int slot : {0, 1, 2, 7}) { ctx->ev_used[slot] = false; }   // phases this build does not run report 0
   ctx->table_size = swa_hashtable_size(n);
   const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
@@ -1156,8 +1161,9 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   // as a rank of a multi-GPU job: with world = 1 this GPU owns every anchor group.
   if (ctx->anchor_usable && owned_index_enabled()) {
     bool needs_table = false;
-    SWA_TRY(build_owned_index(ctx, &needs_table));
+    SWA_TRY(build_owned_index(ctx, first, count, &needs_table));
     owned_ok = !needs_table;
+    ctx->aux_complete = owned_ok && ctx->owner_world == 1;
     SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!owned_ok) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream)); }
@@ -1388,7 +1394,7 @@ extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world
     ctx->owner_world = world;
     ctx->anchor_ready = false;                               // the next network call indexes this rank's groups
     ctx->anchor_slack = 0;
-    if (!ctx->full_index) { ctx->d1_ready = false; }         // hashes exist for the previous owner's groups only
+    if (!ctx->full_index && !ctx->aux_complete) { ctx->d1_ready = false; }   // hashes exist for the previous owner's groups only
   }
   return SWA_OK;
 }

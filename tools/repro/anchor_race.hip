@@ -193,7 +193,7 @@ int main(int argc, char ** argv) {
         k_scan_apply<<<tiles, kScanBlock, 0, stream>>>(a.counts[which], (uint32_t)asize, a.scan_tmp, a.offsets[which]);
         k_anchor_scatter<<<grid(n), 256, 0, stream>>>(a.slot_of[which], n, a.offsets[which], a.cursor[which], a.members[which]);
         k_anchor_items<<<grid(asize), 256, 0, stream>>>(a.counts[which], a.offsets[which], asize, a.items[which], a.acounters + which,
-                                                       a.items[which] + (n / 2 + 64), a.acounters + 3 + which);
+                                                       a.items[which] + (n / 2 + 64), a.acounters + 3 + which, 64u);
       }
       CK(hipGetLastError());
       CK(hipStreamSynchronize(stream));
