@@ -225,6 +225,25 @@ int swa_scan_fetch(swa_ctx * ctx, uint32_t * hit_seedidx, uint32_t * hit_ids, ui
 /* out3 = {q-gram comparisons, aligned pairs, launch sequences} since swa_scan_begin */
 int swa_scan_totals(swa_ctx * ctx, uint64_t * out3);
 
+/* ---- B3 + B4 in bulk: the whole d >= 2 search as ONE graph --------------------------------
+   Everything qgram_diff_fast + search_do can ever answer during algo_run (src/algo.cc:423-602: per seed
+   and sub-seed, the pool amplicons with q-gram bound <= d and alignment diff <= d) depends only on the
+   pair, not on the pool, so it is computed for the whole database at once:
+     row q of the CSR = every target t != q with diff(query q, target t) <= d that the abundance rule
+     allows q to take (abundance[t] <= abundance[q], or all with no_cluster_breaking), ascending t,
+     diffs[e] = that diff (the reference's value, src/algo.cc:460, 554).
+   The caller's greedy loop then needs no further device call.  Candidate pairs come from d + 1 disjoint
+   windows per sequence (an alignment with <= d differences leaves one of them intact, shifted by at most
+   d), which every sequence must have room for: swa_dn_graph_supported != 0 (else use swa_scan_*).
+   Requires swa_qgram_build and swa_search_begin.  Buffers as swa_d1_network: offsets[n + 1] always
+   filled, *total = entries needed, SWA_E_CAPACITY when total > cap (call again with room: nothing is
+   recomputed). */
+int swa_dn_graph_supported(swa_ctx * ctx);
+int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint8_t * diffs,
+                 uint64_t cap, uint64_t * total);
+/* out3 = {q-gram comparisons, aligned pairs, kernel launches} of the last swa_dn_graph */
+int swa_dn_graph_totals(swa_ctx * ctx, uint64_t * out3);
+
 #ifdef __cplusplus
 }
 #endif

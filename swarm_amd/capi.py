@@ -438,7 +438,8 @@ class Context:
 
 _DN_EXPORTS = ["swa_dn_cluster", "swa_dn_result_free", "swa_dn_result_error", "swa_dn_result_summary",
                "swa_dn_write_swarms", "swa_dn_write_stats", "swa_dn_write_structure", "swa_dn_write_seeds",
-               "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_batch", "swa_scan_fetch", "swa_scan_totals"]
+               "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_batch", "swa_scan_fetch", "swa_scan_totals",
+               "swa_dn_graph_supported", "swa_dn_graph", "swa_dn_graph_totals"]
 EXPORTS.extend(_DN_EXPORTS)
 
 
@@ -499,9 +500,15 @@ class DnClusters:
         return {"swarms": int(out[0]), "largest": int(out[1]), "maxgen": int(out[2])}
 
     def scan_totals(self) -> dict:
+        """Work counters of the route that ran: the bulk graph (swa_dn_graph) or the fused scan (swa_scan_*)."""
         out = np.zeros(3, dtype=np.uint64)
+        self.lib.swa_dn_graph_totals.argtypes = [C.c_void_p, u64p]
+        self.lib.swa_dn_graph_supported.argtypes = [C.c_void_p]
+        if self.lib.swa_dn_graph_supported(self.ctx.h) and os.environ.get("SWARM_AMD_DN") != "scan":
+            self.ctx._check(self.lib.swa_dn_graph_totals(self.ctx.h, _p64(out)))
+            return {"route": "graph", "qgram_comparisons": int(out[0]), "aligned_pairs": int(out[1]), "launch_sequences": int(out[2])}
         self.ctx._check(self.lib.swa_scan_totals(self.ctx.h, _p64(out)))
-        return {"qgram_comparisons": int(out[0]), "aligned_pairs": int(out[1]), "launch_sequences": int(out[2])}
+        return {"route": "scan", "qgram_comparisons": int(out[0]), "aligned_pairs": int(out[1]), "launch_sequences": int(out[2])}
 
     def write_swarms(self, path, mothur=False, usearch=False, append_abundance=0) -> None:
         assert self.lib.swa_dn_write_swarms(self.h, self.hdb.h, str(path).encode(), int(mothur), int(usearch),

@@ -506,6 +506,7 @@ extern "C" int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapop
   ctx->pen_gapextend = gapextend;
   ctx->resolution = d;
   ctx->search_ready = true;
+  ctx->dn_graph_ready = false;                               // (penalties / d define the graph of dn_graph.hip)
   // Wavefront fast path (k_align_wfa): usable when every cost <= T has one decomposition only
   // into (non-identical columns, gap columns) — see the comment above the kernel.
   ctx->wfa_steps = 0;

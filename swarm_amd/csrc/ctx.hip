@@ -79,7 +79,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_acursor[0], &ctx->d_acursor[1], &ctx->d_aoffsets[0], &ctx->d_aoffsets[1], &ctx->d_aslot[0],
                        &ctx->d_aslot[1], &ctx->d_amembers[0], &ctx->d_amembers[1], &ctx->d_aitems[0], &ctx->d_aitems[1],
                        &ctx->d_frole, &ctx->d_fkeys, &ctx->d_fcnt, &ctx->d_foff, &ctx->d_fslot, &ctx->d_fmembers, &ctx->d_fitems,
-                       &ctx->d_fpairs}) {
+                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals}) {
     swa_release(*b);
   }
   if (ctx->h_scan_pinned != nullptr) { (void)hipHostFree(ctx->h_scan_pinned); }
@@ -138,6 +138,8 @@ static void invalidate(swa_ctx * ctx) {
   ctx->anchor_ready = false;
   ctx->qgram_ready = false;
   ctx->scan_ready = false;
+  ctx->dn_graph_ready = false;
+  ctx->dn_shortest = 0;
 }
 
 extern "C" int swa_db_upload(swa_ctx * ctx, const swa_db_view * h) {

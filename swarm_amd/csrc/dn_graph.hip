@@ -1,0 +1,585 @@
+// dn_graph.hip — d >= 2 in BULK: every ordered pair (query, target) of amplicons whose alignment has at
+// most d differences, as one CSR, without the greedy loop.
+//
+// The reference (src/algo.cc:384-602) interleaves the search with the clustering: one q-gram scan +
+// alignment call per seed and sub-seed, against the shrinking pool — ~120 k dependent steps for 1 M
+// amplicons, each a few kernels and a host round trip, which is what bounded the fused scan of
+// scan.hip at 3 % of the HBM roofline.  But which pairs are within d differences does not depend on
+// the pool (scan.hip's batching already relies on that), the abundance rule is a property of the
+// pair, and the triangle-inequality prune (src/algo.cc:521-522) only skips pairs that cannot match.
+// So the whole search is a function of the database:  G = { (q, t, diff(q, t)) : diff <= d }  —
+// the same object as the d = 1 network, and the clustering becomes the host walk over it
+// (cluster_dn.cpp), exactly like d = 1.
+//
+// Finding the pairs without comparing everything with everything: an alignment with <= d
+// non-identical columns is <= d edits, so of d + 1 disjoint windows of the query (W nucleotides at
+// offsets 0, W, 2W, ...) at least one is untouched, and it reappears in the target shifted by the net
+// indels before it, -d .. +d.  Every amplicon is filed as a TARGET under its windows at all those
+// shifts and looks itself up as a QUERY under its unshifted windows ("groups", one window at a
+// time); inside a group every (query < target) pair goes through: length difference, "not already
+// found through an earlier window", the q-gram bound (src/qgram.cc:68-96, B3) — survivors are
+// aligned by the B4 kernels (align.hip) in the direction(s) the abundance rule allows, and the
+// accepted (query, target, diff) triples are sorted into a CSR (rocPRIM radix sort).
+//
+// Applies when every sequence holds d + 1 windows of 32 (or 16) nucleotides; otherwise the fused
+// scan of scan.hip serves (swa_dn_graph_supported).  HBM traffic: group bookkeeping (a few tens of
+// bytes per amplicon and window) + the members' sequences and signatures, mostly from L2.
+#include "swa_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <vector>
+
+int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, const uint32_t * d_targets,
+                     const uint32_t * d_count, uint32_t max_count, uint32_t * d_diffs, uint32_t * d_scores,
+                     uint32_t * d_alnlens);
+
+namespace {
+
+constexpr uint32_t kEmpty = SWA_NO_AMPLICON;
+constexpr uint64_t kKeyEmpty = ~0ull;
+constexpr uint32_t kTile = 4096;          // (query, target) pairs per turn of a wave
+constexpr uint32_t kStride = 64;          // a group's tiles are dealt round-robin to at most this many items
+constexpr uint32_t kStage = 256;          // per-wave staging of found pairs
+constexpr int kMaxShifts = 17;            // 2 d + 1 for d <= 8
+
+struct dg_item { uint32_t begin, nt, nq, tile; };   // members[begin, begin+nt) targets, then nq queries
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+
+// `wlen` (<= 32) nucleotides from position pos on (may read the following word: the database ends in zero words)
+__device__ __forceinline__ uint64_t window(const uint64_t * seq, uint32_t pos, uint32_t wlen) {
+  const uint32_t w = pos >> 5, sh = (pos & 31u) << 1;
+  uint64_t v = seq[w] >> sh;
+  if (sh != 0u) { v |= seq[w + 1] << (64u - sh); }
+  return wlen >= 32u ? v : (v & ((1ull << (2u * wlen)) - 1ull));
+}
+
+__device__ __forceinline__ uint64_t window_key(uint64_t w, uint32_t k) {
+  return mix64(w ^ (0xA24BAED4963EE407ull * (uint64_t)(k + 1u))) & 0x7FFFFFFFFFFFFFFFull;
+}
+
+struct GroupArgs {
+  const uint64_t * seqs;
+  const uint64_t * seq_off;
+  const uint32_t * seqlen;
+  uint32_t n, d, k, wlen;        // window k at offset k * wlen
+  unsigned long long * keys;
+  uint32_t * cnt_t, * cnt_q;
+  uint64_t amask;
+  uint32_t * tslot;              // [n * (2 d + 1)]
+  uint32_t * qslot;              // [n]
+  uint32_t * overflow;
+};
+
+__global__ __launch_bounds__(256) void k_dg_clear(unsigned long long * keys, uint32_t * c0, uint32_t * c1, uint32_t * c2, uint32_t * c3,
+                                                  uint64_t asize) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < asize; i += (uint64_t)gridDim.x * blockDim.x) {
+    keys[i] = kKeyEmpty; c0[i] = 0u; c1[i] = 0u; c2[i] = 0u; c3[i] = 0u;
+  }
+}
+
+// every amplicon is a target under its window k at the shifts -d .. +d
+__global__ __launch_bounds__(256) void k_dg_targets(const GroupArgs a) {
+  const uint32_t ns = 2u * a.d + 1u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+    const uint32_t len = a.seqlen[i];
+    const uint64_t * s = a.seqs + a.seq_off[i];
+    uint64_t seen[kMaxShifts];
+    for (uint32_t j = 0; j < ns; ++j) {
+      uint32_t slot = kEmpty;
+      const int64_t pos = (int64_t)a.k * a.wlen + (int64_t)j - (int64_t)a.d;
+      seen[j] = kKeyEmpty;
+      if (pos >= 0 && (uint64_t)pos + a.wlen <= len) {
+        const uint64_t key = window_key(window(s, (uint32_t)pos, a.wlen), a.k);
+        bool repeat = false;                                  // (low complexity: the same window at two shifts — one membership)
+        for (uint32_t q = 0; q < j; ++q) { repeat = repeat || seen[q] == key; }
+        seen[j] = key;
+        if (!repeat) {
+          uint64_t idx = mix64(key) & a.amask;
+          bool placed = false;
+          for (uint64_t probes = 0; probes <= a.amask; ++probes) {
+            const unsigned long long old = atomicCAS(&a.keys[idx], kKeyEmpty, (unsigned long long)key);
+            if (old == kKeyEmpty || old == key) { placed = true; break; }
+            idx = (idx + 1) & a.amask;
+          }
+          if (placed) { atomicAdd(&a.cnt_t[idx], 1u); slot = (uint32_t)idx; }
+          else { *a.overflow = 1u; }
+        }
+      }
+      a.tslot[(uint64_t)i * ns + j] = slot;
+    }
+  }
+}
+
+// ... and a query under the unshifted window (its own target entry at shift 0 made the group)
+__global__ __launch_bounds__(256) void k_dg_queries(const GroupArgs a) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+    const uint64_t key = window_key(window(a.seqs + a.seq_off[i], a.k * a.wlen, a.wlen), a.k);
+    uint64_t idx = mix64(key) & a.amask;
+    uint32_t slot = kEmpty;
+    for (uint64_t probes = 0; probes <= a.amask; ++probes) {
+      const unsigned long long have = a.keys[idx];
+      if (have == key) { atomicAdd(&a.cnt_q[idx], 1u); slot = (uint32_t)idx; break; }
+      if (have == kKeyEmpty) { break; }
+      idx = (idx + 1) & a.amask;
+    }
+    a.qslot[i] = slot;
+  }
+}
+
+// room in the member list only for groups with a pair of DIFFERENT amplicons (an amplicon alone is its own target)
+__global__ __launch_bounds__(256) void k_dg_totals(const uint32_t * __restrict__ cnt_t, const uint32_t * __restrict__ cnt_q,
+                                                   uint64_t asize, uint32_t * __restrict__ tot) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < asize; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t t = cnt_t[i], q = cnt_q[i];
+    tot[i] = t * q >= 2 ? (uint32_t)(t + q) : 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dg_scatter(const GroupArgs a, const uint32_t * __restrict__ tot,
+                                                    const uint64_t * __restrict__ offsets, uint32_t * cur_t, uint32_t * cur_q,
+                                                    uint32_t * __restrict__ members) {
+  const uint32_t ns = 2u * a.d + 1u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+    for (uint32_t j = 0; j < ns; ++j) {
+      const uint32_t s = a.tslot[(uint64_t)i * ns + j];
+      if (s != kEmpty && tot[s] != 0u) { members[offsets[s] + atomicAdd(&cur_t[s], 1u)] = i; }
+    }
+    const uint32_t s = a.qslot[i];
+    if (s != kEmpty && tot[s] != 0u) { members[offsets[s] + a.cnt_t[s] + atomicAdd(&cur_q[s], 1u)] = i; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dg_items(const uint32_t * __restrict__ cnt_t, const uint32_t * __restrict__ cnt_q,
+                                                  const uint32_t * __restrict__ tot, const uint64_t * __restrict__ offsets,
+                                                  uint64_t asize, dg_item * items, uint32_t * counter, uint32_t cap) {
+  __shared__ uint32_t n_items, base;
+  if (threadIdx.x == 0) { n_items = 0u; }
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t start = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  auto items_of = [&](uint64_t s) -> uint32_t {
+    if (tot[s] == 0u) { return 0u; }
+    const uint64_t tiles = ((uint64_t)cnt_t[s] * cnt_q[s] + kTile - 1) / kTile;
+    return (uint32_t)(tiles < kStride ? tiles : kStride);
+  };
+  for (uint64_t s = start; s < asize; s += stride) {
+    const uint32_t k = items_of(s);
+    if (k != 0u) { atomicAdd(&n_items, k); }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { base = n_items != 0u ? atomicAdd(counter, n_items) : 0u; n_items = 0u; }
+  __syncthreads();
+  for (uint64_t s = start; s < asize; s += stride) {
+    const uint32_t k = items_of(s);
+    if (k == 0u) { continue; }
+    const uint32_t at = base + atomicAdd(&n_items, k);
+    dg_item it;
+    it.begin = (uint32_t)offsets[s]; it.nt = cnt_t[s]; it.nq = cnt_q[s];
+    for (uint32_t t = 0; t < k; ++t) { it.tile = t; if (at + t < cap) { items[at + t] = it; } }
+  }
+}
+
+struct PairArgs {
+  const uint64_t * seqs;
+  const uint64_t * seq_off;
+  const uint32_t * seqlen;
+  const ulonglong2 * sigs;       // q-gram signatures, 8 x 16 bytes per amplicon
+  const uint32_t * members;
+  const dg_item * items;
+  const uint32_t * item_count;
+  uint32_t item_cap;
+  uint32_t d, k, wlen;
+  unsigned long long * pairs;    // (query << 32) | target, query < target
+  unsigned long long * counters; // [0] pairs [1] q-gram comparisons
+  uint64_t pair_cap;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+  const int lo = __shfl((int)(uint32_t)v, src, 64);
+  const int hi = __shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// all (query, target) pairs of a group with query < target, one pair per lane and turn
+__global__ __launch_bounds__(256) void k_dg_pairs(const PairArgs a) {
+  __shared__ unsigned long long stage_all[4][kStage];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long * stage = stage_all[wave];
+  uint32_t nstage = 0;
+  unsigned long long compared = 0;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  auto flush = [&]() {
+    wave_lds_sync();
+    unsigned long long base = 0;
+    if (lane == 0) { base = atomicAdd(&a.counters[0], (unsigned long long)nstage); }
+    base = shfl_u64(base, 0);
+    for (uint32_t i = lane; i < nstage; i += 64u) { if (base + i < a.pair_cap) { a.pairs[base + i] = stage[i]; } }
+    nstage = 0;
+    wave_lds_sync();
+  };
+  const uint32_t nitems = min(*a.item_count, a.item_cap);
+  const uint32_t nwaves = gridDim.x * 4u;
+  const int d = (int)a.d;
+  for (uint32_t it = blockIdx.x * 4u + wave; it < nitems; it += nwaves) {
+    const dg_item item = a.items[it];
+    const uint64_t npairs = (uint64_t)item.nt * item.nq;
+    const uint64_t ntiles = (npairs + kTile - 1) / kTile;
+    const uint32_t * targets = a.members + item.begin;
+    const uint32_t * queries = targets + item.nt;
+    for (uint64_t tile = item.tile; tile < ntiles; tile += kStride) {
+      const uint64_t q0 = tile * kTile;
+      const uint64_t q1 = min(q0 + (uint64_t)kTile, npairs);
+      for (uint64_t qb = q0; qb < q1; qb += 64u) {
+        const uint64_t p = qb + (uint64_t)lane;
+        bool take = false;
+        uint32_t q = 0, t = 0;
+        if (p < q1) {
+          const uint32_t iq = (uint32_t)(p / item.nt);
+          const uint32_t itg = (uint32_t)(p - (uint64_t)iq * item.nt);
+          q = queries[iq];
+          t = targets[itg];
+          if (q < t) {
+            const int lq = (int)a.seqlen[q], lt = (int)a.seqlen[t];
+            const int dl = lq - lt;
+            if (dl >= -d && dl <= d) {
+              const uint64_t * sq = a.seqs + a.seq_off[q];
+              const uint64_t * st = a.seqs + a.seq_off[t];
+              // the pair belongs to the FIRST window of the query that reappears (shifted) in the target
+              bool earlier = false;
+              for (uint32_t k2 = 0; k2 < a.k && !earlier; ++k2) {
+                const uint64_t wq = window(sq, k2 * a.wlen, a.wlen);
+                for (int s = -d; s <= d && !earlier; ++s) {
+                  const int pos = (int)(k2 * a.wlen) + s;
+                  earlier = pos >= 0 && pos + (int)a.wlen <= lt && window(st, (uint32_t)pos, a.wlen) == wq;
+                }
+              }
+              if (!earlier) {
+                // (the group key may collide: make sure window k really reappears)
+                bool here = false;
+                const uint64_t wq = window(sq, a.k * a.wlen, a.wlen);
+                for (int s = -d; s <= d && !here; ++s) {
+                  const int pos = (int)(a.k * a.wlen) + s;
+                  here = pos >= 0 && pos + (int)a.wlen <= lt && window(st, (uint32_t)pos, a.wlen) == wq;
+                }
+                if (here) {
+                  // q-gram bound (qgram_diff, src/qgram.cc:68-96): ceil(popcount(sig_q ^ sig_t) / 10) <= d
+                  const ulonglong2 * gq = a.sigs + (uint64_t)q * 8u;
+                  const ulonglong2 * gt = a.sigs + (uint64_t)t * 8u;
+                  uint32_t pop = 0;
+#pragma unroll
+                  for (int w = 0; w < 8; ++w) {
+                    const ulonglong2 x = gq[w], y = gt[w];
+                    pop += (uint32_t)__popcll(x.x ^ y.x) + (uint32_t)__popcll(x.y ^ y.y);
+                  }
+                  ++compared;
+                  take = (pop + 9u) / 10u <= a.d;
+                }
+              }
+            }
+          }
+        }
+        const uint64_t m = __ballot(take);
+        if (m != 0ull) {
+          if (take) { stage[nstage + (uint32_t)__popcll(m & lane_lt)] = ((unsigned long long)q << 32) | t; }
+          nstage += (uint32_t)__popcll(m);
+          if (nstage > kStage - 64u) { flush(); }
+        }
+      }
+    }
+  }
+  if (nstage != 0u) { flush(); }
+  for (int o = 32; o > 0; o >>= 1) { compared += shfl_u64(compared, lane ^ o); }
+  if (lane == 0 && compared != 0ull) { atomicAdd(&a.counters[1], compared); }
+}
+
+// the alignments a pair needs: (a, b) with a < b always (db order is abundance-descending, so b's
+// abundance is not the larger one); (b, a) as well when the abundance rule allows it: equal abundances,
+// or no rule (-n).  Queries / targets of the second kind are appended behind the first npairs entries.
+__global__ __launch_bounds__(256) void k_dg_worklist(const unsigned long long * __restrict__ pairs, uint64_t npairs,
+                                                     const uint64_t * __restrict__ abundance, int ncb, uint32_t * __restrict__ wq,
+                                                     uint32_t * __restrict__ wt, unsigned long long * extra_counter) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t p0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); p0 < npairs; p0 += stride) {
+    const uint64_t p = p0 + (uint64_t)lane;
+    bool both = false;
+    uint32_t a = 0, b = 0;
+    if (p < npairs) {
+      const unsigned long long pr = pairs[p];
+      a = (uint32_t)(pr >> 32); b = (uint32_t)pr;
+      wq[p] = a; wt[p] = b;
+      both = ncb != 0 || abundance[a] == abundance[b];
+    }
+    const uint64_t m = __ballot(both);
+    if (m != 0ull) {
+      unsigned long long base = 0;
+      if (lane == 0) { base = atomicAdd(extra_counter, (unsigned long long)__popcll(m)); }
+      base = shfl_u64(base, 0);
+      if (both) { const uint64_t at = npairs + base + (uint64_t)__popcll(m & lane_lt); wq[at] = b; wt[at] = a; }
+    }
+  }
+}
+
+// accepted alignments -> (query << 32 | target) keys + diffs, compacted
+__global__ __launch_bounds__(256) void k_dg_edges(const uint32_t * __restrict__ wq, const uint32_t * __restrict__ wt,
+                                                  const uint32_t * __restrict__ diffs, uint64_t count, uint32_t d,
+                                                  unsigned long long * __restrict__ keys, uint32_t * __restrict__ vals,
+                                                  unsigned long long * edge_counter) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < count; e0 += stride) {
+    const uint64_t e = e0 + (uint64_t)lane;
+    const bool ok = e < count && diffs[e] <= d;
+    const uint64_t m = __ballot(ok);
+    if (m != 0ull) {
+      unsigned long long base = 0;
+      if (lane == 0) { base = atomicAdd(edge_counter, (unsigned long long)__popcll(m)); }
+      base = shfl_u64(base, 0);
+      if (ok) {
+        const uint64_t at = base + (uint64_t)__popcll(m & lane_lt);
+        keys[at] = ((unsigned long long)wq[e] << 32) | wt[e];
+        vals[at] = diffs[e];
+      }
+    }
+  }
+}
+
+// sorted keys -> CSR: offsets[i] = first key >= i << 32; neighbours / diffs split out of the sorted arrays
+__global__ __launch_bounds__(256) void k_dg_offsets(const unsigned long long * __restrict__ keys, uint64_t count, uint32_t n,
+                                                    uint64_t * __restrict__ offsets) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long want = (unsigned long long)i << 32;
+    uint64_t lo = 0, hi = count;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < want) { lo = mid + 1; } else { hi = mid; } }
+    offsets[i] = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dg_split(const unsigned long long * __restrict__ keys, const uint32_t * __restrict__ vals,
+                                                  uint64_t count, uint32_t * __restrict__ neighbours, uint8_t * __restrict__ diffs) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+    neighbours[i] = (uint32_t)keys[i];
+    diffs[i] = (uint8_t)vals[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dg_shortest(const uint32_t * __restrict__ seqlen, uint32_t n, uint32_t * out) {
+  uint32_t mn = 0xFFFFFFFFu;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { mn = min(mn, seqlen[i]); }
+  for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); }
+  if ((threadIdx.x & 63u) == 0u) { atomicMin(out, mn); }
+}
+
+struct widen_u32 {
+  __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
+};
+
+int grid_for(const swa_ctx * ctx, uint64_t items) {
+  uint64_t blocks = (items + 255) / 256;
+  const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+  return (int)std::max<uint64_t>(1, std::min(blocks, cap));
+}
+
+// window length for this database and d: 32, 16, or 0 (no room for d + 1 windows in the shortest sequence)
+int window_length(swa_ctx * ctx, uint32_t d, uint32_t * out) {
+  if (ctx->dn_shortest == 0) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
+    auto * slot = static_cast<uint32_t *>(ctx->d_flags.ptr) + 10;
+    SWA_HIP(ctx, hipMemsetAsync(slot, 0xFF, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_dg_shortest, dim3(grid_for(ctx, ctx->db.n)), dim3(256), 0, ctx->stream, ctx->db.seqlen, ctx->db.n, slot);
+    uint32_t mn = 0;
+    SWA_HIP(ctx, hipMemcpyAsync(&mn, slot, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dn_shortest = mn;
+  }
+  *out = 0;
+  if (2u * d + 1u > (uint32_t)kMaxShifts) { return SWA_OK; }
+  if (ctx->dn_shortest >= 32u * (d + 1u)) { *out = 32; }
+  else if (ctx->dn_shortest >= 16u * (d + 1u)) { *out = 16; }
+  return SWA_OK;
+}
+
+}  // namespace
+
+extern "C" int swa_dn_graph_supported(swa_ctx * ctx) {
+  if (ctx == nullptr || !ctx->search_ready || ctx->db.n == 0) { return 0; }
+  uint32_t wlen = 0;
+  if (window_length(ctx, (uint32_t)ctx->resolution, &wlen) != SWA_OK) { return 0; }
+  return wlen != 0 ? 1 : 0;
+}
+
+extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint8_t * diffs,
+                            uint64_t cap, uint64_t * total) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->qgram_ready || !ctx->search_ready) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_graph: call swa_qgram_build and swa_search_begin first");
+  }
+  if (offsets == nullptr || total == nullptr || (cap != 0 && (neighbours == nullptr || diffs == nullptr))) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_graph: null buffer");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  const uint32_t d = (uint32_t)ctx->resolution;
+  uint32_t wlen = 0;
+  SWA_TRY(window_length(ctx, d, &wlen));
+  if (wlen == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_graph: a sequence is too short for d + 1 windows (use the scan)"); }
+
+  if (!ctx->dn_graph_ready || ctx->dn_graph_ncb != (no_cluster_breaking != 0)) {
+    const uint32_t ns = 2u * d + 1u;
+    uint64_t asize = 64;
+    while (asize < 2ull * n * ns) { asize <<= 1; }
+    const uint64_t member_cap = (uint64_t)n * (ns + 1u);
+    const uint64_t item_cap64 = (uint64_t)n + member_cap / 2 + 64;
+    const uint32_t item_cap = item_cap64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)item_cap64;
+    SWA_TRY(swa_reserve(ctx, ctx->d_fkeys, asize * sizeof(uint64_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_fcnt, (asize * 5 + 4) * sizeof(uint32_t)));              // (the scan reads one entry past `tot`)
+    SWA_TRY(swa_reserve(ctx, ctx->d_foff, (asize + 2) * sizeof(uint64_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_fslot, (uint64_t)n * (ns + 1u) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_fmembers, member_cap * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_fitems, (uint64_t)item_cap * sizeof(dg_item)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_fcounters, 16 * sizeof(uint64_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
+    auto * keys = static_cast<unsigned long long *>(ctx->d_fkeys.ptr);
+    auto * cnt_t = static_cast<uint32_t *>(ctx->d_fcnt.ptr);
+    auto * cnt_q = cnt_t + asize, * cur_t = cnt_q + asize, * cur_q = cur_t + asize, * tot = cur_q + asize;
+    auto * goff = static_cast<uint64_t *>(ctx->d_foff.ptr);
+    auto * tslot = static_cast<uint32_t *>(ctx->d_fslot.ptr);
+    auto * qslot = tslot + (uint64_t)n * ns;
+    auto * members = static_cast<uint32_t *>(ctx->d_fmembers.ptr);
+    auto * items = static_cast<dg_item *>(ctx->d_fitems.ptr);
+    auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);   // [0] pairs [1] comparisons [2] extra directions [3] edges
+    auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);             // [8] item counter [9] key table overflow
+    size_t scan_bytes = 0;
+    auto tot64 = rocprim::make_transform_iterator(tot, widen_u32());
+    (void)rocprim::exclusive_scan(nullptr, scan_bytes, tot64, goff, (uint64_t)0, asize + 1, rocprim::plus<uint64_t>(), ctx->stream);
+    SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, scan_bytes + 16));
+    if (ctx->dn_pair_cap == 0) { ctx->dn_pair_cap = 16ull * n + (1ull << 20); }
+    uint64_t npairs = 0;
+    uint64_t launches = 0;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      SWA_TRY(swa_reserve(ctx, ctx->d_fpairs, ctx->dn_pair_cap * sizeof(uint64_t)));
+      SWA_HIP(ctx, hipMemsetAsync(fc, 0, 8 * sizeof(uint64_t), ctx->stream));
+      SWA_HIP(ctx, hipMemsetAsync(dflags + 9, 0, sizeof(uint32_t), ctx->stream));
+      for (uint32_t k = 0; k <= d; ++k) {
+        GroupArgs g{};
+        g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen; g.n = n; g.d = d; g.k = k; g.wlen = wlen;
+        g.keys = keys; g.cnt_t = cnt_t; g.cnt_q = cnt_q; g.amask = asize - 1; g.tslot = tslot; g.qslot = qslot; g.overflow = dflags + 9;
+        const dim3 gn(grid_for(ctx, n)), ga(grid_for(ctx, asize)), b(256);
+        hipLaunchKernelGGL(k_dg_clear, ga, b, 0, ctx->stream, keys, cnt_t, cnt_q, cur_t, cur_q, asize);
+        hipLaunchKernelGGL(k_dg_targets, gn, b, 0, ctx->stream, g);
+        hipLaunchKernelGGL(k_dg_queries, gn, b, 0, ctx->stream, g);
+        hipLaunchKernelGGL(k_dg_totals, ga, b, 0, ctx->stream, cnt_t, cnt_q, asize, tot);
+        SWA_HIP(ctx, rocprim::exclusive_scan(ctx->d_scan_tmp.ptr, scan_bytes, tot64, goff, (uint64_t)0, asize + 1, rocprim::plus<uint64_t>(),
+                                             ctx->stream));
+        hipLaunchKernelGGL(k_dg_scatter, gn, b, 0, ctx->stream, g, tot, goff, cur_t, cur_q, members);
+        SWA_HIP(ctx, hipMemsetAsync(dflags + 8, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_dg_items, ga, b, 0, ctx->stream, cnt_t, cnt_q, tot, goff, asize, items, dflags + 8, item_cap);
+        PairArgs p{};
+        p.seqs = ctx->db.seqs; p.seq_off = ctx->db.seq_off; p.seqlen = ctx->db.seqlen;
+        p.sigs = static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr);
+        p.members = members; p.items = items; p.item_count = dflags + 8; p.item_cap = item_cap; p.d = d; p.k = k; p.wlen = wlen;
+        p.pairs = static_cast<unsigned long long *>(ctx->d_fpairs.ptr); p.counters = fc; p.pair_cap = ctx->dn_pair_cap;
+        hipLaunchKernelGGL(k_dg_pairs, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, p);
+        SWA_HIP(ctx, hipGetLastError());
+        launches += 9;
+      }
+      uint64_t got[2] = {0, 0};
+      uint32_t fl[2] = {0, 0};
+      SWA_HIP(ctx, hipMemcpyAsync(got, fc, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+      SWA_HIP(ctx, hipMemcpyAsync(fl, dflags + 8, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+      SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (fl[1] != 0) { return swa_fail_msg(ctx, SWA_E_DEVICE, "swa_dn_graph: group key table overflow"); }
+      ctx->dn_comparisons = got[1];
+      if (got[0] <= ctx->dn_pair_cap) { npairs = got[0]; break; }
+      if (attempt == 5) { return swa_fail_msg(ctx, SWA_E_NOMEM, "swa_dn_graph: pair list keeps overflowing"); }
+      ctx->dn_pair_cap = got[0] + 1024;
+    }
+    // alignments in the direction(s) the abundance rule allows
+    uint64_t nedges = 0;
+    if (npairs != 0) {
+      SWA_TRY(swa_reserve(ctx, ctx->d_scan_targets, 4 * npairs * sizeof(uint32_t)));        // queries | targets, both directions
+      SWA_TRY(swa_reserve(ctx, ctx->d_scan_diffs, 2 * npairs * sizeof(uint32_t)));
+      auto * wq = static_cast<uint32_t *>(ctx->d_scan_targets.ptr);
+      auto * wt = wq + 2 * npairs;
+      auto * wd = static_cast<uint32_t *>(ctx->d_scan_diffs.ptr);
+      hipLaunchKernelGGL(k_dg_worklist, dim3(grid_for(ctx, npairs)), dim3(256), 0, ctx->stream,
+                         static_cast<const unsigned long long *>(ctx->d_fpairs.ptr), npairs, ctx->db.abundance, no_cluster_breaking,
+                         wq, wt, fc + 2);
+      uint64_t extra = 0;
+      SWA_HIP(ctx, hipMemcpyAsync(&extra, fc + 2, sizeof(extra), hipMemcpyDeviceToHost, ctx->stream));
+      SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      const uint64_t nwork = npairs + extra;
+      ctx->dn_aligned = nwork;
+      // (the launcher takes 32-bit counts: in slices)
+      for (uint64_t at = 0; at < nwork; at += 0x40000000ull) {
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>(0x40000000ull, nwork - at);
+        SWA_TRY(swa_align_launch(ctx, 0, wq + at, wt + at, nullptr, cnt, wd + at, nullptr, nullptr));
+        ++launches;
+      }
+      SWA_TRY(swa_reserve(ctx, ctx->d_dn_keys, 2 * nwork * sizeof(uint64_t)));
+      SWA_TRY(swa_reserve(ctx, ctx->d_dn_vals, 2 * nwork * sizeof(uint32_t)));
+      auto * ekeys = static_cast<unsigned long long *>(ctx->d_dn_keys.ptr);
+      auto * evals = static_cast<uint32_t *>(ctx->d_dn_vals.ptr);
+      hipLaunchKernelGGL(k_dg_edges, dim3(grid_for(ctx, nwork)), dim3(256), 0, ctx->stream, wq, wt, wd, nwork, d, ekeys, evals, fc + 3);
+      SWA_HIP(ctx, hipMemcpyAsync(&nedges, fc + 3, sizeof(nedges), hipMemcpyDeviceToHost, ctx->stream));
+      SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (nedges != 0) {
+        size_t sort_bytes = 0;
+        (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, ekeys, ekeys + nwork, evals, evals + nwork, nedges, 0, 64, ctx->stream);
+        SWA_TRY(swa_reserve(ctx, ctx->d_scan_hits, sort_bytes + 16));
+        SWA_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_scan_hits.ptr, sort_bytes, ekeys, ekeys + nwork, evals, evals + nwork, nedges, 0, 64,
+                                               ctx->stream));
+        launches += 6;
+      }
+    }
+    ctx->dn_edges = nedges;
+    ctx->dn_work = npairs != 0 ? ctx->dn_aligned : 0;
+    ctx->dn_launches = launches + 4;
+    ctx->dn_graph_ready = true;
+    ctx->dn_graph_ncb = no_cluster_breaking != 0;
+  }
+  const uint64_t nedges = ctx->dn_edges;
+  *total = nedges;
+  SWA_TRY(swa_reserve(ctx, ctx->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
+  const unsigned long long * sorted = ctx->dn_work != 0 ? static_cast<const unsigned long long *>(ctx->d_dn_keys.ptr) + ctx->dn_work : nullptr;
+  const uint32_t * svals = ctx->dn_work != 0 ? static_cast<const uint32_t *>(ctx->d_dn_vals.ptr) + ctx->dn_work : nullptr;
+  hipLaunchKernelGGL(k_dg_offsets, dim3(grid_for(ctx, (uint64_t)n + 1)), dim3(256), 0, ctx->stream, sorted, nedges, n,
+                     static_cast<uint64_t *>(ctx->d_offsets_tmp.ptr));
+  SWA_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_offsets_tmp.ptr, ((uint64_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (nedges > cap) {
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_dn_graph: neighbour buffer too small");
+  }
+  if (nedges != 0) {
+    SWA_TRY(swa_reserve(ctx, ctx->d_nb_tmp, nedges * (sizeof(uint32_t) + 1)));
+    auto * nb32 = static_cast<uint32_t *>(ctx->d_nb_tmp.ptr);
+    auto * df8 = reinterpret_cast<uint8_t *>(nb32 + nedges);
+    hipLaunchKernelGGL(k_dg_split, dim3(grid_for(ctx, nedges)), dim3(256), 0, ctx->stream, sorted, svals, nedges, nb32, df8);
+    SWA_HIP(ctx, hipMemcpyAsync(neighbours, nb32, nedges * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipMemcpyAsync(diffs, df8, nedges, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  SWA_HIP(ctx, hipGetLastError());
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}
+
+// out3 = {q-gram comparisons, aligned pairs, kernel launches} of the last swa_dn_graph
+extern "C" int swa_dn_graph_totals(swa_ctx * ctx, uint64_t * out3) {
+  if (ctx == nullptr || out3 == nullptr) { return SWA_E_ARG; }
+  out3[0] = ctx->dn_comparisons; out3[1] = ctx->dn_aligned; out3[2] = ctx->dn_launches;
+  return SWA_OK;
+}

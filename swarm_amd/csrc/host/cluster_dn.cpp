@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cinttypes>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,6 +37,67 @@ struct swa_dn_result {
   std::string error;
 };
 
+// The greedy agglomeration of algo_run (src/algo.cc:384-602) over the complete graph of pairs within d differences
+// (swa_dn_graph: row q = the targets t with diff(q, t) <= d that the abundance rule lets q take, ascending, with
+// their diffs).  Same order-defining rules as the loop in swa_dn_cluster: seeds by lowest unswarmed id, a sub-seed's
+// hits in pool (= id) order, queue kept sorted by generation then id (src/algo.cc:205-219).
+static int cluster_over_graph(swa_ctx * ctx, const swa_hostdb * db, int no_cluster_breaking, swa_dn_result * r) {
+  const uint32_t n = db->n;
+  std::vector<uint64_t> off((size_t)n + 1);
+  std::vector<uint32_t> nb;
+  std::vector<uint8_t> df;
+  uint64_t total = 0;
+  int rc = swa_dn_graph(ctx, no_cluster_breaking, off.data(), nullptr, nullptr, 0, &total);
+  if (rc == SWA_E_CAPACITY) {
+    nb.resize(total); df.resize(total);
+    rc = swa_dn_graph(ctx, no_cluster_breaking, off.data(), nb.data(), df.data(), total, &total);
+  }
+  if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  std::vector<uint8_t> swarmed(n, 0);
+  std::vector<swa_dn_result::Member> queue;
+  r->order.reserve(n);
+  r->links.reserve(n);
+  for (uint32_t seed = 0; seed < n; ++seed) {
+    if (swarmed[seed]) { continue; }
+    const uint32_t swarm_no = (uint32_t)r->swarms.size() + 1;
+    swa_dn_result::Swarm sw;
+    sw.link_begin = (uint32_t)r->links.size();
+    swarmed[seed] = 1;
+    queue.clear();
+    queue.push_back({seed, 0, 0});
+    size_t next = 0;
+    while (next < queue.size()) {
+      const swa_dn_result::Member sub = queue[next];
+      ++next;
+      for (uint64_t e = off[sub.id]; e < off[sub.id + 1]; ++e) {
+        const uint32_t id = nb[e];
+        if (swarmed[id]) { continue; }
+        swarmed[id] = 1;
+        const uint32_t diff = df[e];
+        size_t pos = queue.size();
+        while (pos > next && queue[pos - 1].id > id && queue[pos - 1].generation > sub.generation) { --pos; }
+        const swa_dn_result::Member m{id, sub.generation + 1, sub.radius + diff};
+        queue.insert(queue.begin() + (std::ptrdiff_t)pos, m);
+        sw.maxgen = std::max(sw.maxgen, m.generation);
+        sw.maxradius = std::max(sw.maxradius, m.radius);
+        r->links.push_back({sub.id, id, diff, swarm_no, m.generation});
+      }
+    }
+    sw.link_end = (uint32_t)r->links.size();
+    sw.begin = (uint32_t)r->order.size();
+    for (const auto & m : queue) {
+      r->order.push_back(m);
+      sw.mass += db->abundance[m.id];
+      if (db->abundance[m.id] == 1) { ++sw.singletons; }
+    }
+    sw.end = (uint32_t)r->order.size();
+    r->largest = std::max<uint64_t>(r->largest, sw.end - sw.begin);
+    r->maxgenerations = std::max<uint64_t>(r->maxgenerations, sw.maxgen);
+    r->swarms.push_back(sw);
+  }
+  return SWA_OK;
+}
+
 extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
                               uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out) {
   if (ctx == nullptr || db == nullptr || out == nullptr || differences < 2) { return SWA_E_ARG; }
@@ -49,6 +111,15 @@ extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t diff
   if (rc == SWA_OK) { rc = swa_search_begin(ctx, mismatch, gapopen, gapextend, (uint64_t)differences); }
   if (rc == SWA_OK) { rc = swa_scan_begin(ctx); }
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+
+  // Bulk route (dn_graph.hip): when every sequence has room for d + 1 windows the GPU returns the whole graph of
+  // pairs within d differences at once and the greedy loop below runs over that CSR, like d = 1.
+  // SWARM_AMD_DN=scan keeps the fused scan (one launch sequence per swarm generation), =graph insists on the graph.
+  const char * route = std::getenv("SWARM_AMD_DN");
+  const bool want_scan = route != nullptr && std::strcmp(route, "scan") == 0;
+  const bool want_graph = route != nullptr && std::strcmp(route, "graph") == 0;
+  if (!want_scan && swa_dn_graph_supported(ctx) != 0) { return cluster_over_graph(ctx, db, no_cluster_breaking, r); }
+  if (want_graph) { r->error = "SWARM_AMD_DN=graph: a sequence is too short for d + 1 windows"; return SWA_E_ARG; }
 
   std::vector<uint8_t> swarmed(n, 0);
   std::vector<uint32_t> hit_ids(n), hit_diffs(n), hit_sidx(n), batch_ids, batch_radii;

@@ -100,6 +100,12 @@ struct swa_ctx {
   // work items, the (heavy, light) pairs within two edits
   swa_dbuf d_frole, d_fkeys, d_fcnt, d_foff, d_fslot, d_fmembers, d_fitems, d_fpairs;
   uint64_t fast_pair_cap = 0;
+
+  // d >= 2 in bulk (dn_graph.hip): the graph of all pairs within d differences, kept sorted on the device
+  uint32_t dn_shortest = 0;      // shortest sequence of the database (0 = not measured yet)
+  bool dn_graph_ready = false, dn_graph_ncb = false;
+  uint64_t dn_pair_cap = 0, dn_comparisons = 0, dn_aligned = 0, dn_launches = 0, dn_edges = 0, dn_work = 0;
+  swa_dbuf d_dn_keys, d_dn_vals;
 };
 
 int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e);
