@@ -269,24 +269,39 @@ def config3_dn(args, n: int, length: int, d: int) -> dict:
     hdb = HostDb(fa, check_duplicate_sequences=True)
     t_read = time.perf_counter() - t0
     ctx = Context(0)
+    ctx.timing_enable(True)
     ctx.upload_hostdb(hdb)
     t0 = time.perf_counter()
     cl = DnClusters(ctx, hdb, d)
     dt = time.perf_counter() - t0
+    ms = ctx.timing_read()
     scan = cl.scan_totals()
     mm, go, ge = 18, 24, 13
     band = 2 * ((d * max(mm, go + ge)) // ge + 1) + 1
-    qbytes = 144.0 * scan["qgram_comparisons"]
-    res = {"workload": f"{hdb.n} synthetic amplicons x {length} bp, d={d}", "clustering_seconds": round(dt, 3),
-           "fasta_read_seconds": round(t_read, 3), "value": hdb.n / dt, "unit": "amplicons/s (clustering phase)",
-           "swarms": cl.summary()["swarms"], "launch_sequences": scan["launch_sequences"],
+    res = {"workload": f"{hdb.n} synthetic amplicons x {length} bp, d={d}", "route": scan["route"],
+           "clustering_seconds": round(dt, 3), "fasta_read_seconds": round(t_read, 3), "value": hdb.n / dt,
+           "unit": "amplicons/s (clustering phase: search on the GPU + download + host greedy walk)",
+           "swarms": cl.summary()["swarms"], "kernel_launches": scan["launch_sequences"],
            "qgram_comparisons": scan["qgram_comparisons"], "aligned_pairs": scan["aligned_pairs"],
            "qgram_comparisons_per_s": scan["qgram_comparisons"] / dt, "aligned_pairs_per_s": scan["aligned_pairs"] / dt,
            "full_matrix_equivalent_cells_per_s": scan["aligned_pairs"] * float(length) * length / dt,
-           "banded_cells_per_s": scan["aligned_pairs"] * float(band) * length / dt,
-           "roofline": {"bound": "hbm", "kernel": "q-gram scan over the clustering phase (launch-latency bound, not bandwidth bound)",
-                        "algorithmic_bytes": qbytes, "achieved": qbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": qbytes / dt / 1e9 / HBM_PEAK_GBS}}
+           "banded_cells_per_s": scan["aligned_pairs"] * float(band) * length / dt}
+    if scan["route"] == "graph" and ms[6] > 0:
+        # the two kernel groups of dn_graph.hip by HIP events; the alignment group is integer VALU / LDS work
+        # (reported as pairs and cells per second of kernel time), the pair group streams signatures
+        a_s, p_s = ms[6] * 1e-3, ms[5] * 1e-3
+        pbytes = 272.0 * scan["qgram_comparisons"]          # two 128-byte signatures + two ids per comparison
+        res["gpu_kernels_ms"] = {"groups_and_pairs": float(ms[5]), "alignments_and_csr": float(ms[6])}
+        res["alignment_kernel_pairs_per_s"] = scan["aligned_pairs"] / a_s
+        res["alignment_kernel_full_matrix_equivalent_cells_per_s"] = scan["aligned_pairs"] * float(length) * length / a_s
+        res["roofline"] = {"bound": "hbm", "kernel": "k_dg_pairs (group bookkeeping + q-gram signatures of the pairs)",
+                           "algorithmic_bytes": pbytes, "achieved": pbytes / p_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": pbytes / p_s / 1e9 / HBM_PEAK_GBS}
+    else:
+        qbytes = 144.0 * scan["qgram_comparisons"]
+        res["roofline"] = {"bound": "hbm", "kernel": "q-gram scan over the clustering phase (launch-latency bound)",
+                           "algorithmic_bytes": qbytes, "achieved": qbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": qbytes / dt / 1e9 / HBM_PEAK_GBS}
     cl.close()
     ctx.close()
     hdb.close()

@@ -470,6 +470,8 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
     if (ctx->dn_pair_cap == 0) { ctx->dn_pair_cap = 16ull * n + (1ull << 20); }
     uint64_t npairs = 0;
     uint64_t launches = 0;
+    for (int slot : {5, 6}) { ctx->ev_used[slot] = false; }
+    swa_t0(ctx, 5);                                            // timing slot 5: groups + pairs, slot 6: alignments + CSR
     for (int attempt = 0; attempt < 6; ++attempt) {
       SWA_TRY(swa_reserve(ctx, ctx->d_fpairs, ctx->dn_pair_cap * sizeof(uint64_t)));
       SWA_HIP(ctx, hipMemsetAsync(fc, 0, 8 * sizeof(uint64_t), ctx->stream));
@@ -508,7 +510,9 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
       if (attempt == 5) { return swa_fail_msg(ctx, SWA_E_NOMEM, "swa_dn_graph: pair list keeps overflowing"); }
       ctx->dn_pair_cap = got[0] + 1024;
     }
+    swa_t1(ctx, 5);
     // alignments in the direction(s) the abundance rule allows
+    swa_t0(ctx, 6);
     uint64_t nedges = 0;
     if (npairs != 0) {
       SWA_TRY(swa_reserve(ctx, ctx->d_scan_targets, 4 * npairs * sizeof(uint32_t)));        // queries | targets, both directions
@@ -546,6 +550,7 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
         launches += 6;
       }
     }
+    swa_t1(ctx, 6);
     ctx->dn_edges = nedges;
     ctx->dn_work = npairs != 0 ? ctx->dn_aligned : 0;
     ctx->dn_launches = launches + 4;

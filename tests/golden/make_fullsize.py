@@ -41,6 +41,8 @@ KEEP = re.compile(r"^(Database info|Number of swarms|Largest swarm|Max generatio
 # (src/bloomflex.cc:61-64), an update can be lost, and then a candidate is missed — "Got N graft
 # candidates" (and, rarely, a graft) depends on thread timing.  -t 1 is the specification.
 RUNS = {"d1": (["-d", "1"], "osj", 0.0, 8), "d1_f": (["-d", "1", "-f"], "osi", 0.3, 1)}
+# BASELINE configs[3]: 1 M x 400, d = 3 (generator with up to 3 edits per amplicon); `d3` is only run for 1 M
+RUNS_DN = {"d3": (["-d", "3"], "osi", 3, 8)}
 FLAG = {"o": "-o", "s": "-s", "i": "-i", "j": "-j"}
 
 
@@ -57,7 +59,7 @@ def md5_of(path: Path) -> dict:
 
 def main() -> None:
     sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1_000_000, 10_000_000]
-    only = [a for a in sys.argv[1:] if a in RUNS] or list(RUNS)
+    only = [a for a in sys.argv[1:] if a in RUNS] or ([] if any(a in RUNS_DN for a in sys.argv[1:]) else list(RUNS))
     out_path = HERE / "fullsize.json"
     data = json.loads(out_path.read_text()) if out_path.exists() else {}
     for n in sizes:
@@ -78,6 +80,24 @@ def main() -> None:
                 assert r.returncode == 0, r.stderr
                 log = [ln for ln in Path(f"{tmp}/log").read_text().splitlines() if KEEP.match(ln)]
                 rec["runs"][name] = {"args": args, "generator": f"bench.gen_fasta({n}, 150, 1, 1, {light})",
+                                     "fasta": md5_of(fasta), "reference_threads": threads, "reference_seconds_here": round(dt, 2),
+                                     "files": {k: md5_of(Path(f"{tmp}/{k}")) for k in keep}, "log": log}
+                print(n, name, f"{dt:.1f} s", flush=True)
+        for name, (args, keep, edits, threads) in RUNS_DN.items():
+            if name not in sys.argv[1:] or n != 1_000_000:
+                continue
+            fasta = bench.gen_fasta(n, 400, 1, edits, 0.0)
+            with tempfile.TemporaryDirectory() as tmp:
+                cmd = list(args) + ["-t", str(threads)]
+                for k in keep:
+                    cmd += [FLAG[k], f"{tmp}/{k}"]
+                cmd += ["-l", f"{tmp}/log", str(fasta)]
+                t0 = time.perf_counter()
+                r = S.run_ref_swarm(cmd)
+                dt = time.perf_counter() - t0
+                assert r.returncode == 0, r.stderr
+                log = [ln for ln in Path(f"{tmp}/log").read_text().splitlines() if KEEP.match(ln)]
+                rec["runs"][name] = {"args": args, "generator": f"bench.gen_fasta({n}, 400, 1, {edits}, 0.0)",
                                      "fasta": md5_of(fasta), "reference_threads": threads, "reference_seconds_here": round(dt, 2),
                                      "files": {k: md5_of(Path(f"{tmp}/{k}")) for k in keep}, "log": log}
                 print(n, name, f"{dt:.1f} s", flush=True)
