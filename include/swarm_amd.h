@@ -244,6 +244,29 @@ int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * offsets, uin
 /* out3 = {q-gram comparisons, aligned pairs, kernel launches} of the last swa_dn_graph */
 int swa_dn_graph_totals(swa_ctx * ctx, uint64_t * out3);
 
+/* ---- d = 1 on several GPUs of one node --------------------------------
+   Replaces the thread fan-out of src/algod1.cc:1166-1167 / src/utils/threads.h:145-162: one context, stream and
+   host thread per listed device inside the calling process; the database replicated, the probing divided by
+   ownership of anchor groups (swa_d1_set_ownership), every rank's flat link list all-gathered with RCCL over
+   xGMI, CSR assembled on the device; fastidious: heavy amplicons split, graft_cand combined with
+   ncclAllReduce(min).  A device may be listed more than once (several ranks on one GPU: the exchange then uses
+   device-to-device copies — RCCL admits one rank per GPU); results never depend on the device list. */
+typedef struct swa_multi swa_multi;
+int  swa_multi_create(const int * devices, int ndevices, swa_multi ** out);
+void swa_multi_destroy(swa_multi * m);
+int  swa_multi_size(const swa_multi * m);
+int  swa_multi_uses_rccl(const swa_multi * m);
+swa_ctx * swa_multi_ctx(swa_multi * m, int rank);
+const char * swa_multi_last_error(const swa_multi * m);
+int  swa_multi_db_upload(swa_multi * m, const swa_db_view * host);
+/* = swa_d1_index_build + swa_d1_network over the whole database (same buffers, same capacity protocol);
+   *has_duplicates as swa_d1_index_build (SWA_E_DUPLICATES returned) */
+int  swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint64_t cap,
+                          uint64_t * total, int * has_duplicates);
+/* = swa_d1_fastidious */
+int  swa_multi_d1_fastidious(swa_multi * m, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
+                             uint32_t * graft_cand, uint64_t * counters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,4 +6,4 @@
 
 The product never imports oracle/ and has no CPU fallback.
 """
-from .capi import Context, D0Clusters, D1Clusters, DnClusters, derep, HostDb, SwaError, d1_write_uclust, reduced_penalties, build_library, load_library  # noqa: F401
+from .capi import Context, MultiContext, D0Clusters, D1Clusters, DnClusters, derep, HostDb, SwaError, d1_write_uclust, reduced_penalties, build_library, load_library  # noqa: F401

@@ -439,7 +439,9 @@ class Context:
 _DN_EXPORTS = ["swa_dn_cluster", "swa_dn_result_free", "swa_dn_result_error", "swa_dn_result_summary",
                "swa_dn_write_swarms", "swa_dn_write_stats", "swa_dn_write_structure", "swa_dn_write_seeds",
                "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_batch", "swa_scan_fetch", "swa_scan_totals",
-               "swa_dn_graph_supported", "swa_dn_graph", "swa_dn_graph_totals"]
+               "swa_dn_graph_supported", "swa_dn_graph", "swa_dn_graph_totals",
+               "swa_multi_create", "swa_multi_destroy", "swa_multi_size", "swa_multi_uses_rccl", "swa_multi_ctx", "swa_multi_last_error",
+               "swa_multi_db_upload", "swa_multi_d1_network", "swa_multi_d1_fastidious"]
 EXPORTS.extend(_DN_EXPORTS)
 
 
@@ -624,3 +626,76 @@ def d1_write_uclust(clusters: "D1Clusters", path, usearch=False, append_abundanc
     mm, go, ge = penalties or reduced_penalties()
     assert lib.swa_d1_write_uclust(clusters.h, clusters.hdb.h, str(path).encode(), int(usearch), append_abundance,
                                    mm, go, ge) == SWA_OK
+
+
+# ---- d = 1 on several GPUs from one process (multi.hip) -----------------------------------------
+
+class MultiContext:
+    """swa_multi_*: one context + stream + host thread per listed device inside the library; RCCL for the exchange
+    when the devices are distinct, device-to-device copies when a device is listed twice."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        lib = self.lib
+        lib.swa_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        lib.swa_multi_destroy.argtypes = [C.c_void_p]
+        lib.swa_multi_destroy.restype = None
+        lib.swa_multi_last_error.argtypes = [C.c_void_p]
+        lib.swa_multi_last_error.restype = C.c_char_p
+        lib.swa_multi_uses_rccl.argtypes = [C.c_void_p]
+        lib.swa_multi_db_upload.argtypes = [C.c_void_p, C.POINTER(DbView)]
+        lib.swa_multi_d1_network.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.POINTER(C.c_int)]
+        lib.swa_multi_d1_fastidious.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = lib.swa_multi_create(arr, len(devices), C.byref(h))
+        self.h = h
+        if rc != SWA_OK:
+            msg = lib.swa_multi_last_error(h).decode() if h else "allocation failed"
+            self.close()
+            raise SwaError(rc, msg)
+        self.n = 0
+
+    def _check(self, rc: int, allow=()) -> int:
+        if rc != SWA_OK and rc not in allow:
+            raise SwaError(rc, self.lib.swa_multi_last_error(self.h).decode())
+        return rc
+
+    def uses_rccl(self) -> bool:
+        return bool(self.lib.swa_multi_uses_rccl(self.h))
+
+    def upload_hostdb(self, hdb: "HostDb") -> None:
+        v = DbView(hdb.n, hdb.longest, _ptr(hdb.seqs), _ptr(hdb.seq_off), _ptr(hdb.seqlen), _ptr(hdb.abundance))
+        self._check(self.lib.swa_multi_db_upload(self.h, C.byref(v)))
+        self.n = hdb.n
+
+    def d1_network(self, no_cluster_breaking: bool = False):
+        offsets = np.zeros(self.n + 1, dtype=np.uint64)
+        cap = max(1024, 4 * self.n)
+        total = C.c_uint64(0)
+        dup = C.c_int(0)
+        while True:
+            nb = np.zeros(cap, dtype=np.uint32)
+            rc = self._check(self.lib.swa_multi_d1_network(self.h, int(no_cluster_breaking), _ptr(offsets), _ptr(nb), cap,
+                                                           C.byref(total), C.byref(dup)), allow=(SWA_E_CAPACITY,))
+            if rc == SWA_OK:
+                return offsets, nb[:total.value]
+            cap = int(total.value)
+
+    def d1_fastidious(self, is_light: np.ndarray, light_nt: int, bloom_bits: int = 16):
+        is_light = np.ascontiguousarray(is_light, dtype=np.uint8)
+        graft = np.zeros(self.n, dtype=np.uint32)
+        counters = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.swa_multi_d1_fastidious(self.h, _ptr(is_light), int(light_nt), int(bloom_bits), _ptr(graft), _ptr(counters)))
+        return graft, counters
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.swa_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

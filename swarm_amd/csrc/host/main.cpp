@@ -4,10 +4,11 @@
 // greedy clustering and the writers are the host code in cluster_d1.cpp / cluster_dn.cpp.
 //
 //   d = 1      swa_d1_index_build + swa_d1_network -> swa_d1_cluster [-> swa_d1_fastidious -> graft]
-//   d >= 2     swa_dn_cluster (one swa_scan_step per seed / sub-seed)
-//   d = 0      dereplication is outside this build's scope: refused with a message.
+//   d >= 2     swa_dn_cluster (the whole graph of pairs within d at once, or one swa_scan_step per swarm generation)
+//   d = 0      swa_derep -> swa_d0_cluster
 //
-// Environment (no new flags, to stay drop-in): SWARM_AMD_DEVICE = HIP device ordinal (default 0).
+// Environment (no new flags, to stay drop-in): SWARM_AMD_DEVICE = HIP device ordinal (default 0);
+// SWARM_AMD_DEVICES = 0,1,2,... : d = 1 on several GPUs (swa_multi_*: one rank per entry, RCCL exchange).
 #include "../../../include/swarm_amd.h"
 #include "../../../include/swarm_amd_host.h"
 
@@ -201,9 +202,8 @@ void validate(const Options & o) {            // src/swarm.cc:486-630, same orde
 }
 
 // a phase line of the log: "<prompt> 100%" (the reference animates a percentage on a tty)
-void phase(const Options & o, const char * prompt) {
-  if (!o.log.empty()) { std::fprintf(g_log, "%s 100%%\n", prompt); }
-  else { std::fprintf(g_log, "%s 100%%\n", prompt); }
+void phase(const Options &, const char * prompt) {
+  std::fprintf(g_log, "%s 100%%\n", prompt);
   std::fflush(g_log);
 }
 
@@ -254,13 +254,32 @@ int main(int argc, char ** argv) {
 
   const uint32_t n = view.n;
   swa_ctx * ctx = nullptr;
+  swa_multi * multi = nullptr;           // d = 1 on several GPUs: SWARM_AMD_DEVICES=0,1,2,... (one rank per entry)
   if (n > 0) {
-    const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
-    const int device = dev_env != nullptr ? std::atoi(dev_env) : 0;
-    if (swa_ctx_create(device, nullptr, &ctx) != SWA_OK) {
-      die("no usable gfx950 GPU (this build has no CPU fallback).");
+    std::vector<int> devices;
+    if (const char * list = std::getenv("SWARM_AMD_DEVICES")) {
+      for (const char * p = list; *p != '\0';) {
+        char * end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end == p) { break; }
+        devices.push_back((int)v);
+        p = (*end == ',') ? end + 1 : end;
+      }
     }
-    if (swa_db_upload(ctx, &view) != SWA_OK) { die(swa_last_error(ctx)); }
+    if (devices.size() > 1 && o.differences == 1) {
+      if (swa_multi_create(devices.data(), (int)devices.size(), &multi) != SWA_OK) {
+        die(multi != nullptr ? swa_multi_last_error(multi) : "no usable gfx950 GPU (this build has no CPU fallback).");
+      }
+      if (swa_multi_db_upload(multi, &view) != SWA_OK) { die(swa_multi_last_error(multi)); }
+      ctx = swa_multi_ctx(multi, 0);
+    } else {
+      const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
+      const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
+      if (swa_ctx_create(device, nullptr, &ctx) != SWA_OK) {
+        die("no usable gfx950 GPU (this build has no CPU fallback).");
+      }
+      if (swa_db_upload(ctx, &view) != SWA_OK) { die(swa_last_error(ctx)); }
+    }
   }
 
   if (o.differences == 0) {
@@ -286,7 +305,27 @@ int main(int argc, char ** argv) {
     // ---- seam B1: the network on the GPU
     std::vector<uint64_t> offsets((size_t)n + 1, 0);
     std::vector<uint32_t> neighbours;
-    if (n > 0) {
+    const char * dup_text = "some fasta entries have identical sequences.\n"
+                            "Swarm expects dereplicated fasta files.\n"
+                            "Such files can be produced with swarm or vsearch:\n"
+                            " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
+                            "or\n"
+                            " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
+    if (n > 0 && multi != nullptr) {
+      uint64_t total = 0;
+      int dup = 0;
+      neighbours.resize(std::max<size_t>(4 * (size_t)n, 1024));
+      for (;;) {
+        rc = swa_multi_d1_network(multi, o.no_break ? 1 : 0, offsets.data(), neighbours.data(), neighbours.size(), &total, &dup);
+        if (rc == SWA_E_DUPLICATES) { die(dup_text); }
+        if (rc == SWA_E_CAPACITY) { neighbours.resize(total); continue; }
+        if (rc != SWA_OK) { die(swa_multi_last_error(multi)); }
+        break;
+      }
+      neighbours.resize(total);
+      phase(o, "Hashing sequences:");
+      phase(o, "Building network: ");
+    } else if (n > 0) {
       int dup = 0;
       rc = swa_d1_index_build(ctx, &dup);
       if (rc == SWA_E_DUPLICATES) {
@@ -356,8 +395,13 @@ int main(int argc, char ** argv) {
         if (m < 64) { m = 64; }
         std::fprintf(g_log, "Bloom filter: bits=%" PRIu64 ", m=%" PRIu64 ", k=%u, size=%.1fMB\n", bits, m, k,
                      (double)m / (8.0 * 1024.0 * 1024.0));
-        rc = swa_d1_fastidious(ctx, is_light.data(), st[2], (uint32_t)bits, graft.data(), counters);
-        if (rc != SWA_OK) { die(swa_last_error(ctx)); }
+        if (multi != nullptr) {
+          rc = swa_multi_d1_fastidious(multi, is_light.data(), st[2], (uint32_t)bits, graft.data(), counters);
+          if (rc != SWA_OK) { die(swa_multi_last_error(multi)); }
+        } else {
+          rc = swa_d1_fastidious(ctx, is_light.data(), st[2], (uint32_t)bits, graft.data(), counters);
+          if (rc != SWA_OK) { die(swa_last_error(ctx)); }
+        }
         phase(o, "Adding light swarm amplicons to Bloom filter");
         std::fprintf(g_log, "Generated %" PRIu64 " variants from light swarms\n", counters[0]);
         phase(o, "Checking heavy swarm amplicons against Bloom filter");
@@ -413,7 +457,8 @@ int main(int argc, char ** argv) {
     std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
                  sum[1], sum[2]);
   }
-  if (ctx != nullptr) { swa_ctx_destroy(ctx); }
+  if (multi != nullptr) { swa_multi_destroy(multi); }
+  else if (ctx != nullptr) { swa_ctx_destroy(ctx); }
   swa_hostdb_free(db);
   if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
   return EXIT_SUCCESS;

@@ -1,0 +1,303 @@
+// multi.hip — the d = 1 path on several GPUs of one node, from C++ (no Python, no torch): one context, one
+// stream and one host thread per GPU inside this process, RCCL over xGMI for the exchange.
+//
+// The reference fans its probe loop out over pthreads that share one hash table
+// (src/algod1.cc:641-669, 1166-1167; src/utils/threads.h:145-162).  Here the database is replicated
+// (288 GB per GPU is never the limit) and the PROBING is divided by ownership of anchor groups
+// (swa_d1_set_ownership: rank r serves the groups whose key maps to r, with all their members), so every
+// link of the network is found by exactly one rank.  Exchange, as SURVEY 8e / the north star name it: the
+// per-rank hit counts are known on the host when the kernels return, then every rank's flat link list is
+// all-gathered into every GPU (grouped ncclBroadcast = an all-gather with unequal counts), and the CSR is
+// a radix sort + offsets on the device.  Fastidious: the heavy amplicons are split
+// (swa_d1_fastidious_shard), graft_cand is combined with ncclAllReduce(min) (src/algod1.cc:244-258 keeps
+// the smallest heavy id), the two heavy-side counters add up.
+//
+// The same code runs with several contexts on ONE device (SWARM_AMD_DEVICES=0,0: what a one-GPU box can
+// test); RCCL refuses two ranks on one GPU, so that configuration moves the same bytes with device-to-
+// device copies instead.  Results are identical to a single GPU by construction and by test
+// (tests/test_multi_gpu.py).
+#include "swa_internal.h"
+
+#include <rccl/rccl.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <functional>
+#include <set>
+#include <thread>
+#include <vector>
+
+struct swa_multi {
+  std::vector<swa_ctx *> ctx;
+  std::vector<int> devices;
+  std::vector<ncclComm_t> comms;       // empty: in-process copies (several ranks on one device)
+  std::vector<swa_dbuf> links, gathered;
+  std::vector<uint64_t> link_cap;
+  std::string err;
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_links_offsets(const unsigned long long * __restrict__ keys, uint64_t count, uint32_t n,
+                                                       uint64_t * __restrict__ offsets) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long want = (unsigned long long)i << 32;
+    uint64_t lo = 0, hi = count;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < want) { lo = mid + 1; } else { hi = mid; } }
+    offsets[i] = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_links_targets(const unsigned long long * __restrict__ keys, uint64_t count,
+                                                       uint32_t * __restrict__ neighbours) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+    neighbours[i] = (uint32_t)keys[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_min_u32(uint32_t * __restrict__ acc, const uint32_t * __restrict__ other, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    acc[i] = min(acc[i], other[i]);
+  }
+}
+
+int blocks_for(const swa_ctx * ctx, uint64_t items) {
+  const uint64_t b = (items + 255) / 256, cap = (uint64_t)ctx->num_cus * 8;
+  return (int)std::max<uint64_t>(1, std::min(b, cap));
+}
+
+// runs f(rank) on one host thread per rank; first non-zero status wins
+int on_all(swa_multi * m, const std::function<int(int)> & f) {
+  const int world = (int)m->ctx.size();
+  std::vector<int> rc((size_t)world, SWA_OK);
+  if (world == 1) { rc[0] = f(0); }
+  else {
+    std::vector<std::thread> threads;
+    for (int r = 0; r < world; ++r) { threads.emplace_back([&, r]() { rc[(size_t)r] = f(r); }); }
+    for (auto & t : threads) { t.join(); }
+  }
+  for (int r = 0; r < world; ++r) {
+    if (rc[(size_t)r] != SWA_OK) { m->err = "rank " + std::to_string(r) + ": " + swa_last_error(m->ctx[(size_t)r]); return rc[(size_t)r]; }
+  }
+  return SWA_OK;
+}
+
+int fail(swa_multi * m, int code, const std::string & msg) { m->err = msg; return code; }
+
+#define NCCL_OK(m, expr)                                                                               \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess) { return fail((m), SWA_E_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)); } \
+  } while (0)
+
+// every rank's buffer src[r] (count[r] elements of `bytes_per` bytes) into dst[k] + prefix(r) on every rank k
+int all_gather_v(swa_multi * m, const std::vector<const void *> & src, const std::vector<void *> & dst,
+                 const std::vector<uint64_t> & count, size_t bytes_per) {
+  const int world = (int)m->ctx.size();
+  std::vector<uint64_t> at((size_t)world + 1, 0);
+  for (int r = 0; r < world; ++r) { at[(size_t)r + 1] = at[(size_t)r] + count[(size_t)r]; }
+  if (!m->comms.empty()) {
+    NCCL_OK(m, ncclGroupStart());
+    for (int k = 0; k < world; ++k) {
+      for (int r = 0; r < world; ++r) {
+        if (count[(size_t)r] == 0) { continue; }
+        char * recv = static_cast<char *>(dst[(size_t)k]) + at[(size_t)r] * bytes_per;
+        // (the send buffer only matters on the root)
+        NCCL_OK(m, ncclBroadcast(k == r ? src[(size_t)r] : recv, recv, count[(size_t)r] * bytes_per, ncclUint8, r, m->comms[(size_t)k],
+                                 m->ctx[(size_t)k]->stream));
+      }
+    }
+    NCCL_OK(m, ncclGroupEnd());
+  } else {
+    for (int k = 0; k < world; ++k) {
+      if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+      for (int r = 0; r < world; ++r) {
+        if (count[(size_t)r] == 0) { continue; }
+        char * recv = static_cast<char *>(dst[(size_t)k]) + at[(size_t)r] * bytes_per;
+        if (hipMemcpyAsync(recv, src[(size_t)r], count[(size_t)r] * bytes_per, hipMemcpyDefault, m->ctx[(size_t)k]->stream) != hipSuccess) {
+          return fail(m, SWA_E_DEVICE, "device-to-device copy of a link list failed");
+        }
+      }
+    }
+  }
+  for (int k = 0; k < world; ++k) {
+    if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
+      return fail(m, SWA_E_DEVICE, "synchronising the exchange failed");
+    }
+  }
+  return SWA_OK;
+}
+
+}  // namespace
+
+extern "C" int swa_multi_create(const int * devices, int ndevices, swa_multi ** out) {
+  if (out == nullptr || devices == nullptr || ndevices < 1 || ndevices > 64) { return SWA_E_ARG; }
+  auto * m = new swa_multi();
+  *out = m;
+  m->devices.assign(devices, devices + ndevices);
+  for (int r = 0; r < ndevices; ++r) {
+    swa_ctx * c = nullptr;
+    const int rc = swa_ctx_create(devices[r], nullptr, &c);
+    if (rc != SWA_OK) { m->err = "no usable gfx950 GPU with index " + std::to_string(devices[r]); return rc; }
+    m->ctx.push_back(c);
+  }
+  m->links.resize((size_t)ndevices);
+  m->gathered.resize((size_t)ndevices);
+  m->link_cap.assign((size_t)ndevices, 0);
+  const std::set<int> distinct(m->devices.begin(), m->devices.end());
+  const char * force = getenv("SWARM_AMD_FORCE_RCCL");       // test hook: RCCL even for a single rank
+  if ((int)distinct.size() == ndevices && (ndevices > 1 || (force != nullptr && force[0] == '1'))) {
+    m->comms.resize((size_t)ndevices);
+    const ncclResult_t r = ncclCommInitAll(m->comms.data(), ndevices, m->devices.data());
+    if (r != ncclSuccess) { m->comms.clear(); m->err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return SWA_E_DEVICE; }
+  }
+  return SWA_OK;
+}
+
+extern "C" void swa_multi_destroy(swa_multi * m) {
+  if (m == nullptr) { return; }
+  for (size_t r = 0; r < m->ctx.size(); ++r) {
+    (void)hipSetDevice(m->devices[r]);
+    swa_release(m->links[r]);
+    swa_release(m->gathered[r]);
+  }
+  for (auto & c : m->comms) { (void)ncclCommDestroy(c); }
+  for (auto * c : m->ctx) { swa_ctx_destroy(c); }
+  delete m;
+}
+
+extern "C" int swa_multi_size(const swa_multi * m) { return m != nullptr ? (int)m->ctx.size() : 0; }
+extern "C" int swa_multi_uses_rccl(const swa_multi * m) { return m != nullptr && !m->comms.empty() ? 1 : 0; }
+extern "C" swa_ctx * swa_multi_ctx(swa_multi * m, int rank) {
+  return (m != nullptr && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[(size_t)rank] : nullptr;
+}
+extern "C" const char * swa_multi_last_error(const swa_multi * m) { return m != nullptr ? m->err.c_str() : "null handle"; }
+
+extern "C" int swa_multi_db_upload(swa_multi * m, const swa_db_view * host) {
+  if (m == nullptr) { return SWA_E_ARG; }
+  return on_all(m, [&](int r) { return swa_db_upload(m->ctx[(size_t)r], host); });
+}
+
+// the whole network of the database as a CSR on the host (buffers and capacity protocol of swa_d1_network)
+extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint64_t cap,
+                                    uint64_t * total, int * has_duplicates) {
+  if (m == nullptr || offsets == nullptr || total == nullptr || (neighbours == nullptr && cap != 0)) { return SWA_E_ARG; }
+  const int world = (int)m->ctx.size();
+  const uint32_t n = m->ctx[0]->db.n;
+  if (n == 0) { return fail(m, SWA_E_ARG, "swa_multi_d1_network: no database"); }
+  // 1. every rank indexes and probes the anchor groups it owns
+  std::vector<int> dup((size_t)world, 0);
+  std::vector<uint64_t> count((size_t)world, 0);
+  int rc = on_all(m, [&](int r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    SWA_TRY(swa_d1_set_ownership(c, (uint32_t)r, (uint32_t)world));
+    int rc2 = swa_d1_index_build(c, &dup[(size_t)r]);
+    if (rc2 != SWA_OK) { return rc2; }
+    if (m->link_cap[(size_t)r] == 0) { m->link_cap[(size_t)r] = 4ull * n / (uint64_t)world + 65536; }
+    for (;;) {
+      SWA_HIP(c, hipSetDevice(c->device));
+      SWA_TRY(swa_reserve(c, m->links[(size_t)r], m->link_cap[(size_t)r] * sizeof(uint64_t)));
+      rc2 = swa_d1_network_edges_device(c, no_cluster_breaking, 0, n, static_cast<uint64_t *>(m->links[(size_t)r].ptr),
+                                        m->link_cap[(size_t)r], &count[(size_t)r]);
+      if (rc2 == SWA_E_CAPACITY) { m->link_cap[(size_t)r] = count[(size_t)r] + 1024; continue; }
+      return rc2;
+    }
+  });
+  if (has_duplicates != nullptr) { *has_duplicates = 0; for (int d : dup) { *has_duplicates |= d; } }
+  if (rc != SWA_OK) { return rc; }
+  // 2. all-gather of the link lists (counts are on the host already)
+  uint64_t all = 0;
+  for (uint64_t c : count) { all += c; }
+  *total = all;
+  std::vector<const void *> src((size_t)world);
+  std::vector<void *> dst((size_t)world);
+  for (int r = 0; r < world; ++r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    if (hipSetDevice(c->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+    // (sorted in place below: twice the room, for the radix sort's output)
+    rc = swa_reserve(c, m->gathered[(size_t)r], (2 * all + 2) * sizeof(uint64_t));
+    if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
+    src[(size_t)r] = m->links[(size_t)r].ptr;
+    dst[(size_t)r] = m->gathered[(size_t)r].ptr;
+  }
+  if (all != 0) { rc = all_gather_v(m, src, dst, count, sizeof(uint64_t)); if (rc != SWA_OK) { return rc; } }
+  // 3. rank 0: sort by (source, target) -> CSR -> host
+  swa_ctx * c0 = m->ctx[0];
+  if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+  auto * keys_in = static_cast<unsigned long long *>(m->gathered[0].ptr);
+  auto * keys_out = keys_in + all + 1;
+  auto stage = [&]() -> int {
+    if (all != 0) {
+      size_t bytes = 0;
+      (void)rocprim::radix_sort_keys(nullptr, bytes, keys_in, keys_out, all, 0, 64, c0->stream);
+      SWA_TRY(swa_reserve(c0, c0->d_scan_hits, bytes + 16));
+      SWA_HIP(c0, rocprim::radix_sort_keys(c0->d_scan_hits.ptr, bytes, keys_in, keys_out, all, 0, 64, c0->stream));
+    }
+    SWA_TRY(swa_reserve(c0, c0->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
+    hipLaunchKernelGGL(k_links_offsets, dim3(blocks_for(c0, (uint64_t)n + 1)), dim3(256), 0, c0->stream, keys_out, all, n,
+                       static_cast<uint64_t *>(c0->d_offsets_tmp.ptr));
+    SWA_HIP(c0, hipMemcpyAsync(offsets, c0->d_offsets_tmp.ptr, ((uint64_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
+    if (all != 0 && all <= cap) {
+      SWA_TRY(swa_reserve(c0, c0->d_nb_tmp, all * sizeof(uint32_t)));
+      hipLaunchKernelGGL(k_links_targets, dim3(blocks_for(c0, all)), dim3(256), 0, c0->stream, keys_out, all,
+                         static_cast<uint32_t *>(c0->d_nb_tmp.ptr));
+      SWA_HIP(c0, hipMemcpyAsync(neighbours, c0->d_nb_tmp.ptr, all * sizeof(uint32_t), hipMemcpyDeviceToHost, c0->stream));
+    }
+    SWA_HIP(c0, hipGetLastError());
+    SWA_HIP(c0, hipStreamSynchronize(c0->stream));
+    return SWA_OK;
+  };
+  rc = stage();
+  if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c0)); }
+  if (all > cap) { return fail(m, SWA_E_CAPACITY, "swa_multi_d1_network: neighbour buffer too small"); }
+  return SWA_OK;
+}
+
+// B2 on all GPUs: heavy amplicons split over the ranks, graft_cand combined with MIN, heavy counters summed
+extern "C" int swa_multi_d1_fastidious(swa_multi * m, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
+                                       uint32_t * graft_cand, uint64_t * counters) {
+  if (m == nullptr || is_light == nullptr || graft_cand == nullptr || counters == nullptr) { return SWA_E_ARG; }
+  const int world = (int)m->ctx.size();
+  const uint32_t n = m->ctx[0]->db.n;
+  std::vector<std::vector<uint32_t>> scratch((size_t)world);
+  std::vector<std::vector<uint64_t>> cnt((size_t)world, std::vector<uint64_t>(8, 0));
+  int rc = on_all(m, [&](int r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    if (!c->d1_ready) { int dup = 0; SWA_TRY(swa_d1_index_build(c, &dup)); }
+    uint32_t * host = graft_cand;
+    if (r != 0) { scratch[(size_t)r].resize(n); host = scratch[(size_t)r].data(); }   // (the per-rank host copy is not the result)
+    return swa_d1_fastidious_shard(c, is_light, light_nt, bloom_bits, (uint32_t)r, (uint32_t)world, host, cnt[(size_t)r].data());
+  });
+  if (rc != SWA_OK) { return rc; }
+  for (int k = 0; k < 5; ++k) { counters[k] = cnt[0][(size_t)k]; }
+  for (int r = 1; r < world; ++r) { counters[1] += cnt[(size_t)r][1]; counters[2] += cnt[(size_t)r][2]; }
+  if (world == 1 && m->comms.empty()) { return SWA_OK; }
+  // element-wise minimum of the ranks' graft_cand arrays, which are still in HBM (d_graft)
+  if (!m->comms.empty()) {
+    NCCL_OK(m, ncclGroupStart());
+    for (int r = 0; r < world; ++r) {
+      NCCL_OK(m, ncclAllReduce(m->ctx[(size_t)r]->d_graft.ptr, m->ctx[(size_t)r]->d_graft.ptr, n, ncclUint32, ncclMin, m->comms[(size_t)r],
+                               m->ctx[(size_t)r]->stream));
+    }
+    NCCL_OK(m, ncclGroupEnd());
+  } else {
+    swa_ctx * c0 = m->ctx[0];
+    if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+    rc = swa_reserve(c0, m->gathered[0], (uint64_t)n * sizeof(uint32_t));
+    if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c0)); }
+    for (int r = 1; r < world; ++r) {
+      if (hipMemcpyAsync(m->gathered[0].ptr, m->ctx[(size_t)r]->d_graft.ptr, (uint64_t)n * sizeof(uint32_t), hipMemcpyDefault, c0->stream) != hipSuccess) {
+        return fail(m, SWA_E_DEVICE, "device-to-device copy of graft candidates failed");
+      }
+      hipLaunchKernelGGL(k_min_u32, dim3(blocks_for(c0, n)), dim3(256), 0, c0->stream, static_cast<uint32_t *>(c0->d_graft.ptr),
+                         static_cast<const uint32_t *>(m->gathered[0].ptr), (uint64_t)n);
+    }
+  }
+  swa_ctx * c0 = m->ctx[0];
+  if (hipSetDevice(c0->device) != hipSuccess ||
+      hipMemcpyAsync(graft_cand, c0->d_graft.ptr, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c0->stream) != hipSuccess ||
+      hipStreamSynchronize(c0->stream) != hipSuccess) {
+    return fail(m, SWA_E_DEVICE, "download of the combined graft candidates failed");
+  }
+  return SWA_OK;
+}

@@ -1,0 +1,78 @@
+"""d = 1 on several GPUs from C++ (swa_multi_*, swarm_amd/csrc/multi.hip): one context + host thread per
+rank inside the library, ownership sharding, link lists all-gathered, fastidious shards combined with MIN.  A
+one-GPU box runs it with several ranks on device 0 (the exchange then uses device-to-device copies) and with ONE
+rank through RCCL (communicator of size 1: the ncclBroadcast / ncclAllReduce calls themselves).  Whatever the
+device list, the result must be the single-GPU result, byte for byte."""
+import filecmp
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import support as S
+from swarm_amd import Context, D1Clusters, HostDb, MultiContext
+
+pytestmark = pytest.mark.gpu
+BIN = S.ROOT / "swarm_amd" / "bin" / "swarm"
+
+
+@pytest.fixture(scope="module")
+def light_set(tmp_path_factory):
+    fa = tmp_path_factory.mktemp("multi") / "in.fa"
+    S.gen_fasta(fa, 60000, 150, 61, 1, 0.3)
+    hdb = HostDb(fa)
+    ctx = Context(0)
+    ctx.upload_hostdb(hdb)
+    assert ctx.d1_index_build() is False
+    off, nb = ctx.d1_network()
+    cl = D1Clusters(hdb, off, nb)
+    flags, stats = cl.light_flags(3)
+    graft, counters = ctx.d1_fastidious(flags, stats[2], 16)
+    ctx.close()
+    return fa, hdb, off, nb, flags, stats, graft, counters
+
+
+@pytest.mark.parametrize("devices,rccl", [([0, 0], False), ([0, 0, 0], False), ([0], True)])
+def test_multi_matches_single(light_set, monkeypatch, devices, rccl):
+    fa, hdb, off, nb, flags, stats, graft, counters = light_set
+    if rccl:
+        monkeypatch.setenv("SWARM_AMD_FORCE_RCCL", "1")
+    m = MultiContext(devices)
+    assert m.uses_rccl() is rccl
+    m.upload_hostdb(hdb)
+    for ncb in (False, True):
+        moff, mnb = m.d1_network(ncb)
+        if not ncb:
+            assert np.array_equal(moff, off) and np.array_equal(mnb, nb)
+    moff, mnb = m.d1_network(False)
+    assert np.array_equal(moff, off) and np.array_equal(mnb, nb)
+    mgraft, mcounters = m.d1_fastidious(flags, stats[2], 16)
+    assert np.array_equal(mgraft, graft)
+    assert [int(x) for x in mcounters[:5]] == [int(x) for x in counters[:5]]
+    m.close()
+
+
+@pytest.mark.parametrize("args", [["-d", "1"], ["-d", "1", "-f"], ["-d", "1", "-n"]])
+def test_cli_with_several_ranks_is_byte_identical(light_set, tmp_path, args):
+    fa = light_set[0]
+    outs = {}
+    for tag, env in (("one", {}), ("two", {"SWARM_AMD_DEVICES": "0,0"}), ("three", {"SWARM_AMD_DEVICES": "0,0,0"})):
+        cmd = [str(BIN)] + args + ["-o", str(tmp_path / f"{tag}.o"), "-s", str(tmp_path / f"{tag}.s"), "-i", str(tmp_path / f"{tag}.i"),
+                                   "-j", str(tmp_path / f"{tag}.j"), "-l", str(tmp_path / f"{tag}.log"), str(fa)]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs[tag] = tmp_path
+    for tag in ("two", "three"):
+        for suffix in "osij":
+            assert filecmp.cmp(tmp_path / f"one.{suffix}", tmp_path / f"{tag}.{suffix}", shallow=False), (tag, suffix)
+        keep = lambda p: [ln for ln in p.read_text().splitlines() if ln.startswith(("Number", "Largest", "Max", "Got", "Made", "Heavy var", "Generated"))]
+        assert keep(tmp_path / "one.log") == keep(tmp_path / f"{tag}.log")
+
+
+def test_multi_reports_duplicates(tmp_path):
+    fa = tmp_path / "dup.fa"
+    seq = "ACGTTGCAAGCTTAGCGATCGGATCCATGCAAGTCTAGCTAGGCTAACGTACGATCGATCGTAGCTAGCTAGCATCGATCAGCTACGACTAGCATCAGCTAC"
+    fa.write_text(f">a_3\n{seq}\n>b_2\n{seq}\n>c_1\n{seq[:-1]}G\n")
+    r = subprocess.run([str(BIN), "-d", "1", str(fa)], capture_output=True, text=True, env=dict(os.environ, SWARM_AMD_DEVICES="0,0"))
+    assert r.returncode == 1 and "some fasta entries have identical sequences" in r.stderr
