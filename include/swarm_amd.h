@@ -78,6 +78,9 @@ void swa_ctx_destroy(swa_ctx * ctx);
 const char * swa_last_error(const swa_ctx * ctx);
 /* blocks until everything enqueued on the context's stream has finished */
 int  swa_ctx_synchronize(swa_ctx * ctx);
+/* Optional: pays the device's first-use costs (memory pools, copy queues, code-object loads) now — e.g. on a helper
+   thread while the caller reads its input. */
+int  swa_ctx_warmup(swa_ctx * ctx);
 
 /* Per-kernel timing with HIP events on the context's stream (off by default).
    swa_timing_read: ms[0] seqhash, [1] table+Bloom build, [2] duplicate check,
@@ -146,6 +149,18 @@ int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t
    {variants, bloom_pass, hash_match, verified, hits, 0,0,0} */
 int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out_bytes);
 uint64_t swa_d1_table_size(const swa_ctx * ctx);
+
+/* The same network computed into the context's own HBM buffers and kept there (no host copy):
+   *total = number of links.  swa_d1_network_fetch copies it out later if somebody wants the lists (-j);
+   swa_d1_cluster_device evaluates the agglomeration of src/algod1.cc:1175-1257 on it where it lies:
+   swarmid / generation / parent per amplicon (parent = SWA_NO_AMPLICON for seeds), `order` = the members
+   swarm after swarm (swarms by seed id, members seed first, then by generation and id), swarm s =
+   order[swarm_begin[s], swarm_begin[s + 1]).  swarm_begin holds swarm_cap + 1 entries; SWA_E_CAPACITY
+   with *nswarms = the number of swarms when that is too small (n always suffices). */
+int swa_d1_network_resident(swa_ctx * ctx, int no_cluster_breaking, uint64_t * total);
+int swa_d1_network_fetch(swa_ctx * ctx, uint64_t * offsets, uint32_t * neighbours, uint64_t cap);
+int swa_d1_cluster_device(swa_ctx * ctx, uint32_t * swarmid, uint32_t * generation, uint32_t * parent, uint32_t * order,
+                          uint32_t * swarm_begin, uint32_t swarm_cap, uint32_t * nswarms);
 
 /* ---- B2: fastidious second pass ------------------------------------------------- */
 /* is_light[n]: != 0 when the amplicon's swarm has mass < boundary.  light_nt: total

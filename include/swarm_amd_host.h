@@ -41,6 +41,9 @@ typedef struct swa_d1_result swa_d1_result;
    (replaces the clustering loop of algo_d1_run, src/algod1.cc:1185-1280). */
 int  swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,
                     swa_d1_result ** out);
+/* The same result from the network that swa_d1_network_resident left in HBM: evaluated on the GPU
+   (swa_d1_cluster_device), per-swarm sums on the host.  Needs the context that holds the network. */
+int  swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
 void swa_d1_result_free(swa_d1_result * res);
 /* out4 = {swarms after grafting, largest swarm, max generations, swarms before grafting}
    (the numbers of the log's summary lines, src/algod1.cc:1484-1487) */

@@ -37,7 +37,8 @@ class DbView(C.Structure):
 
 
 EXPORTS = [
-    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize",
+    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup",
+    "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_resident",
     "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
@@ -205,6 +206,22 @@ class D1Clusters:
             raise SwaError(rc, "swa_d1_cluster failed")
         self.h = h
 
+    @classmethod
+    def from_resident(cls, ctx: "Context", hdb: HostDb) -> "D1Clusters":
+        """The same result from the network ctx.d1_network_resident() left in HBM: agglomeration on the GPU
+        (swa_d1_cluster_device), per-swarm sums on the host."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.hdb = hdb
+        self._keep = None
+        self.lib.swa_d1_cluster_resident.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        rc = self.lib.swa_d1_cluster_resident(ctx.h, hdb.h, C.byref(h))
+        self.h = h
+        if rc != SWA_OK:
+            raise SwaError(rc, "swa_d1_cluster_resident failed: " + ctx.lib.swa_last_error(ctx.h).decode())
+        return self
+
     def summary(self) -> dict:
         out = np.zeros(4, dtype=np.uint64)
         self.lib.swa_d1_result_summary(self.h, _p64(out))
@@ -358,6 +375,20 @@ class Context:
             if rc == SWA_OK:
                 return offsets, nb[:total.value]
             cap = int(total.value)
+
+    def d1_network_resident(self, no_cluster_breaking: bool = False) -> int:
+        """The network of the whole database computed into the context's own HBM buffers and kept there."""
+        self.lib.swa_d1_network_resident.argtypes = [C.c_void_p, C.c_int, u64p]
+        total = C.c_uint64(0)
+        self._check(self.lib.swa_d1_network_resident(self.h, int(no_cluster_breaking), C.byref(total)))
+        return int(total.value)
+
+    def d1_network_fetch(self, total: int):
+        self.lib.swa_d1_network_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        offsets = np.zeros(self.n + 1, dtype=np.uint64)
+        nb = np.zeros(max(total, 1), dtype=np.uint32)
+        self._check(self.lib.swa_d1_network_fetch(self.h, _ptr(offsets), _ptr(nb), len(nb)))
+        return offsets, nb[:total]
 
     def d1_network_device(self, d_offsets, d_neighbours, cap: int, no_cluster_breaking: bool = False,
                           first: int = 0, count: int | None = None) -> int:

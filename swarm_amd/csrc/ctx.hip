@@ -64,6 +64,29 @@ extern "C" int swa_ctx_create(int device, void * stream, swa_ctx ** out) {
   return SWA_OK;
 }
 
+// First use of a device costs: memory pools, copy queues and — per translation unit — the load of its code object
+// at the first kernel launch (~0.25 s in all at 10 M amplicons).  A caller that has something else to do meanwhile
+// (reading a FASTA file) runs this on a helper thread right after swa_ctx_create.
+void swa_warm_d1(swa_ctx * ctx);          // d1.hip
+void swa_warm_cluster(swa_ctx * ctx);     // cluster_gpu.hip
+__global__ void k_warm(uint32_t * p) { if (threadIdx.x == 0u && p != nullptr) { p[0] = 1u; } }
+
+extern "C" int swa_ctx_warmup(swa_ctx * ctx) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  void * d = nullptr;
+  std::vector<uint8_t> host(1u << 20, 1);
+  SWA_HIP(ctx, hipMalloc(&d, 64u << 20));
+  SWA_HIP(ctx, hipMemcpyAsync(d, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, ctx->stream, static_cast<uint32_t *>(d));
+  swa_warm_d1(ctx);
+  swa_warm_cluster(ctx);
+  SWA_HIP(ctx, hipMemcpyAsync(host.data(), d, 4096, hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SWA_HIP(ctx, hipFree(d));
+  return SWA_OK;
+}
+
 extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
   if (ctx == nullptr) { return; }
   (void)hipSetDevice(ctx->device);
@@ -79,7 +102,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_acursor[0], &ctx->d_acursor[1], &ctx->d_aoffsets[0], &ctx->d_aoffsets[1], &ctx->d_aslot[0],
                        &ctx->d_aslot[1], &ctx->d_amembers[0], &ctx->d_amembers[1], &ctx->d_aitems[0], &ctx->d_aitems[1],
                        &ctx->d_frole, &ctx->d_fkeys, &ctx->d_fcnt, &ctx->d_foff, &ctx->d_fslot, &ctx->d_fmembers, &ctx->d_fitems,
-                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals}) {
+                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster}) {
     swa_release(*b);
   }
   if (ctx->h_scan_pinned != nullptr) { (void)hipHostFree(ctx->h_scan_pinned); }
@@ -140,6 +163,7 @@ static void invalidate(swa_ctx * ctx) {
   ctx->scan_ready = false;
   ctx->dn_graph_ready = false;
   ctx->dn_shortest = 0;
+  ctx->csr_ready = false;
 }
 
 extern "C" int swa_db_upload(swa_ctx * ctx, const swa_db_view * h) {

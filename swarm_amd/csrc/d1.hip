@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
                                                  const uint32_t * __restrict__ seqlen,
                                                  const uint64_t * __restrict__ zobrist, uint32_t zlen,
                                                  uint32_t n, uint64_t * __restrict__ seqhash,
-                                                 swa_aux * __restrict__ aux, const uint32_t * __restrict__ slot_p,
-                                                 const uint32_t * __restrict__ slot_s) {
+                                                 swa_aux * __restrict__ aux, const uint32_t * __restrict__ list,
+                                                 const uint64_t * __restrict__ list_count) {
   extern __shared__ uint64_t lds[];
   const uint64_t * zob = zobrist;
   if (ZLDS) {
@@ -95,9 +95,11 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
     __syncthreads();
     zob = lds;
   }
-  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
-    // ownership (multi-GPU): only members of this rank's anchor groups are ever looked at
-    if (slot_p != nullptr && slot_p[a] == kEmpty && slot_s[a] == kEmpty) { continue; }
+  // list != nullptr: only the amplicons of that list (the members of the anchor groups a rank serves: dense
+  // waves, work proportional to the rank's share instead of a walk over the whole replicated database)
+  const uint32_t todo = list != nullptr ? (uint32_t)*list_count : n;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < todo; k += gridDim.x * blockDim.x) {
+    const uint32_t a = list != nullptr ? list[k] : k;
     const uint64_t * s = seqs + seq_off[a];
     const uint32_t len = seqlen[a];
     uint64_t h = 0, dall = 0, iall = 0;
@@ -802,6 +804,12 @@ int grid_for(const swa_ctx * ctx, uint64_t items, int per_block, int max_per_cu)
 
 }  // namespace
 
+// loads this translation unit's code object (see swa_ctx_warmup): an empty launch
+void swa_warm_d1(swa_ctx * ctx) {
+  hipLaunchKernelGGL(k_table_clear, dim3(1), dim3(64), 0, ctx->stream, static_cast<swa_slot *>(nullptr), (uint64_t)0,
+                     static_cast<uint64_t *>(nullptr), (uint64_t)0);
+}
+
 // shared with fastidious.hip
 int swa_d1_rebuild_table(swa_ctx * ctx, const uint8_t * d_is_member) {
   const uint32_t n = ctx->db.n;
@@ -1023,18 +1031,24 @@ static int prepare_hashing(swa_ctx * ctx) {
 static int launch_seqhash(swa_ctx * ctx, bool members_only) {
   const uint32_t n = ctx->db.n;
   const size_t zbytes = 4ull * ctx->zobrist_len * sizeof(uint64_t);
-  const uint32_t * slot_p = members_only ? static_cast<const uint32_t *>(ctx->d_aslot[0].ptr) : nullptr;
-  const uint32_t * slot_s = members_only ? static_cast<const uint32_t *>(ctx->d_aslot[1].ptr) : nullptr;
-  const int hgrid = grid_for(ctx, n, 256, 8);
+  const bool zlds = zbytes <= kMaxZobristLds;
+  if (ctx->owner_world == 1) { members_only = false; }        // a single GPU owns every group: everybody is a member
   swa_t0(ctx, 0);
-  if (zbytes <= kMaxZobristLds) {
-    hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                       ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), slot_p, slot_s);
-  } else {
-    hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                       ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), slot_p, slot_s);
+  // members_only: the member lists of the two anchor indexes (an amplicon in both is hashed twice: same values)
+  for (int pass = 0; pass < (members_only ? 2 : 1); ++pass) {
+    const uint32_t * list = members_only ? static_cast<const uint32_t *>(ctx->d_amembers[pass].ptr) : nullptr;
+    const uint64_t * list_count = members_only ? static_cast<const uint64_t *>(ctx->d_aoffsets[pass].ptr) + ctx->anchor_slots : nullptr;
+    const uint64_t upper = members_only && ctx->owner_world > 1 ? (uint64_t(n) / ctx->owner_world) * 2 + 1024 : n;
+    const int hgrid = grid_for(ctx, upper, 256, 8);
+    if (zlds) {
+      hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                         ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
+                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count);
+    } else {
+      hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                         ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
+                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count);
+    }
   }
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 0);

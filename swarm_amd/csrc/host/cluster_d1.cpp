@@ -145,26 +145,54 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   auto & parent = r->parent;
 #pragma omp parallel for schedule(static)
   for (int64_t v = 0; v < n64; ++v) { gen[(size_t)v] = label[(size_t)v] == (uint32_t)v ? 0u : kUnset; parent[(size_t)v] = kUnset; }
-  for (uint32_t level = 1;; ++level) {
-    bool grew = false;
-    // one sweep per level: a node reached from level - 1 gets this level (possibly from several
-    // threads at once, all writing the same value) and keeps the smallest id that reached it
-#pragma omp parallel for schedule(dynamic, 8192) reduction(|| : grew)
-    for (int64_t u = 0; u < n64; ++u) {
-      if (__atomic_load_n(&gen[(size_t)u], __ATOMIC_RELAXED) != level - 1) { continue; }   // (others may be assigning `level` right now)
-      const uint32_t lu = label[(size_t)u];
-      for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
-        const uint32_t v = neighbours[e];
-        if (label[v] != lu) { continue; }
-        const uint32_t gv = __atomic_load_n(&gen[v], __ATOMIC_RELAXED);
-        if (gv == kUnset || gv == level) {
-          if (gv == kUnset) { __atomic_store_n(&gen[v], level, __ATOMIC_RELAXED); }
-          atomic_min_u32(&parent[v], (uint32_t)u);
-          grew = true;
+  // Frontier by frontier (not a sweep over all amplicons per level: swarms can be hundreds of generations
+  // deep): the nodes of level - 1 are a list; a node is claimed for `level` by exactly one thread (compare and
+  // swap on its generation), which appends it to that thread's piece of the next list; parents are the
+  // smallest claiming or co-claiming id, by atomic minimum.
+  {
+    const int nthreads = std::max(1, omp_get_max_threads());
+    std::vector<std::vector<uint32_t>> piece((size_t)nthreads);
+    std::vector<uint32_t> frontier, next;
+    // level 0 = the seeds
+#pragma omp parallel
+    {
+      auto & mine = piece[(size_t)omp_get_thread_num()];
+      mine.clear();
+#pragma omp for schedule(static) nowait
+      for (int64_t v = 0; v < n64; ++v) { if (label[(size_t)v] == (uint32_t)v) { mine.push_back((uint32_t)v); } }
+    }
+    auto gather_pieces = [&](std::vector<uint32_t> & into) {
+      std::vector<size_t> at((size_t)nthreads + 1, 0);
+      for (int t = 0; t < nthreads; ++t) { at[(size_t)t + 1] = at[(size_t)t] + piece[(size_t)t].size(); }
+      into.resize(at[(size_t)nthreads]);
+#pragma omp parallel for schedule(static, 1)
+      for (int t = 0; t < nthreads; ++t) { std::copy(piece[(size_t)t].begin(), piece[(size_t)t].end(), into.begin() + (std::ptrdiff_t)at[(size_t)t]); }
+    };
+    gather_pieces(frontier);
+    for (uint32_t level = 1; !frontier.empty(); ++level) {
+      const int64_t fsize = (int64_t)frontier.size();
+#pragma omp parallel
+      {
+        auto & mine = piece[(size_t)omp_get_thread_num()];
+        mine.clear();
+#pragma omp for schedule(dynamic, 2048) nowait
+        for (int64_t k = 0; k < fsize; ++k) {
+          const uint32_t u = frontier[(size_t)k];
+          const uint32_t lu = label[u];
+          for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
+            const uint32_t v = neighbours[e];
+            if (label[v] != lu) { continue; }
+            uint32_t gv = __atomic_load_n(&gen[v], __ATOMIC_RELAXED);
+            if (gv == kUnset) {
+              if (__atomic_compare_exchange_n(&gen[v], &gv, level, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { mine.push_back(v); gv = level; }
+            }
+            if (gv == level) { atomic_min_u32(&parent[v], u); }   // (gv holds the winner's value after a lost exchange)
+          }
         }
       }
+      gather_pieces(next);
+      frontier.swap(next);
     }
-    if (!grew) { break; }
   }
   lap("generations + parents");
   // 3. swarms in seed order, members by (generation, id)
@@ -235,6 +263,53 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
 }
 
 }  // namespace
+
+// ---- the same result from the network that is still in HBM (cluster_gpu.hip) ------------------
+// swa_d1_network_resident left the CSR on the device; the three order-free statements above are evaluated
+// there and only swarm / generation / parent / member order come back.  The per-swarm sums stay here.
+extern "C" int swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out) {
+  if (ctx == nullptr || db == nullptr || out == nullptr) { return SWA_E_ARG; }
+  auto * r = new swa_d1_result();
+  *out = r;
+  const uint32_t n = db->n;
+  r->n = n;
+  fill_parallel(r->swarmid, n, (uint32_t)SWA_NO_AMPLICON);
+  fill_parallel(r->parent, n, (uint32_t)SWA_NO_AMPLICON);
+  fill_parallel(r->generation, n, 0u);
+  fill_parallel(r->graft_cand, n, (uint32_t)SWA_NO_AMPLICON);
+  fill_parallel(r->order, n, 0u);
+  if (n == 0) { return SWA_OK; }
+  swa_vec<uint32_t> begin;
+  fill_parallel(begin, (size_t)n + 1, 0u);
+  uint32_t nswarms = 0;
+  const int rc = swa_d1_cluster_device(ctx, r->swarmid.data(), r->generation.data(), r->parent.data(), r->order.data(), begin.data(), n,
+                                       &nswarms);
+  if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  fill_parallel(r->swarms, nswarms, swa_d1_result::empty_swarm());
+  uint32_t largest = 0, maxgen = 0;
+  const auto & gen = r->generation;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(max : largest) reduction(max : maxgen)
+  for (int64_t s = 0; s < (int64_t)nswarms; ++s) {
+    auto & sw = r->swarms[(size_t)s];
+    sw.begin = begin[(size_t)s];
+    sw.end = begin[(size_t)s + 1];
+    sw.seed = r->order[sw.begin];
+    sw.size = sw.end - sw.begin;
+    for (uint32_t k = sw.begin; k < sw.end; ++k) {
+      const uint32_t a = r->order[k];
+      sw.mass += db->abundance[a];
+      sw.sumlen += db->seqlen[a];
+      if (db->abundance[a] == 1) { ++sw.singletons; }
+      sw.maxgen = std::max(sw.maxgen, gen[a]);
+    }
+    largest = std::max(largest, sw.size);
+    maxgen = std::max(maxgen, sw.maxgen);
+  }
+  r->largest = largest;
+  r->maxgen = maxgen;
+  r->swarmcount_adjusted = r->swarms.size();
+  return SWA_OK;
+}
 
 // ---- clustering (src/algod1.cc:1185-1280, process_seed 673-718) ------------------------
 extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint32_t * neighbours,

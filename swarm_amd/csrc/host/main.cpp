@@ -9,6 +9,8 @@
 //
 // Environment (no new flags, to stay drop-in): SWARM_AMD_DEVICE = HIP device ordinal (default 0);
 // SWARM_AMD_DEVICES = 0,1,2,... : d = 1 on several GPUs (swa_multi_*: one rank per entry, RCCL exchange).
+#include <chrono>
+#include <thread>
 #include "../../../include/swarm_amd.h"
 #include "../../../include/swarm_amd_host.h"
 
@@ -202,9 +204,17 @@ void validate(const Options & o) {            // src/swarm.cc:486-630, same orde
 }
 
 // a phase line of the log: "<prompt> 100%" (the reference animates a percentage on a tty)
+// SWARM_AMD_TIMING=1: seconds since process start at every milestone, on stderr
+void stamp(const char * what) {
+  static const bool on = std::getenv("SWARM_AMD_TIMING") != nullptr;
+  static const auto t0 = std::chrono::steady_clock::now();
+  if (on) { std::fprintf(stderr, "[t %8.3f] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); }
+}
+
 void phase(const Options &, const char * prompt) {
   std::fprintf(g_log, "%s 100%%\n", prompt);
   std::fflush(g_log);
+  stamp(prompt);
 }
 
 void check_writer(int rc, const char * what) {
@@ -214,6 +224,7 @@ void check_writer(int rc, const char * what) {
 }  // namespace
 
 int main(int argc, char ** argv) {
+  stamp("start");
   Options o = parse(argc, argv);
   validate(o);
   if (!o.log.empty()) {
@@ -240,9 +251,34 @@ int main(int argc, char ** argv) {
   else { std::fprintf(g_log, "Fastidious:        No\n"); }
   std::fprintf(g_log, "\n");
 
+  // The GPU context (HIP runtime start-up, ~0.25 s) is created by a helper thread while this one reads the FASTA file.
+  std::vector<int> devices;
+  if (const char * list = std::getenv("SWARM_AMD_DEVICES")) {
+    for (const char * p = list; *p != '\0';) {
+      char * end = nullptr;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) { break; }
+      devices.push_back((int)v);
+      p = (*end == ',') ? end + 1 : end;
+    }
+  }
+  const bool use_multi = devices.size() > 1 && o.differences == 1;
+  swa_ctx * early_ctx = nullptr;
+  int early_rc = SWA_OK;
+  std::thread early;
+  if (!use_multi) {
+    const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
+    const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
+    early = std::thread([&early_ctx, &early_rc, device]() {
+      early_rc = swa_ctx_create(device, nullptr, &early_ctx);
+      if (early_rc == SWA_OK) { (void)swa_ctx_warmup(early_ctx); }
+    });
+  }
+
   // ---- read the database (seam L2, host side)
   swa_hostdb * db = nullptr;
   int rc = swa_hostdb_read_fasta(o.input.c_str(), o.usearch ? 1 : 0, o.append_abundance, o.differences > 1 ? 1 : 0, &db);
+  if (early.joinable()) { early.join(); }
   if (rc != SWA_OK) { die_raw(db != nullptr ? swa_hostdb_error(db) : "\nError: out of memory"); }
   phase(o, "Reading sequences:");
   phase(o, "Indexing database:");
@@ -256,29 +292,18 @@ int main(int argc, char ** argv) {
   swa_ctx * ctx = nullptr;
   swa_multi * multi = nullptr;           // d = 1 on several GPUs: SWARM_AMD_DEVICES=0,1,2,... (one rank per entry)
   if (n > 0) {
-    std::vector<int> devices;
-    if (const char * list = std::getenv("SWARM_AMD_DEVICES")) {
-      for (const char * p = list; *p != '\0';) {
-        char * end = nullptr;
-        const long v = std::strtol(p, &end, 10);
-        if (end == p) { break; }
-        devices.push_back((int)v);
-        p = (*end == ',') ? end + 1 : end;
-      }
-    }
-    if (devices.size() > 1 && o.differences == 1) {
+    if (use_multi) {
       if (swa_multi_create(devices.data(), (int)devices.size(), &multi) != SWA_OK) {
         die(multi != nullptr ? swa_multi_last_error(multi) : "no usable gfx950 GPU (this build has no CPU fallback).");
       }
       if (swa_multi_db_upload(multi, &view) != SWA_OK) { die(swa_multi_last_error(multi)); }
       ctx = swa_multi_ctx(multi, 0);
     } else {
-      const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
-      const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
-      if (swa_ctx_create(device, nullptr, &ctx) != SWA_OK) {
-        die("no usable gfx950 GPU (this build has no CPU fallback).");
-      }
+      if (early_rc != SWA_OK || early_ctx == nullptr) { die("no usable gfx950 GPU (this build has no CPU fallback)."); }
+      ctx = early_ctx;
+      stamp("context created");
       if (swa_db_upload(ctx, &view) != SWA_OK) { die(swa_last_error(ctx)); }
+      stamp("database uploaded");
     }
   }
 
@@ -303,8 +328,10 @@ int main(int argc, char ** argv) {
     swa_d0_result_free(res);
   } else if (o.differences == 1) {
     // ---- seam B1: the network on the GPU
-    std::vector<uint64_t> offsets((size_t)n + 1, 0);
+    std::vector<uint64_t> offsets;              // (the CSR only comes to the host for -j and from several GPUs)
     std::vector<uint32_t> neighbours;
+    bool resident = false;
+    if (multi != nullptr || !o.network.empty()) { offsets.assign((size_t)n + 1, 0); }
     const char * dup_text = "some fasta entries have identical sequences.\n"
                             "Swarm expects dereplicated fasta files.\n"
                             "Such files can be produced with swarm or vsearch:\n"
@@ -338,15 +365,15 @@ int main(int argc, char ** argv) {
       }
       if (rc != SWA_OK) { die(swa_last_error(ctx)); }
       phase(o, "Hashing sequences:");
+      // the network stays in HBM: the agglomeration runs on it there; it only comes to the host for -j
       uint64_t total = 0;
-      neighbours.resize(std::max<size_t>(4 * (size_t)n, 1024));
-      for (;;) {
-        rc = swa_d1_network(ctx, o.no_break ? 1 : 0, 0, n, offsets.data(), neighbours.data(), neighbours.size(), &total);
-        if (rc == SWA_E_CAPACITY) { neighbours.resize(total); continue; }
-        if (rc != SWA_OK) { die(swa_last_error(ctx)); }
-        break;
+      rc = swa_d1_network_resident(ctx, o.no_break ? 1 : 0, &total);
+      if (rc != SWA_OK) { die(swa_last_error(ctx)); }
+      resident = true;
+      if (!o.network.empty()) {
+        neighbours.resize(total);
+        if (swa_d1_network_fetch(ctx, offsets.data(), neighbours.data(), neighbours.size()) != SWA_OK) { die(swa_last_error(ctx)); }
       }
-      neighbours.resize(total);
       phase(o, "Building network: ");
     }
     if (!o.network.empty()) {
@@ -355,7 +382,8 @@ int main(int argc, char ** argv) {
     }
     // ---- host: greedy clustering over the neighbour lists
     swa_d1_result * res = nullptr;
-    if (swa_d1_cluster(db, offsets.data(), neighbours.data(), &res) != SWA_OK) { die("clustering failed"); }
+    if (resident) { if (swa_d1_cluster_resident(ctx, db, &res) != SWA_OK) { die(swa_last_error(ctx)); } }
+    else if (swa_d1_cluster(db, offsets.data(), neighbours.data(), &res) != SWA_OK) { die("clustering failed"); }
     phase(o, "Clustering:       ");
     uint64_t sum[4];
     swa_d1_result_summary(res, sum);
@@ -457,9 +485,20 @@ int main(int argc, char ** argv) {
     std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
                  sum[1], sum[2]);
   }
+  stamp("results written");
+  // Every output file is closed at this point.  Tearing down gigabytes of host vectors, the device buffers and the
+  // HIP runtime costs ~0.25 s at 10 M amplicons and serves nobody: leave it to the kernel (SWARM_AMD_FULL_TEARDOWN=1
+  // keeps the orderly path, e.g. under a leak checker).
+  if (std::getenv("SWARM_AMD_FULL_TEARDOWN") == nullptr) {
+    if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
+    std::fflush(nullptr);
+    std::_Exit(EXIT_SUCCESS);
+  }
   if (multi != nullptr) { swa_multi_destroy(multi); }
   else if (ctx != nullptr) { swa_ctx_destroy(ctx); }
+  stamp("device released");
   swa_hostdb_free(db);
+  stamp("host database released");
   if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
   return EXIT_SUCCESS;
 }

@@ -106,6 +106,11 @@ struct swa_ctx {
   bool dn_graph_ready = false, dn_graph_ncb = false;
   uint64_t dn_pair_cap = 0, dn_comparisons = 0, dn_aligned = 0, dn_launches = 0, dn_edges = 0, dn_work = 0;
   swa_dbuf d_dn_keys, d_dn_vals;
+
+  // the d = 1 network kept in d_offsets_tmp / d_nb_tmp (swa_d1_network_resident) and its clustering (cluster_gpu.hip)
+  bool csr_ready = false;
+  uint64_t csr_total = 0;
+  swa_dbuf d_cluster;
 };
 
 int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e);

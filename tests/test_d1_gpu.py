@@ -384,3 +384,36 @@ def test_owner_ranks_find_duplicates_without_the_table(tmp_path):
             assert sum(found) == 1, found
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n,L,seed,ncb", [(1000, 150, 11, False), (30000, 150, 95, False), (20000, 80, 96, True), (400, 33, 97, False)])
+def test_device_clustering_equals_the_host_walk(gpu_ctx, tmp_path, n, L, seed, ncb):
+    """swa_d1_cluster_device (agglomeration on the network that stayed in HBM) against the serial walk of
+    cluster_d1.cpp over the downloaded CSR: swarm, generation, parent of every amplicon, and every output file."""
+    import filecmp
+    import os
+    from swarm_amd import D1Clusters, HostDb
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, n, L, seed)
+    hdb = HostDb(fa)
+    gpu_ctx.upload_hostdb(hdb)
+    assert gpu_ctx.d1_index_build() is False
+    total = gpu_ctx.d1_network_resident(ncb)
+    off, nb = gpu_ctx.d1_network_fetch(total)
+    woff, wnb = gpu_ctx.d1_network(ncb)
+    assert np.array_equal(off, woff) and np.array_equal(nb, wnb)
+    gpu_ctx.d1_network_resident(ncb)
+    dev = D1Clusters.from_resident(gpu_ctx, hdb)
+    os.environ["SWARM_AMD_CLUSTER"] = "serial"
+    try:
+        host = D1Clusters(hdb, off, nb)
+    finally:
+        del os.environ["SWARM_AMD_CLUSTER"]
+    assert dev.summary() == host.summary()
+    assert np.array_equal(dev.swarmid(), host.swarmid())
+    assert np.array_equal(dev.generation(), host.generation())
+    assert np.array_equal(dev.parent(), host.parent())
+    for name, fn in (("o", "write_swarms"), ("s", "write_stats"), ("i", "write_structure"), ("w", "write_seeds")):
+        getattr(dev, fn)(tmp_path / f"d{name}")
+        getattr(host, fn)(tmp_path / f"h{name}")
+        assert filecmp.cmp(tmp_path / f"d{name}", tmp_path / f"h{name}", shallow=False), name
