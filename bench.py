@@ -39,6 +39,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before torch / the library load libgomp (see swarm_amd/capi.py)
 import subprocess
 import sys
 import tempfile

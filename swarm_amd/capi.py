@@ -8,6 +8,10 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+
+# libgomp's default (workers spin between parallel regions) costs the host phases up to 30x on a many-core GPU host
+# (see host/main.cpp); it reads the variable when it is first loaded, which importing this module usually precedes.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 import subprocess
 from pathlib import Path
 

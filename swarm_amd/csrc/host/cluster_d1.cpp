@@ -273,6 +273,14 @@ extern "C" int swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa
   *out = r;
   const uint32_t n = db->n;
   r->n = n;
+  const bool timing = std::getenv("SWARM_AMD_CLUSTER_TIMING") != nullptr;
+  double t_last = omp_get_wtime();
+  auto lap = [&](const char * what) {
+    if (!timing) { return; }
+    const double now = omp_get_wtime();
+    std::fprintf(stderr, "[cluster] %-24s %8.3f ms\n", what, 1000.0 * (now - t_last));
+    t_last = now;
+  };
   fill_parallel(r->swarmid, n, (uint32_t)SWA_NO_AMPLICON);
   fill_parallel(r->parent, n, (uint32_t)SWA_NO_AMPLICON);
   fill_parallel(r->generation, n, 0u);
@@ -281,10 +289,12 @@ extern "C" int swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa
   if (n == 0) { return SWA_OK; }
   swa_vec<uint32_t> begin;
   fill_parallel(begin, (size_t)n + 1, 0u);
+  lap("result arrays");
   uint32_t nswarms = 0;
   const int rc = swa_d1_cluster_device(ctx, r->swarmid.data(), r->generation.data(), r->parent.data(), r->order.data(), begin.data(), n,
                                        &nswarms);
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  lap("device + download");
   fill_parallel(r->swarms, nswarms, swa_d1_result::empty_swarm());
   uint32_t largest = 0, maxgen = 0;
   const auto & gen = r->generation;
@@ -308,6 +318,7 @@ extern "C" int swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa
   r->largest = largest;
   r->maxgen = maxgen;
   r->swarmcount_adjusted = r->swarms.size();
+  lap("swarm table + sums");
   return SWA_OK;
 }
 

@@ -541,8 +541,11 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   if (!sorted.load()) {
     // libstdc++ parallel mode: multiway merge sort over the host cores (OpenMP); the order is a
     // strict total order (identifiers are unique), so the result equals std::sort's
+    // (thread count for this sort only: the process-wide setting belongs to the caller)
+    const int caller_threads = omp_get_max_threads();
     omp_set_num_threads((int)threads);
     __gnu_parallel::sort(recs.begin(), recs.end(), less);
+    omp_set_num_threads(caller_threads);
   }
   auto order = [&](uint64_t k) { return recs[k].entry; };
   timer.lap("sort");
@@ -602,17 +605,22 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   });
   db->seqs[woff] = 0;
   timer.lap("gather into db order");
-  // The parse buffers, the sort records and the input mapping (≈ 3 GB at 10 M amplicons) are torn
-  // down by a detached thread: returning them to the kernel took as long as the sort.
+  // The parse buffers, the sort records and the input mapping (≈ 3 GB at 10 M amplicons) are NOT returned to the
+  // kernel now: that takes as long as the sort, and done by a detached thread (as it was) it holds the process's
+  // memory-map lock just when the caller starts allocating and copying on the GPU (measured: the first upload
+  // stalled for ~0.25 s behind it).  They go when the handle is freed — or with the process.
+  // SWARM_AMD_EAGER_FREE=1: release them right away on a helper thread (small-memory hosts).
   struct Leftovers {
     std::vector<Piece> pieces; swa_vec<const RawEntry *> ent; swa_vec<SortRec> recs; const char * data; size_t size; bool mapped;
   };
   auto * rest = new Leftovers{std::move(pieces), std::move(ent), std::move(recs), in.data, in.size, in.mapped};
-  in.mapped = false;                                         // the thread below unmaps
-  std::thread([rest] {
+  in.mapped = false;                                         // (unmapped with the leftovers)
+  auto release = [rest] {
     if (rest->mapped) { ::munmap(const_cast<char *>(rest->data), rest->size); }
     delete rest;
-  }).detach();
+  };
+  if (std::getenv("SWARM_AMD_EAGER_FREE") != nullptr) { std::thread(release).detach(); }
+  else { db->release_leftovers = release; }
   timer.lap("hand-off of parse buffers");
   return SWA_OK;
 }

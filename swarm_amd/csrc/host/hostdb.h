@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <memory>
 #include <new>
+#include <functional>
 #include <string>
 #include <thread>
 #include <algorithm>
@@ -77,4 +78,8 @@ struct swa_hostdb {
   swa_vec<int32_t> ab_start;     // abundance annotation span inside each header
   swa_vec<int32_t> ab_end;
   std::string error;
+  // what the reader no longer needs (parse buffers, sort records, the input mapping: ~3 GB at 10 M amplicons), kept
+  // until the handle is freed — see swa_hostdb_read_fasta
+  std::function<void()> release_leftovers;
+  ~swa_hostdb() { if (release_leftovers) { release_leftovers(); } }
 };
