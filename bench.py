@@ -211,7 +211,8 @@ def md5_of(path) -> str:
 
 def config2_fastidious(args, n: int) -> dict:
     """BASELINE configs[2]: n x 150 with 30 % light amplicons, d=1 --fastidious, whole pipeline through the
-    C ABI from host buffers; the two fastidious kernel groups timed with HIP events.  SURVEY 8(d) bytes of the
+    C ABI as the command line drives it (network kept in HBM, agglomeration on the GPU, fastidious pair route);
+    the two fastidious kernel groups timed with HIP events.  SURVEY 8(d) bytes of the
     fastidious pass: 8 B per light microvariant (written) + 8 B per heavy microvariant (read); the second
     level (p V V' 8) is left out, so the fraction is a lower bound."""
     from swarm_amd import Context, D1Clusters, HostDb
@@ -229,8 +230,8 @@ def config2_fastidious(args, n: int) -> dict:
     ctx.timing_enable(True)
     timed("upload", lambda: ctx.upload_hostdb(hdb))
     timed("index_build", ctx.d1_index_build)
-    off, nb = timed("network_incl_download", ctx.d1_network)
-    cl = timed("host_clustering", lambda: D1Clusters(hdb, off, nb))
+    timed("network_resident", ctx.d1_network_resident)
+    cl = timed("clustering_gpu_plus_sums", lambda: D1Clusters.from_resident(ctx, hdb))
     flags, stats = timed("light_flags", cl.light_flags)
     graft, counters = timed("fastidious_gpu", lambda: ctx.d1_fastidious(flags, stats[2]))
     ms = ctx.timing_read()
