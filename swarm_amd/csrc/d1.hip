@@ -105,9 +105,17 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
     uint64_t h = 0, dall = 0, iall = 0;
     uint64_t word = 0;
     swa_aux ax{};
+    // pb: first position of the run that contains position 31 (see swa_aux)
+    uint32_t pb = kAnchor;
+    if (len >= kAnchor) {
+      const uint64_t w0 = s[0];
+      const uint64_t differs = w0 ^ ((w0 >> 62) * 0x5555555555555555ull);          // 2-bit groups != the nucleotide at 31
+      pb = differs == 0ull ? 0u : (uint32_t)(64 - __builtin_clzll(differs) + 1) >> 1;   // one past the last differing position
+    }
+    ax.pb = pb;
     for (uint32_t p = 0; p < len; ++p) {
       if ((p & 31u) == 0u) { word = s[p >> 5]; }
-      if (p == kAnchor) { ax.a32 = h; ax.d32 = dall; ax.i32 = iall; }      // the three streams below position 32
+      if (p == pb) { ax.a32 = h; ax.d32 = dall; ax.i32 = iall; }          // the three streams below position pb
       const uint32_t c = (uint32_t)(word & 3u);
       h ^= zob[4u * p + c];
       if (p >= 1u) { dall ^= zob[4u * (p - 1u) + c]; }
@@ -285,7 +293,7 @@ template <bool SECOND>
 __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64_t * sw, uint32_t slen,
                                                  uint32_t snw, uint32_t seed, uint64_t seed_abundance,
                                                  uint64_t h, uint32_t code, uint32_t & out_amp,
-                                                 uint32_t & n_match) {
+                                                 uint32_t & n_match, bool differ_prefix = false) {
   const uint32_t type = code & 3u;
   const uint32_t base = (code >> 2) & 3u;
   const uint32_t pos = code >> 4;
@@ -304,7 +312,7 @@ __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64
       else { allowed = amp != seed && (a.no_cluster_breaking != 0 || seed_abundance >= a.abundance[amp]); }
       if (allowed && alen == vlen) {
         const uint64_t * y = a.seqs + a.seq_off[amp];
-        bool same = true;
+        bool same = !differ_prefix || y[0] != sw[0];             // (suffix-pass share of a seed: first 32 nt must differ)
         for (uint32_t w = 0; w < vnw; ++w) {
           same = same && (swa_variant_word(sw, snw, type, pos, base, w) == y[w]);
         }
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
       uint32_t amp = 0;
       uint32_t nmatch = 0;
       if ((uint32_t)lane < cnt) {
-        hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch);
+        hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch, MODE == 2 && range == 2u);
       }
       const uint64_t hm = __ballot(hit);
       if (STATS) {
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
     };
     if (MODE == 2) {
       const swa_aux ax = a.aux[seed];
-      const uint32_t pb = range == 1u ? kAnchor : 0u;
+      const uint32_t pb = range == 1u ? ax.pb : 0u;            // range 1 = what the prefix pass would have done (swa_aux::pb)
       const uint32_t pe = range == 2u ? kAnchor : len + 1u;
       enumerate_range(sw, len, zob, lane, pb, pe < len + 1u ? pe : len + 1u, ax.h, range == 1u ? ax.a32 : 0ull,
                       range == 1u ? (ax.dall ^ ax.d32) : ax.dall, range == 1u ? (ax.iall ^ ax.i32) : ax.iall,
@@ -973,7 +981,8 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
                      count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
                      static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
-                     static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world);
+                     static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world,
+                     ctx->db.seqs, ctx->db.seq_off);
   NetArgs f{};
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
   f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
@@ -1103,7 +1112,7 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, std::max<uint64_t>(n, asize), 256, 8)), dim3(256), 0, ctx->stream,
                      ctx->db.seqlen, n, static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
-                     static_cast<const uint32_t *>(ctx->d_acounts[1].ptr), asize, dflags);
+                     static_cast<const uint32_t *>(ctx->d_acounts[1].ptr), asize, dflags, ctx->db.seqs, ctx->db.seq_off);
   SWA_TRY(launch_seqhash(ctx, true));
   // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
   swa_t0(ctx, 2);

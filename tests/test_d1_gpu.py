@@ -417,3 +417,32 @@ def test_device_clustering_equals_the_host_walk(gpu_ctx, tmp_path, n, L, seed, n
         getattr(dev, fn)(tmp_path / f"d{name}")
         getattr(host, fn)(tmp_path / f"h{name}")
         assert filecmp.cmp(tmp_path / f"d{name}", tmp_path / f"h{name}", shallow=False), name
+
+
+def test_runs_across_the_anchor_boundary(gpu_ctx, tmp_path):
+    """The passes divide a seed's microvariants by whether they keep its first 32 nucleotides (swa_aux::pb).  The cases
+    that rule exists for: homopolymer runs that cross position 31 / 32 with deletions and insertions inside the run
+    (generate_variants lists them at the run's FIRST position), and sequences whose first 32+ nucleotides are one run."""
+    rng = np.random.default_rng(17)
+    seqs = set()
+    for fam in range(300):
+        left = "".join(rng.choice(list("ACGT"), int(rng.integers(0, 31))))
+        run = str(rng.choice(list("ACGT"))) * int(rng.integers(2, 40))
+        if fam % 10 == 0:
+            left = ""                                          # the run starts at position 0: first 32 nt one run
+            run = run[0] * int(rng.integers(33, 45))
+        tail = "".join(rng.choice(list("ACGT"), 120))
+        base = (left + run + tail)[:130]
+        seqs.add(base)
+        for _ in range(12):
+            p = int(rng.integers(max(0, len(left) - 2), min(len(base), len(left) + len(run) + 2)))
+            k = int(rng.integers(0, 3))
+            b = str(rng.choice(list("ACGT")))
+            seqs.add(base[:p] + b + base[p + 1:] if k == 0 else (base[:p] + base[p + 1:] if k == 1 else base[:p] + b + base[p:]))
+    seqs = sorted(seqs)
+    fa = tmp_path / "runs.fa"
+    fa.write_text("".join(f">r{i}_{int(rng.integers(1, 4))}\n{s}\n" for i, s in enumerate(seqs)))
+    db = S.db_from_fasta(fa)
+    off, nb = _check_vs_oracle(gpu_ctx, db)
+    assert len(nb) > 3000
+    _check_vs_oracle(gpu_ctx, db, ncb=True)

@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps $STEPS --warmup 1 --no-extras"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o d1 -- $BENCH > "$OUT/trace.log" 2>&1
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
