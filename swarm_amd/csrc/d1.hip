@@ -931,13 +931,17 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   swa_t0(ctx, 3);
   // work items: every group of the index (it was built for exactly this query range)
   const uint64_t asize = ctx->anchor_slots;
+  // small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_pairs), else by
+  // enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
+  const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
+  const int pairs_width = (env_enum != nullptr && env_enum[0] == '1') ? 0 : (ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0));
   for (int which = 0; which < 2; ++which) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                        static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
                        static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr), acounters + which,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr) + small_items_at(ctx->db.n), acounters + 3 + which,
-                       which == 0 ? kSmallChunkPrefix : kSmallChunkSuffix);
+                       pairs_width != 0 ? kSmallGroup : (which == 0 ? kSmallChunkPrefix : kSmallChunkSuffix));
   }
   SWA_HIP(ctx, hipGetLastError());
   for (int pass = 0; pass < 2; ++pass) {
@@ -966,7 +970,15 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.small_chunk = pass == 0 ? kSmallChunkPrefix : kSmallChunkSuffix;
     a.table_slots = 2 * kSmallGroup;
     const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom
-    if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
+    if (pairs_width == 5) {
+      a.small_chunk = kSmallGroup;
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs<0, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_pairs<1, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+    } else if (pairs_width == 8) {
+      a.small_chunk = kSmallGroup;
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs<0, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_pairs<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+    } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
