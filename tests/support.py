@@ -284,3 +284,26 @@ def gen_bin() -> Path:
 def gen_fasta(path, n: int, length: int, seed: int, max_edits: int = 1, light_frac: float = 0.0) -> None:
     subprocess.run([str(gen_bin()), str(n), str(length), str(seed), str(max_edits), str(light_frac), str(path)],
                    check=True)
+
+
+# -------------------------------------------------------------------- device memory poison
+
+def poison_device_memory(chunks: int = 32, chunk_bytes: int = 1 << 28) -> None:
+    """Fill `chunks` x `chunk_bytes` of HBM with non-zero bytes and free it again, through the same HIP runtime the
+    library uses (libamdhip64.so, already loaded with it): what the library allocates next has been 0xA5 / 0xFF /
+    0x01 / 0x5A, not zero.  (torch is deliberately not used here: its wheel carries its own copy of the HIP
+    runtime, and initialising that one after the library's has been seen to fail with "No HIP GPUs are available".)"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    held = []
+    for k in range(chunks):
+        ptr = C.c_void_p()
+        if hip.hipMalloc(C.byref(ptr), chunk_bytes) != 0:
+            break
+        assert hip.hipMemset(ptr, (0xA5, 0xFF, 0x01, 0x5A)[k % 4], chunk_bytes) == 0
+        held.append(ptr)
+    assert hip.hipDeviceSynchronize() == 0 and len(held) > 0
+    for ptr in held:
+        assert hip.hipFree(ptr) == 0

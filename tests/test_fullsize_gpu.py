@@ -80,7 +80,6 @@ def test_complete_network_equals_the_reference(tmp_path, n):
     """B1 through the C ABI: the whole CSR, written as the -j file by the host writer, has the md5 of
     the reference's -j file; then repeated builds (reused context, fresh contexts, one behind
     poisoned device memory) all give that same network."""
-    import torch
     from swarm_amd import Context, D1Clusters, HostDb
     hdb = HostDb(bench_fasta(n))
     ctx = Context(0)
@@ -102,10 +101,7 @@ def test_complete_network_equals_the_reference(tmp_path, n):
     for r in range(repeats):                                  # fresh contexts (fresh allocations)
         if r == repeats // 2:
             # poison: whatever the allocator hands out next has been 0xA5 / 0xFF, not zero
-            junk = [torch.full((1 << 28,), v, dtype=torch.uint8, device="cuda:0") for v in (0xA5, 0xFF, 0x01, 0x5A) * 8]
-            torch.cuda.synchronize()
-            del junk
-            torch.cuda.empty_cache()
+            S.poison_device_memory()
         c = Context(0)
         c.upload_hostdb(hdb)
         assert c.d1_index_build() is False
