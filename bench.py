@@ -22,6 +22,7 @@ At N = 1 the same run also measures, after the timed region (none of it enters `
   config.configs2      BASELINE configs[2]: 10 M x 150 with 30 % light amplicons, d=1 --fastidious: whole pipeline
                        + the fastidious kernels' own time and fraction of the HBM roofline
   config.configs3      BASELINE configs[3]: 1 M x 400, d=3: q-gram comparisons/s, aligned pairs/s, DP cells/s
+  config.skewed        the headline step on a set whose centroids all share their first / last 40 nt (conserved flanks)
   config.whole_run     FASTA -> -o through the drop-in command line, 1 M (md5 against the reference's -o) and 10 M
   config.host_seam_ms  swa_db_upload + swa_d1_index_build + swa_d1_network from / to host buffers (PCIe inclusive)
   roofline.traffic     HBM bytes per step from nested rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
@@ -71,7 +72,7 @@ def gen_tool() -> Path:
     return out
 
 
-def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0) -> Path:
+def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0, flank: int = 0) -> Path:
     """The synthetic amplicon set (SURVEY.md section 8d shapes; tools/gen_amplicons.c), cached in
     the temp dir.  Sets above 2 M are generated as independent blocks of <= 2 M amplicons by
     parallel processes (disjoint header numbers, seeds derived from `seed`) and concatenated.
@@ -84,14 +85,17 @@ def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0
             subprocess.run([str(gen_tool()), str(n), str(length), str(seed), str(edits), str(light), str(tmp)], check=True)
             os.replace(tmp, fasta)
         return fasta
-    fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{length}_s{seed}.fa"
+    # flank > 0: all centroids share their first and last `flank` nucleotides (GEN_FLANK of the generator): the skewed
+    # case for anchors at the ends of the sequences
+    fasta = Path(tempfile.gettempdir()) / (f"swa_bench_{n}x{length}_s{seed}.fa" if flank == 0 else f"swa_bench_{n}x{length}_s{seed}_f{flank}.fa")
     if fasta.exists():
         return fasta
+    genv = dict(os.environ, GEN_FLANK=str(flank)) if flank else None
     tool = str(gen_tool())
     tmp = fasta.with_suffix(f".tmp{os.getpid()}")
     block = 2_000_000
     if n <= block:
-        subprocess.run([tool, str(n), str(length), str(seed), "1", "0", str(tmp)], check=True)
+        subprocess.run([tool, str(n), str(length), str(seed), "1", "0", str(tmp)], check=True, env=genv)
     else:
         parts, procs, at, b = [], [], 0, 0
         limit = max(1, min(32, (os.cpu_count() or 2) // 2))
@@ -99,7 +103,7 @@ def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0
             size = min(block, n - at)
             part = fasta.with_suffix(f".part{b}.{os.getpid()}")
             parts.append(part)
-            procs.append(subprocess.Popen([tool, str(size), str(length), str(seed * 1000 + b + 1), "1", "0", str(part), str(at)]))
+            procs.append(subprocess.Popen([tool, str(size), str(length), str(seed * 1000 + b + 1), "1", "0", str(part), str(at)], env=genv))
             at += size
             b += 1
             while sum(p.poll() is None for p in procs) >= limit:
@@ -162,10 +166,10 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
                 "sample": f"oracle/ C restatement, index build + network only, {sample_n} x {length} bp, {dt:.2f} s"}
 
 
-def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int) -> dict:
+def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, flank: int = 0) -> dict:
     """The bench step (index build + network, db and CSR resident) on n x length amplicons."""
     from swarm_amd import Context, HostDb
-    hdb = HostDb(gen_fasta(n, args.length, args.seed))
+    hdb = HostDb(gen_fasta(n, args.length, args.seed, 1, 0.0, flank))
 
     def to_dev(a: np.ndarray, as_dtype):
         return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
@@ -191,8 +195,10 @@ def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int) -
     elapsed = time.perf_counter() - t0
     k = float(np.mean(k_ms))
     abytes = algorithmic_bytes(hdb.seqlen, total)
+    windows = ctx.d1_anchor_windows()
     ctx.close()
-    return {"workload": f"{hdb.n} synthetic amplicons x {args.length} bp, d=1", "value": hdb.n * steps / elapsed,
+    return {"workload": f"{hdb.n} synthetic amplicons x {args.length} bp, d=1" + (f", all centroids share their first / last {flank} nt" if flank else ""),
+            "anchor_windows_nt_from_the_ends": list(windows), "value": hdb.n * steps / elapsed,
             "unit": "amplicons/s", "steps": steps, "ms_per_step": 1000.0 * elapsed / steps, "network_kernels_ms": k,
             "neighbour_links": int(total), "roofline_frac": abytes / (k * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
@@ -604,7 +610,8 @@ def main() -> None:
                 # thread settings it is tried with inside the 10-30 s budget
                 out["cpu_baseline"] = cpu_baseline(gen_fasta(sample_n, args.length, args.seed), sample_n, args.length, args.seed)
                 ref_md5 = out["cpu_baseline"].pop("output_md5", None)
-            for name, fn in (("host_seam_ms", lambda: host_seam(args, n_total)),
+            for name, fn in (("skewed", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 40)),
+                             ("host_seam_ms", lambda: host_seam(args, n_total)),
                              ("whole_run", lambda: whole_run(args, n_total, ref_md5, sample_n)),
                              ("configs2", lambda: config2_fastidious(args, args.per_gpu)),
                              ("configs3", lambda: config3_dn(args, 1_000_000, 400, 3))):

@@ -107,6 +107,9 @@ int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates);
    [first, first + count) are checked for an identical twin (anywhere in the database).  A job
    that gives every rank its slice and ORs the flags detects every duplicate exactly once more
    cheaply than every rank checking everything.  Returns SWA_E_DUPLICATES like the above. */
+/* Where the last index build put the two anchor windows that group the amplicons: out2 = {nt from the start, nt from
+   the end}; (0, 0) = the first / last 32 nt, moved inwards when those are (nearly) the same for everybody. */
+int swa_d1_anchor_windows(const swa_ctx * ctx, uint32_t * out2);
 int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates);
 /* Multi-GPU by ownership (no reference counterpart: src/algod1.cc:641-669 splits the seeds over
    threads that share one table).  With world > 1 this context serves only its share of the

@@ -41,7 +41,7 @@ class DbView(C.Structure):
 
 
 EXPORTS = [
-    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup",
+    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_d1_anchor_windows",
     "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_resident",
     "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
@@ -379,6 +379,12 @@ class Context:
             if rc == SWA_OK:
                 return offsets, nb[:total.value]
             cap = int(total.value)
+
+    def d1_anchor_windows(self):
+        out = np.zeros(2, dtype=np.uint32)
+        self.lib.swa_d1_anchor_windows.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.lib.swa_d1_anchor_windows(self.h, _ptr(out)))
+        return int(out[0]), int(out[1])
 
     def d1_network_resident(self, no_cluster_breaking: bool = False) -> int:
         """The network of the whole database computed into the context's own HBM buffers and kept there."""

@@ -73,6 +73,10 @@ struct NetArgs {
   uint32_t * graft;
   unsigned long long * cand_counter;
   uint32_t fast_min_len;        // a (heavy, light) pair with both lengths >= this belongs to the pair route (d1_fast.inc)
+  // MODE 2 in window mode (anchor windows moved inwards): a fallback seed's share is defined by the window itself —
+  // range 1 = neighbours with the same prefix-side window (word win_word), range 2 = the others; all positions are
+  // enumerated and the hits filtered
+  uint32_t window_mode, win_word;
 };
 
 #define SWA_ANCHOR_TYPES_ONLY
@@ -293,7 +297,7 @@ template <bool SECOND>
 __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64_t * sw, uint32_t slen,
                                                  uint32_t snw, uint32_t seed, uint64_t seed_abundance,
                                                  uint64_t h, uint32_t code, uint32_t & out_amp,
-                                                 uint32_t & n_match, bool differ_prefix = false) {
+                                                 uint32_t & n_match, int window_filter = 0, uint32_t win_word = 0) {
   const uint32_t type = code & 3u;
   const uint32_t base = (code >> 2) & 3u;
   const uint32_t pos = code >> 4;
@@ -312,7 +316,8 @@ __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64
       else { allowed = amp != seed && (a.no_cluster_breaking != 0 || seed_abundance >= a.abundance[amp]); }
       if (allowed && alen == vlen) {
         const uint64_t * y = a.seqs + a.seq_off[amp];
-        bool same = !differ_prefix || y[0] != sw[0];             // (suffix-pass share of a seed: first 32 nt must differ)
+        // window_filter 1: only neighbours that share the seed's prefix-side window, 2: only those that do not
+        bool same = window_filter == 0 || (window_filter == 1 ? y[win_word] == sw[win_word] : y[win_word] != sw[win_word]);
         for (uint32_t w = 0; w < vnw; ++w) {
           same = same && (swa_variant_word(sw, snw, type, pos, base, w) == y[w]);
         }
@@ -400,7 +405,8 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
       uint32_t amp = 0;
       uint32_t nmatch = 0;
       if ((uint32_t)lane < cnt) {
-        hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch, MODE == 2 && range == 2u);
+        const int wf = MODE != 2 ? 0 : (a.window_mode != 0u ? (int)range : (range == 2u ? 2 : 0));
+        hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch, wf, a.win_word);
       }
       const uint64_t hm = __ballot(hit);
       if (STATS) {
@@ -462,10 +468,12 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
     };
     if (MODE == 2) {
       const swa_aux ax = a.aux[seed];
-      const uint32_t pb = range == 1u ? ax.pb : 0u;            // range 1 = what the prefix pass would have done (swa_aux::pb)
-      const uint32_t pe = range == 2u ? kAnchor : len + 1u;
-      enumerate_range(sw, len, zob, lane, pb, pe < len + 1u ? pe : len + 1u, ax.h, range == 1u ? ax.a32 : 0ull,
-                      range == 1u ? (ax.dall ^ ax.d32) : ax.dall, range == 1u ? (ax.iall ^ ax.i32) : ax.iall,
+      const bool by_position = a.window_mode == 0u;           // (window mode: every position, the hits are filtered)
+      const uint32_t pb = by_position && range == 1u ? ax.pb : 0u;   // range 1 = what the prefix pass would have done (swa_aux::pb)
+      const uint32_t pe = by_position && range == 2u ? kAnchor : len + 1u;
+      const uint32_t erange = by_position ? range : 0u;       // (`range` itself still selects the filter in drain())
+      enumerate_range(sw, len, zob, lane, pb, pe < len + 1u ? pe : len + 1u, ax.h, erange == 1u ? ax.a32 : 0ull,
+                      erange == 1u ? (ax.dall ^ ax.d32) : ax.dall, erange == 1u ? (ax.iall ^ ax.i32) : ax.iall,
                       probe_slots);
     } else {
       (void)enumerate_variants(sw, len, zob, lane, probe_slots);
@@ -896,6 +904,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     b.first = first; b.count = count;
     b.keys = keys; b.counts = counts; b.amask = asize - 1; b.slot_of = slot_of;
     b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.overflow = overflow;
+    b.win_a = ctx->anchor_a; b.win_b = ctx->anchor_b;
     hipLaunchKernelGGL(k_anchor_insert, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
     if (count < n) {
       hipLaunchKernelGGL(k_anchor_lookup, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
@@ -934,7 +943,10 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   // small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_pairs), else by
   // enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
   const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
-  const int pairs_width = (env_enum != nullptr && env_enum[0] == '1') ? 0 : (ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0));
+  const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;       // (only chosen when the pair kernels apply)
+  const int pairs_width = (env_enum != nullptr && env_enum[0] == '1' && !window_mode) ? 0 : (ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0));
+  const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");                    // test switch: tiled pair kernel for the big groups in any mode
+  const bool tiled_big = pairs_width != 0 && (window_mode || (env_tiled != nullptr && env_tiled[0] == '1'));
   for (int which = 0; which < 2; ++which) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                        static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
@@ -961,6 +973,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.seg_cap = ctx->seg_cap;
     a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
     a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
+    a.minlen = ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen;
+    a.win_word = ctx->anchor_a / 32u;
+    a.window_mode = window_mode ? 1u : 0u;
     const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + 2 * kPend);   // in u64 units
     const int grid = ctx->num_cus * 8;
     // small groups: one wave per group
@@ -985,7 +1000,13 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.item_count = acounters + pass;
     a.table_slots = 2 * kGroupCap;
     const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 2 + a.table_slots / 4);
-    if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    if (tiled_big && pairs_width == 5) {
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+    } else if (tiled_big) {
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+    } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<false, 1>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     SWA_HIP(ctx, hipGetLastError());
   }
@@ -994,7 +1015,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
                      count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
                      static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
                      static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world,
-                     ctx->db.seqs, ctx->db.seq_off);
+                     ctx->db.seqs, ctx->db.seq_off, ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen, window_mode ? 1u : 0u);
   NetArgs f{};
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
   f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
@@ -1015,6 +1036,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   f.fallback_count = acounters + 2;
   f.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
   f.owner_rank = 0; f.owner_world = 1;                       // the list already is this rank's share
+  f.window_mode = window_mode ? 1u : 0u; f.win_word = ctx->anchor_a / 32u;
   const size_t flds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull +
                                           kWaves * ((size_t)(maxwords + 2u) + kQueueCap + kQueueCap / 2));
   const int fgrid = grid_for(ctx, count, kWaves, 8);
@@ -1110,7 +1132,8 @@ static int ensure_full_index(swa_ctx * ctx) {
 // those members only, duplicates inside the owned prefix groups.  *needs_table is set when some
 // seed can only be served by the plain kernel (a sequence shorter than 65 nt anywhere, a group
 // too large for LDS) or the db order does not hold: the caller then builds the full index.
-static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool * needs_table) {
+static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool * needs_table, uint32_t * oversized_mass = nullptr,
+                             uint32_t * shortest = nullptr) {
   const uint32_t n = ctx->db.n;
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
   SWA_TRY(prepare_hashing(ctx));
@@ -1124,7 +1147,8 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, std::max<uint64_t>(n, asize), 256, 8)), dim3(256), 0, ctx->stream,
                      ctx->db.seqlen, n, static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
-                     static_cast<const uint32_t *>(ctx->d_acounts[1].ptr), asize, dflags, ctx->db.seqs, ctx->db.seq_off);
+                     static_cast<const uint32_t *>(ctx->d_acounts[1].ptr), asize, dflags, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen, (ctx->anchor_a != 0 || ctx->anchor_b != 0) ? 1u : 0u);
   SWA_TRY(launch_seqhash(ctx, true));
   // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
   swa_t0(ctx, 2);
@@ -1149,9 +1173,13 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 2);
-  uint32_t flags[5] = {};     // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence [4] oversized group
+  // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence / pb = 0 [4] oversized group
+  // [5] members of oversized groups [6] 0xFFFFFFFF - shortest sequence
+  uint32_t flags[7] = {};
   SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
+  if (shortest != nullptr) { *shortest = 0xFFFFFFFFu - flags[6]; }
   if (flags[2] != 0) {                                      // skewed ownership: share-sized key tables too small
     ctx->anchor_slack = 1;
     ctx->anchor_ready = false;
@@ -1196,7 +1224,30 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   // as a rank of a multi-GPU job: with world = 1 this GPU owns every anchor group.
   if (ctx->anchor_usable && owned_index_enabled()) {
     bool needs_table = false;
-    SWA_TRY(build_owned_index(ctx, first, count, &needs_table));
+    uint32_t mass = 0, shortest = 0;
+    ctx->anchor_a = ctx->anchor_b = 0;
+    SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &mass, &shortest));
+    // Conserved flanks: when a noticeable part of the database sits in groups too large for LDS (everybody shares
+    // the first or last 32 nt), the anchor windows move inwards, 32 nt at a time, as far as the shortest sequence
+    // allows (every seed needs win_a + win_b + 65 nt), and the setting with the fewest stranded members wins.  Window
+    // mode needs the pair kernels (sequences up to 256 nt); SWA_D1_WINDOWS=0 switches the search off.
+    const char * env_win = getenv("SWA_D1_WINDOWS");
+    if (needs_table && mass > n / 64u && ctx->db.longest <= 256u && !(env_win != nullptr && env_win[0] == '0')) {
+      uint32_t best = 0, best_mass = mass;
+      for (uint32_t w = 32; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
+        ctx->anchor_a = ctx->anchor_b = w;
+        SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
+        uint32_t m = 0;
+        SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &m));
+        if (m < best_mass) { best_mass = m; best = w; }
+        if (m <= n / 64u) { break; }
+      }
+      if (ctx->anchor_a != best) {                            // (the last one tried was not the best: build that one again)
+        ctx->anchor_a = ctx->anchor_b = best;
+        SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
+        SWA_TRY(build_owned_index(ctx, first, count, &needs_table));
+      }
+    }
     owned_ok = !needs_table;
     ctx->aux_complete = owned_ok && ctx->owner_world == 1;
     SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1238,6 +1289,13 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
 }
 
 extern "C" uint64_t swa_d1_table_size(const swa_ctx * ctx) { return ctx != nullptr ? ctx->table_size : 0; }
+
+// the anchor windows the last index build chose: out2 = {nt from the start, nt from the end} (0, 0 = the first / last 32 nt)
+extern "C" int swa_d1_anchor_windows(const swa_ctx * ctx, uint32_t * out2) {
+  if (ctx == nullptr || out2 == nullptr) { return SWA_E_ARG; }
+  out2[0] = ctx->anchor_a; out2[1] = ctx->anchor_b;
+  return SWA_OK;
+}
 
 static size_t network_lds_bytes(const swa_ctx * ctx, bool zlds) {
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;

@@ -446,3 +446,65 @@ def test_runs_across_the_anchor_boundary(gpu_ctx, tmp_path):
     off, nb = _check_vs_oracle(gpu_ctx, db)
     assert len(nb) > 3000
     _check_vs_oracle(gpu_ctx, db, ncb=True)
+
+
+def _conserved_flank_set(path, n, seed, flank=40):
+    """Every amplicon starts and ends with the same `flank` nucleotides (primers / conserved regions left on): with the
+    default anchors (first / last 32 nt) everybody lands in one prefix and one suffix group."""
+    src = path.with_suffix(".src.fa")
+    S.gen_fasta(src, n, 150, seed)
+    rng = np.random.default_rng(seed)
+    head = "".join(rng.choice(list("ACGT"), flank))
+    tail = "".join(rng.choice(list("ACGT"), flank))
+    seen, out = set(), []
+    for h, s in S.read_fasta(src):
+        s = s.decode().upper()
+        t = head + s[flank:len(s) - flank] + tail
+        if t not in seen:
+            seen.add(t)
+            out.append(b">" + h + b"\n" + t.encode() + b"\n")
+    path.write_bytes(b"".join(out))
+
+
+@pytest.mark.parametrize("n,seed", [(30000, 71), (150000, 72)])
+def test_conserved_flanks_move_the_anchor_windows(tmp_path, n, seed):
+    """Groups far beyond the LDS limit under the default anchors: the index build moves the windows inwards (window
+    mode: pair kernels, tiled for groups of 65..2048, filtered plain kernel beyond) — same network as the oracle's."""
+    from swarm_amd import Context
+    fa = tmp_path / "flanks.fa"
+    _conserved_flank_set(fa, n, seed)
+    db = S.db_from_fasta(fa)
+    ctx = Context(0)
+    try:
+        off, nb = _check_vs_oracle(ctx, db)
+        assert len(nb) > n // 2
+        assert ctx.d1_anchor_windows()[0] >= 32                # the windows did move
+        _check_vs_oracle(ctx, db, ncb=True)
+    finally:
+        ctx.close()
+
+
+def test_tiled_pair_kernel_on_big_groups(tmp_path, monkeypatch):
+    """k_d1_pairs_tiled (64 x 64 tiles) in place of the enumerating kernel for groups of 65..2048, default anchors."""
+    from swarm_amd import Context
+    monkeypatch.setenv("SWA_D1_PAIRS_TILED", "1")
+    rng = np.random.default_rng(5)
+    cent = "".join(rng.choice(list("ACGT"), 150))
+    seqs = {cent}
+    while len(seqs) < 1500:                                   # one family of 1500: one prefix and one suffix group of ~1200
+        s = cent
+        for _ in range(int(rng.integers(1, 3))):
+            p = int(rng.integers(0, len(s)))
+            k = int(rng.integers(0, 3))
+            b = str(rng.choice(list("ACGT")))
+            s = s[:p] + b + s[p + 1:] if k == 0 else (s[:p] + s[p + 1:] if k == 1 else s[:p] + b + s[p:])
+        seqs.add(s)
+    fa = tmp_path / "family.fa"
+    fa.write_text("".join(f">m{i}_{int(rng.integers(1, 50))}\n{s}\n" for i, s in enumerate(sorted(seqs))))
+    db = S.db_from_fasta(fa)
+    ctx = Context(0)
+    try:
+        off, nb = _check_vs_oracle(ctx, db)
+        assert len(nb) > 2000
+    finally:
+        ctx.close()

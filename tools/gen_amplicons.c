@@ -16,6 +16,7 @@
  * Build:  gcc -O2 -o gen_amplicons tools/gen_amplicons.c          (CLI)
  *         gcc -O2 -shared -fPIC -DGEN_NO_MAIN ...                   (library)
  * CLI:    gen_amplicons <n> <L> <seed> <max_edits> <light_frac> <out.fasta>
+ *         GEN_FLANK=<k> in the environment: all centroids share their first and last k nucleotides
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -24,6 +25,7 @@
 #include <math.h>
 
 typedef struct { uint64_t s; } rng_t;
+static uint32_t g_flank = 0;        /* GEN_FLANK environment variable (see below) */
 
 static uint64_t rng_next(rng_t * r) {            /* splitmix64 */
   uint64_t z = (r->s += 0x9E3779B97F4A7C15ULL);
@@ -117,6 +119,14 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
     if (count < centroids) {
       len = L;
       for (uint32_t i = 0; i < len; ++i) tmp[i] = (uint8_t)(rng_next(&rng) >> 62);
+      /* GEN_FLANK=<k>: every centroid starts and ends with the same k nucleotides (conserved flanks / primers left
+         on: the skewed case for anything that groups sequences by their ends); drawn from a generator of their own,
+         so the rest of the set does not depend on the option */
+      if (g_flank > 0 && 2u * g_flank < len) {
+        rng_t fr; fr.s = 0x5EEDF1A2ULL;
+        for (uint32_t i = 0; i < g_flank; ++i) tmp[i] = (uint8_t)(rng_next(&fr) >> 62);
+        for (uint32_t i = 0; i < g_flank; ++i) tmp[len - g_flank + i] = (uint8_t)(rng_next(&fr) >> 62);
+      }
       double u = rng_unit(&rng); if (u < 1e-12) u = 1e-12;
       double a = 20.0 * pow(u, -1.0 / 0.8) + 2.0;
       if (a > 1e12) a = 1e12;
@@ -179,6 +189,7 @@ int main(int argc, char ** argv) {
     return 2;
   }
   if (argc == 8) g_id_offset = strtoull(argv[7], NULL, 10);
+  if (getenv("GEN_FLANK") != NULL) g_flank = (uint32_t)atoi(getenv("GEN_FLANK"));
   const int rc = gen_amplicons_fasta(strtoull(argv[1], NULL, 10), (uint32_t)atoi(argv[2]),
                                      strtoull(argv[3], NULL, 10), (uint32_t)atoi(argv[4]),
                                      atof(argv[5]), argv[6]);
