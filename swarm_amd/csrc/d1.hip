@@ -1126,6 +1126,38 @@ static int ensure_full_index(swa_ctx * ctx) {
   return SWA_OK;
 }
 
+// Anchor windows for this database, from a sample (k_anchor_sample): the smallest offset whose estimated share of
+// amplicons in oversized groups and of too-short seeds is below 1 / 64 each; (0, 0) when nothing is skewed, which is
+// the normal case.  Window mode needs the pair kernels (sequences up to 256 nt); SWA_D1_WINDOWS=0 switches it off.
+static int choose_anchor_windows(swa_ctx * ctx) {
+  ctx->anchor_a = ctx->anchor_b = 0;
+  const char * env_win = getenv("SWA_D1_WINDOWS");
+  if (ctx->db.longest > 256u || (env_win != nullptr && env_win[0] == '0')) { return SWA_OK; }
+  const uint32_t n = ctx->db.n;
+  const uint32_t stride = std::max<uint32_t>(1u, n / 65536u);
+  const uint32_t samples = (n + stride - 1) / stride;
+  const size_t slots = (size_t)2 * kSampleCandidates * kSampleSlots;
+  SWA_TRY(swa_reserve(ctx, ctx->d_akeys[0], std::max<size_t>(ctx->d_akeys[0].bytes, slots * sizeof(uint64_t))));
+  SWA_TRY(swa_reserve(ctx, ctx->d_acounts[0], std::max<size_t>(ctx->d_acounts[0].bytes, (slots + 16) * sizeof(uint32_t))));
+  auto * keys = static_cast<unsigned long long *>(ctx->d_akeys[0].ptr);
+  auto * counts = static_cast<uint32_t *>(ctx->d_acounts[0].ptr);
+  uint32_t * stats = counts + slots;                         // [0..4) too short, [4..8) mass
+  SWA_HIP(ctx, hipMemsetAsync(keys, 0xFF, slots * sizeof(uint64_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(counts, 0, (slots + 16) * sizeof(uint32_t), ctx->stream));
+  hipLaunchKernelGGL(k_anchor_sample, dim3(grid_for(ctx, samples, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->db.seqlen, n, stride, keys, counts, stats);
+  hipLaunchKernelGGL(k_sample_mass, dim3(grid_for(ctx, slots, 256, 8)), dim3(256), 0, ctx->stream, counts, stride, stats + 4);
+  uint32_t host[8] = {};
+  SWA_HIP(ctx, hipMemcpyAsync(host, stats, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t c = 0; c < kSampleCandidates; ++c) {
+    const bool few_short = host[c] <= samples / 64u || c == 0;
+    if (host[4 + c] <= samples / 64u && few_short) { ctx->anchor_a = ctx->anchor_b = 32u * c; return SWA_OK; }
+    if (!few_short) { break; }                               // (larger offsets only strand more seeds)
+  }
+  return SWA_OK;                                             // nothing qualifies: the ends it is (and the plain kernel for the giants)
+}
+
 // Index build of a rank that serves only the anchor groups it owns (swa_d1_set_ownership,
 // world > 1), without anything proportional to the database except streaming passes: abundance
 // ranks, the anchor indexes of the owned groups (all their members), hashes and XOR streams of
@@ -1200,6 +1232,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   ctx->anchor_ready = false;
   ctx->full_index = false;
   ctx->aux_complete = false;
+  ctx->anchor_a = ctx->anchor_b = 0;
   for (int slot : {0, 1, 2, 7}) { ctx->ev_used[slot] = false; }   // phases this build does not run report 0
   ctx->table_size = swa_hashtable_size(n);
   const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
@@ -1225,16 +1258,18 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   if (ctx->anchor_usable && owned_index_enabled()) {
     bool needs_table = false;
     uint32_t mass = 0, shortest = 0;
-    ctx->anchor_a = ctx->anchor_b = 0;
+    SWA_TRY(choose_anchor_windows(ctx));
+    const uint32_t sampled = ctx->anchor_a;
     SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &mass, &shortest));
     // Conserved flanks: when a noticeable part of the database sits in groups too large for LDS (everybody shares
     // the first or last 32 nt), the anchor windows move inwards, 32 nt at a time, as far as the shortest sequence
     // allows (every seed needs win_a + win_b + 65 nt), and the setting with the fewest stranded members wins.  Window
     // mode needs the pair kernels (sequences up to 256 nt); SWA_D1_WINDOWS=0 switches the search off.
     const char * env_win = getenv("SWA_D1_WINDOWS");
+    // (safety net behind the sample: the real build still found too many stranded members — try the next offsets)
     if (needs_table && mass > n / 64u && ctx->db.longest <= 256u && !(env_win != nullptr && env_win[0] == '0')) {
-      uint32_t best = 0, best_mass = mass;
-      for (uint32_t w = 32; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
+      uint32_t best = sampled, best_mass = mass;
+      for (uint32_t w = sampled + 32u; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
         ctx->anchor_a = ctx->anchor_b = w;
         SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
         uint32_t m = 0;
