@@ -130,3 +130,24 @@ def test_regrown_link_segments_give_the_same_network(tmp_path, monkeypatch):
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     woff, wnb, _ = S.oracle_d1_network(db)
     assert np.array_equal(got[0], woff)
+
+
+def test_cli_d3_one_million_equals_the_reference(tmp_path):
+    """BASELINE configs[3] at full size: 1 M x 400 bp, d = 3 (the reference needs ~18 minutes on 8 threads for this
+    run; its -o / -s / -i md5s are in fullsize.json).  Takes the bulk graph route (dn_graph.hip)."""
+    import bench
+    gold = GOLD["1000000"]["runs"]["d3"]
+    fasta = bench.gen_fasta(1_000_000, 400, 1, 3, 0.0)
+    assert md5_of(fasta) == gold["fasta"]["md5"], "the generator produced a different set on this box"
+    cmd = [str(BIN)] + gold["args"]
+    for k in gold["files"]:
+        cmd += [FLAG[k], str(tmp_path / k)]
+    cmd += ["-l", str(tmp_path / "log"), str(fasta)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for k, want in gold["files"].items():
+        assert (tmp_path / k).stat().st_size == want["bytes"], k
+        assert md5_of(tmp_path / k) == want["md5"], k
+    log = (tmp_path / "log").read_text()
+    for line in gold["log"]:
+        assert line in log, line
