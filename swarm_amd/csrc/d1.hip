@@ -1780,11 +1780,21 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
     c.zlen = ctx->zobrist_len; c.maxwords = (ctx->db.longest + 31u) >> 5; c.slots = slots;
     c.pairs = static_cast<const unsigned long long *>(ctx->d_fpairs.ptr); c.npairs = npairs;
     c.graft = static_cast<uint32_t *>(ctx->d_graft.ptr); c.cand_counter = fc + 2;
+    const char * env_sets = getenv("SWA_FAST_COUNT_SETS");     // test switch: the LDS-set kernel whatever the length
+    const bool by_sites = ctx->db.longest <= 255u && !(env_sets != nullptr && env_sets[0] == '1');
+    if (by_sites) {
+      uint64_t blocks = (npairs + kWaves - 1) / kWaves;
+      const uint64_t max_blocks = (uint64_t)ctx->num_cus * 8;
+      if (blocks > max_blocks) { blocks = max_blocks; }
+      if (ctx->db.longest <= 159u) { hipLaunchKernelGGL(k_fast_count_sites<5>, dim3((uint32_t)blocks), dim3(kThreads), 0, ctx->stream, c); }
+      else { hipLaunchKernelGGL(k_fast_count_sites<8>, dim3((uint32_t)blocks), dim3(kThreads), 0, ctx->stream, c); }
+    } else {
     const size_t lds = fast_count_lds(ctx, slots, count_waves);
     uint64_t blocks = (npairs + count_waves - 1) / count_waves;
     const uint64_t max_blocks = (uint64_t)ctx->num_cus * 8;
     if (blocks > max_blocks) { blocks = max_blocks; }
     hipLaunchKernelGGL(k_fast_count, dim3((uint32_t)blocks), dim3(64 * count_waves), lds, ctx->stream, c);
+    }
     SWA_HIP(ctx, hipGetLastError());
   }
   swa_t1(ctx, 6);

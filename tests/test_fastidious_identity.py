@@ -100,3 +100,68 @@ def test_two_edits_leave_a_shared_window():
             seen_classes.add("M")
             assert h[40:72] in (x[39:71], x[40:72], x[41:73]), (h, x)
     assert seen_classes == {"P", "S", "M"}
+
+
+def _canonical_slots(s: str):
+    """(position, microvariant) for every slot of generate_variants (src/variants.cc:184-249): substitutions at p,
+    the deletion of a run filed under the run's first position, insertions of bases that differ from the left neighbour."""
+    out = []
+    for p in range(len(s)):
+        for b in "ACGT":
+            if b != s[p]:
+                out.append((p, s[:p] + b + s[p + 1:]))
+        if p == 0 or s[p] != s[p - 1]:
+            out.append((p, s[:p] + s[p + 1:]))
+    for p in range(len(s) + 1):
+        for b in "ACGT":
+            if p == 0 or b != s[p - 1]:
+                out.append((p, s[:p] + b + s[p:]))
+    return out
+
+
+def test_common_microvariants_come_from_the_difference_interval():
+    """k_fast_count_sites only expands the canonical positions [runstart(h, min(P, E) - 1) - 1, max(P, E) + 1] of h,
+    P = first mismatch of h and x, E = last mismatch of the end-aligned comparison: that must find every common
+    microvariant — also in periodic sequences, where the two edits can sit anywhere inside a repeat."""
+    rng = np.random.default_rng(3)
+
+    def edit(s, alpha):
+        p = int(rng.integers(0, len(s) + 1))
+        k = int(rng.integers(0, 3))
+        b = str(rng.choice(list(alpha)))
+        if k == 0 and p < len(s):
+            return s[:p] + b + s[p + 1:]
+        if k == 1 and p < len(s):
+            return s[:p] + s[p + 1:]
+        return s[:p] + b + s[p:]
+
+    checked = 0
+    for t in range(12000):
+        alpha = "ACGT" if t % 3 == 0 else ("AC" if t % 3 == 1 else "AAAAAAC")
+        h = "".join(rng.choice(list(alpha), int(rng.integers(3, 40))))
+        x = h
+        for _ in range(int(rng.integers(1, 3))):
+            x = edit(x, alpha)
+        if x == h:
+            continue
+        lh, lx = len(h), len(x)
+        dl = lx - lh
+        P = 0
+        while P < min(lh, lx) and h[P] == x[P]:
+            P += 1
+        E = -1
+        for i in range(lh - 1, -1, -1):
+            if i + dl < 0 or h[i] != x[i + dl]:
+                E = i
+                break
+        P, E = min(P, lh - 1), min(max(E, 0), lh - 1)
+        q = max(min(P, E) - 1, 0)
+        while q > 0 and h[q - 1] == h[q]:
+            q -= 1
+        lo, hi = max(q - 1, 0), min(max(P, E) + 1, lh)
+        vx = v1(x)
+        want = len(v1(h) & vx)
+        got = sum(1 for p, v in _canonical_slots(h) if lo <= p <= hi and v in vx)
+        assert got == want, (h, x, want, got, lo, hi)
+        checked += 1
+    assert checked > 10000
