@@ -1701,23 +1701,24 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
   const uint32_t n = ctx->db.n;
   auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);
   if (n_light == 0 || n_heavy == 0) { return SWA_OK; }
-  uint64_t asize = 64;
-  while (asize < 6ull * n_light) { asize <<= 1; }            // load <= 0.5 with three memberships per light amplicon
+  uint64_t asize_max = 64, asize_ends = 64;
+  while (asize_max < 6ull * n_light) { asize_max <<= 1; }    // load <= 0.5 with three memberships per light amplicon (middle windows)
+  while (asize_ends < 2ull * n_light) { asize_ends <<= 1; }  // one membership (prefix / suffix groups): a smaller table to clear and scan
+  uint64_t asize = asize_max;
   const uint64_t member_cap = 3ull * n_light + n_heavy;
   const uint64_t item_cap64 = 3ull * n_light + (3ull * n_light + n_heavy) / 2 + 64;
   const uint32_t item_cap = item_cap64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)item_cap64;
-  const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
   SWA_TRY(swa_reserve(ctx, ctx->d_fkeys, asize * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_fcnt, asize * 5 * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_foff, (asize + 1) * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_fslot, uint64_t(n) * 4 * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_fmembers, member_cap * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_fitems, uint64_t(item_cap) * sizeof(swa_fitem)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, ((asize_max + kScanTile - 1) / kScanTile) * sizeof(uint64_t)));
   if (ctx->fast_pair_cap == 0) { ctx->fast_pair_cap = 4ull * n_light + (1ull << 20); }
   auto * keys = static_cast<unsigned long long *>(ctx->d_fkeys.ptr);
   auto * cnt_l = static_cast<uint32_t *>(ctx->d_fcnt.ptr);
-  auto * cnt_h = cnt_l + asize, * cur_l = cnt_h + asize, * cur_h = cur_l + asize, * tot = cur_h + asize;
+  uint32_t * cnt_h = cnt_l + asize, * cur_l = cnt_h + asize, * cur_h = cur_l + asize, * tot = cur_h + asize;
   auto * offsets = static_cast<uint64_t *>(ctx->d_foff.ptr);
   auto * lslot = static_cast<uint32_t *>(ctx->d_fslot.ptr);
   auto * hslot = lslot + 3ull * n;
@@ -1732,6 +1733,9 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
     SWA_HIP(ctx, hipMemsetAsync(fc + 5, 0, sizeof(uint64_t), ctx->stream));
     SWA_HIP(ctx, hipMemsetAsync(dflags + 9, 0, sizeof(uint32_t), ctx->stream));
     for (int type = 0; type < 3; ++type) {
+      asize = type == 2 ? asize_max : asize_ends;
+      cnt_h = cnt_l + asize; cur_l = cnt_h + asize; cur_h = cur_l + asize; tot = cur_h + asize;
+      const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
       FastGroupArgs g{};
       g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
       g.role = static_cast<const uint8_t *>(ctx->d_frole.ptr); g.n = n;
