@@ -389,7 +389,7 @@ def measured_traffic(args) -> dict | None:
             for f in glob.glob(f"{tmp}/{counter}/**/*counter_collection.csv", recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == counter and ("k_d1_anchor" in row["Kernel_Name"] or "k_d1_probe" in row["Kernel_Name"]):
+                        if row["Counter_Name"] == counter and "k_d1_" in row["Kernel_Name"]:
                             total += float(row["Counter_Value"])
                             rows += 1
             if rows == 0:
@@ -585,7 +585,7 @@ def main() -> None:
                 "phase_ms": {"seqhash": timings[0], "table_bloom_build": timings[1], "dup_check": timings[2],
                              "anchor_index_build": timings[7], "network_kernels": k_ms, "csr": timings[4]},
             },
-            "roofline": {"bound": "hbm", "kernel": "d=1 network = k_d1_anchor<small|big> x (prefix, suffix pass) + k_d1_probe<MODE 2> "
+            "roofline": {"bound": "hbm", "kernel": "d=1 network = k_d1_pairs (groups of 2..64) + k_d1_anchor<big> x (prefix, suffix pass) + k_d1_probe<MODE 2> "
                                    "fallback: together one probe per microvariant; duration = their sum per step", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_kernel_ms": k_ms},

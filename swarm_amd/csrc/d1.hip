@@ -860,9 +860,18 @@ static bool anchor_applicable(const swa_ctx * ctx) {
   return anchored_enabled() && ctx->db.longest >= kMinAnchoredLen && ctx->db.longest <= 64u * kPrefetchWords * 32u - 64u;
 }
 
-// work items of an index: big ones (64-seed chunks of groups of 65..2048: fewer than n / 32) at the start of
-// d_aitems, small ones (chunks of groups of 2..64: at most n / 2 + n / kSmallChunkPrefix) from here on
+// work items of an index.  d_aitems: 64-seed chunks of the groups served by the enumerating / tiled kernels (fewer
+// than n / 32) at the start, from small_items_at on EITHER the small-group items of k_anchor_items (at most n / 2 +
+// n / kSmallChunkPrefix) OR the lists of k_anchor_items_classes (pair_region: groups of a class have at least
+// 2, 5, 9, 17, 33 and 65 members, which bounds each list); sized for both
 static uint64_t small_items_at(uint32_t n) { return uint64_t(n) / 8 + 32; }
+static uint64_t pair_region(uint32_t c, uint32_t n) {
+  static const uint32_t least[kPairClasses + 2] = {2, 5, 9, 17, 33, 65, 0};
+  uint64_t at = small_items_at(n);
+  for (uint32_t k = 0; k < c; ++k) { at += uint64_t(n) / least[k] + 64; }
+  return at;
+}
+static uint64_t items_capacity(uint32_t n) { return std::max<uint64_t>(uint64_t(n) + 128, pair_region(kPairClasses + 1, n)); }
 constexpr uint32_t kSmallChunkPrefix = 16;  // prefix pass: seeds per small item (a seed walks its whole sequence)
 constexpr uint32_t kSmallChunkSuffix = 64;  // suffix pass: 32 positions per seed, the table build dominates: no split
 
@@ -884,7 +893,8 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     SWA_TRY(swa_reserve(ctx, ctx->d_aoffsets[which], (asize + 1) * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aslot[which], uint64_t(n) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_amembers[which], uint64_t(n) * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], (uint64_t(n) + 128) * sizeof(swa_item)));   // big (n/8 + 32) | small
+    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], items_capacity(n) * sizeof(swa_item)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_ainfo[which], uint64_t(n) * sizeof(uint4)));
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
   const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
@@ -915,7 +925,8 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, counts, (uint32_t)asize,
                        static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), offsets);
     hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, slot_of, n, offsets, cursor,
-                       static_cast<uint32_t *>(ctx->d_amembers[which].ptr));
+                       static_cast<uint32_t *>(ctx->d_amembers[which].ptr), ctx->db.seqlen,
+                       static_cast<const uint32_t *>(ctx->d_arank.ptr), ctx->db.seq_off, static_cast<uint4 *>(ctx->d_ainfo[which].ptr));
     SWA_HIP(ctx, hipGetLastError());
   }
   ctx->anchor_first = first;
@@ -927,13 +938,14 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 // anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
 // the plain kernel; edges / counts / edge counter as launch_network leaves them
 static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count) {
-  // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items
+  // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items [16..32) work counters
+  // [32 + 8 pass + c] lists of k_anchor_items_classes
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
   // item counts [0,1] big / [3,4] small, fallback count [2], work counters of both passes [16..32)
-  SWA_HIP(ctx, hipMemsetAsync(acounters, 0, 32 * sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(acounters, 0, 64 * sizeof(uint32_t), ctx->stream));
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
   auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
@@ -947,13 +959,30 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   const int pairs_width = (env_enum != nullptr && env_enum[0] == '1' && !window_mode) ? 0 : (ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0));
   const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");                    // test switch: tiled pair kernel for the big groups in any mode
   const bool tiled_big = pairs_width != 0 && (window_mode || (env_tiled != nullptr && env_tiled[0] == '1'));
+  // groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
+  // them to the enumerating / tiled kernel (test switch)
+  const char * env_pair_big = getenv("SWA_D1_PAIR_BIG");
+  const uint32_t pair_big = env_pair_big != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env_pair_big))) : kPairBigCap;
   for (int which = 0; which < 2; ++which) {
+    if (pairs_width != 0) {
+      PairLists l{};
+      l.items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
+      for (uint32_t c = 0; c <= kPairClasses; ++c) { l.region[c] = pair_region(c, ctx->db.n); }
+      l.counters = acounters + 32 + 8 * which;
+      l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
+      l.chunk_counter = acounters + which;
+      l.pair_big = pair_big;
+      hipLaunchKernelGGL(k_anchor_items_classes, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                         static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
+                         static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize, l);
+      continue;
+    }
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                        static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
                        static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr), acounters + which,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr) + small_items_at(ctx->db.n), acounters + 3 + which,
-                       pairs_width != 0 ? kSmallGroup : (which == 0 ? kSmallChunkPrefix : kSmallChunkSuffix));
+                       which == 0 ? kSmallChunkPrefix : kSmallChunkSuffix);
   }
   SWA_HIP(ctx, hipGetLastError());
   for (int pass = 0; pass < 2; ++pass) {
@@ -985,14 +1014,16 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.small_chunk = pass == 0 ? kSmallChunkPrefix : kSmallChunkSuffix;
     a.table_slots = 2 * kSmallGroup;
     const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom
+    a.minfo = static_cast<const uint4 *>(ctx->d_ainfo[pass].ptr);
+    a.pair_items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
+    for (uint32_t c = 0; c <= kPairClasses; ++c) { a.pair_region[c] = pair_region(c, ctx->db.n); }
+    a.pair_counters = acounters + 32 + 8 * pass;
     if (pairs_width == 5) {
-      a.small_chunk = kSmallGroup;
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs<0, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_pairs<1, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
     } else if (pairs_width == 8) {
-      a.small_chunk = kSmallGroup;
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs<0, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_pairs<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
     } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk

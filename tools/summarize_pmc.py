@@ -24,7 +24,7 @@ def main() -> None:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
-                if "k_d1_anchor" in name or "k_d1_probe" in name:
+                if "k_d1_" in name:
                     m = re.search(r"(k_d1_\w+<[^>]*>)", name)
                     short = m.group(1) if m else name
                     per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -38,7 +38,7 @@ def main() -> None:
     corrected = (2.0 * fetch_kib + write_kib) * 1024.0 / steps
     rec = {"workload": tag, "bench_steps_profiled": steps,
            "hbm_bytes_per_launch": corrected, "hbm_bytes_per_launch_uncorrected": raw,
-           "note": "launch = one bench step = all k_d1_anchor<small|big, pass> + k_d1_probe<..,2> dispatches of the step; "
+           "note": "launch = one bench step = all k_d1_pairs / k_d1_anchor / k_d1_probe dispatches of the step; "
                    "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported",
            "kernels": kernels}
     with open(out, "w") as fh:
