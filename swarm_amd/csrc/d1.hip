@@ -889,50 +889,76 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   for (int which = 0; which < 2; ++which) {
     SWA_TRY(swa_reserve(ctx, ctx->d_akeys[which], asize * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_acounts[which], asize * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_acursor[which], asize * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aoffsets[which], (asize + 1) * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aslot[which], uint64_t(n) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_apos[which], uint64_t(n) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_amembers[which], uint64_t(n) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], items_capacity(n) * sizeof(swa_item)));
     SWA_TRY(swa_reserve(ctx, ctx->d_ainfo[which], uint64_t(n) * sizeof(uint4)));
   }
+  SWA_TRY(swa_reserve(ctx, ctx->d_afp[0], uint64_t(n) * sizeof(uint64_t)));      // per amplicon
+  SWA_TRY(swa_reserve(ctx, ctx->d_afp[1], uint64_t(n) * sizeof(uint64_t)));      // prefix index, group order
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
   const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
-  auto * overflow = static_cast<uint32_t *>(ctx->d_flags.ptr) + 2;
-  SWA_HIP(ctx, hipMemsetAsync(overflow, 0, sizeof(uint32_t), ctx->stream));
+  auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
+  SWA_HIP(ctx, hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), ctx->stream));
+  AnchorBuildArgs b{};
+  AnchorScatterArgs sc{};
+  b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n;
+  b.first = first; b.count = count; b.amask = asize - 1;
+  b.fingerprint = static_cast<uint64_t *>(ctx->d_afp[0].ptr);
+  b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.flags = dflags;
+  b.win_a = ctx->anchor_a; b.win_b = ctx->anchor_b;
+  b.minlen = ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen;
+  b.window_mode = (ctx->anchor_a != 0 || ctx->anchor_b != 0) ? 1u : 0u;
   for (int which = 0; which < 2; ++which) {
-    auto * keys = static_cast<unsigned long long *>(ctx->d_akeys[which].ptr);
-    auto * counts = static_cast<uint32_t *>(ctx->d_acounts[which].ptr);
-    auto * cursor = static_cast<uint32_t *>(ctx->d_acursor[which].ptr);
-    auto * offsets = static_cast<uint64_t *>(ctx->d_aoffsets[which].ptr);
-    auto * slot_of = static_cast<uint32_t *>(ctx->d_aslot[which].ptr);
-    hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, keys, counts, cursor, asize);
-    AnchorBuildArgs b{};
-    b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n; b.which = which;
-    b.first = first; b.count = count;
-    b.keys = keys; b.counts = counts; b.amask = asize - 1; b.slot_of = slot_of;
-    b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.overflow = overflow;
-    b.win_a = ctx->anchor_a; b.win_b = ctx->anchor_b;
-    hipLaunchKernelGGL(k_anchor_insert, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
-    if (count < n) {
-      hipLaunchKernelGGL(k_anchor_lookup, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
-    }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, counts, (uint32_t)asize,
+    b.keys[which] = static_cast<unsigned long long *>(ctx->d_akeys[which].ptr);
+    b.counts[which] = static_cast<uint32_t *>(ctx->d_acounts[which].ptr);
+    b.slot_of[which] = static_cast<uint32_t *>(ctx->d_aslot[which].ptr);
+    b.pos_of[which] = static_cast<uint32_t *>(ctx->d_apos[which].ptr);
+    sc.slot_of[which] = b.slot_of[which]; sc.pos_of[which] = b.pos_of[which];
+    sc.offsets[which] = static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr);
+    sc.members[which] = static_cast<uint32_t *>(ctx->d_amembers[which].ptr);
+    sc.minfo[which] = static_cast<uint4 *>(ctx->d_ainfo[which].ptr);
+  }
+  sc.fingerprint = b.fingerprint; sc.member_fingerprint = static_cast<uint64_t *>(ctx->d_afp[1].ptr);
+  sc.seqlen = ctx->db.seqlen; sc.rank = static_cast<const uint32_t *>(ctx->d_arank.ptr); sc.seq_off = ctx->db.seq_off; sc.n = n;
+  hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, b.keys[0], b.counts[0],
+                     b.keys[1], b.counts[1], asize);
+  hipLaunchKernelGGL(k_anchor_place<true>, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
+  if (count < n) {
+    hipLaunchKernelGGL(k_anchor_place<false>, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
+  }
+  for (int which = 0; which < 2; ++which) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize,
                        static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, counts, (uint32_t)asize,
-                       static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), offsets);
-    hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, slot_of, n, offsets, cursor,
-                       static_cast<uint32_t *>(ctx->d_amembers[which].ptr), ctx->db.seqlen,
-                       static_cast<const uint32_t *>(ctx->d_arank.ptr), ctx->db.seq_off, static_cast<uint4 *>(ctx->d_ainfo[which].ptr));
-    SWA_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize,
+                       static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), static_cast<uint64_t *>(ctx->d_aoffsets[which].ptr));
   }
+  hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, sc);
+  SWA_HIP(ctx, hipGetLastError());
   ctx->anchor_first = first;
   ctx->anchor_count = count;
   ctx->anchor_ready = true;
   return SWA_OK;
+}
+
+// small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_group_pairs), else by
+// enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
+static int pairs_width_for(const swa_ctx * ctx) {
+  const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
+  const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;       // (only chosen when the pair kernels apply)
+  if (env_enum != nullptr && env_enum[0] == '1' && !window_mode) { return 0; }
+  return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0);
+}
+// groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
+// them to the enumerating / tiled kernel (test switch)
+static uint32_t pair_big_limit() {
+  const char * env = getenv("SWA_D1_PAIR_BIG");
+  return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env))) : kPairBigCap;
 }
 
 // anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
@@ -952,17 +978,11 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   swa_t0(ctx, 3);
   // work items: every group of the index (it was built for exactly this query range)
   const uint64_t asize = ctx->anchor_slots;
-  // small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_pairs), else by
-  // enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
-  const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
-  const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;       // (only chosen when the pair kernels apply)
-  const int pairs_width = (env_enum != nullptr && env_enum[0] == '1' && !window_mode) ? 0 : (ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0));
+  const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;
+  const int pairs_width = pairs_width_for(ctx);
   const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");                    // test switch: tiled pair kernel for the big groups in any mode
   const bool tiled_big = pairs_width != 0 && (window_mode || (env_tiled != nullptr && env_tiled[0] == '1'));
-  // groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
-  // them to the enumerating / tiled kernel (test switch)
-  const char * env_pair_big = getenv("SWA_D1_PAIR_BIG");
-  const uint32_t pair_big = env_pair_big != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env_pair_big))) : kPairBigCap;
+  const uint32_t pair_big = pair_big_limit();
   for (int which = 0; which < 2; ++which) {
     if (pairs_width != 0) {
       PairLists l{};
@@ -1208,11 +1228,9 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   swa_t1(ctx, 7);
   const uint64_t asize = ctx->anchor_slots;
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
-  hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, std::max<uint64_t>(n, asize), 256, 8)), dim3(256), 0, ctx->stream,
-                     ctx->db.seqlen, n, static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
-                     static_cast<const uint32_t *>(ctx->d_acounts[1].ptr), asize, dflags, ctx->db.seqs, ctx->db.seq_off,
-                     ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen, (ctx->anchor_a != 0 || ctx->anchor_b != 0) ? 1u : 0u);
-  SWA_TRY(launch_seqhash(ctx, true));
+  hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                     static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
+                     asize, dflags, pairs_width_for(ctx) != 0 ? pair_big_limit() : 0u);
   // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
   swa_t0(ctx, 2);
   hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
@@ -1221,8 +1239,8 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
                      static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
   DupArgs da{};
   da.seqs = ctx->db.seqs; da.seq_off = ctx->db.seq_off; da.seqlen = ctx->db.seqlen;
-  da.seqhash = static_cast<const uint64_t *>(ctx->d_seqhash.ptr);
-  da.members = static_cast<const uint32_t *>(ctx->d_amembers[0].ptr);
+  da.minfo = static_cast<const uint4 *>(ctx->d_ainfo[0].ptr);
+  da.member_fingerprint = static_cast<const uint64_t *>(ctx->d_afp[1].ptr);
   da.flag = dflags;
   // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair is
   // seen by exactly one rank); a single GPU honours the slice it was asked about
@@ -1237,8 +1255,8 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 2);
   // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence / pb = 0 [4] oversized group
-  // [5] members of oversized groups [6] 0xFFFFFFFF - shortest sequence
-  uint32_t flags[7] = {};
+  // [5] members of oversized groups [6] 0xFFFFFFFF - shortest sequence [7] groups for the enumerating kernels
+  uint32_t flags[8] = {};
   SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
@@ -1250,6 +1268,15 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
     return SWA_OK;
   }
   *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
+  // Zobrist hashes and XOR streams of the members: only the enumerating kernels read them (the pair kernels compare
+  // the sequences themselves, the duplicate check their fingerprints); the full route hashes everybody anyway
+  ctx->aux_members = false;
+  // (the groups of the whole database bound those of any later re-index — another query range, another owner)
+  ctx->aux_needed = flags[7] != 0 || pairs_width_for(ctx) == 0;
+  if (!*needs_table && ctx->aux_needed) {
+    SWA_TRY(launch_seqhash(ctx, true));
+    ctx->aux_members = true;
+  }
   return SWA_OK;
 }
 
@@ -1315,7 +1342,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
       }
     }
     owned_ok = !needs_table;
-    ctx->aux_complete = owned_ok && ctx->owner_world == 1;
+    ctx->aux_complete = owned_ok && ctx->owner_world == 1 && (ctx->aux_members || !ctx->aux_needed);
     SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!owned_ok) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream)); }
@@ -1442,6 +1469,12 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
         swa_t0(ctx, 7);
         SWA_TRY(build_anchor_index(ctx, first, count));
         swa_t1(ctx, 7);
+        // another owner's groups after a lean build: the enumerating kernels, if any group needs them, read hashes
+        // and XOR streams that exist for the previous owner's members only
+        if (!ctx->full_index && !ctx->aux_complete && ctx->aux_needed) {
+          SWA_TRY(launch_seqhash(ctx, true));
+          ctx->aux_members = true;
+        }
       }
       SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count));
     }
@@ -1553,7 +1586,6 @@ extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world
     ctx->owner_world = world;
     ctx->anchor_ready = false;                               // the next network call indexes this rank's groups
     ctx->anchor_slack = 0;
-    if (!ctx->full_index && !ctx->aux_complete) { ctx->d1_ready = false; }   // hashes exist for the previous owner's groups only
   }
   return SWA_OK;
 }

@@ -4,7 +4,7 @@
 // against keys computed on the host.  No Python, no library: one binary, one stream.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o anchor_race anchor_race.hip \
-//         ../../swarm_amd/csrc/ctx.hip ../../swarm_amd/csrc/host_tables.cpp
+//         ../../swarm_amd/csrc/ctx.hip ../../swarm_amd/csrc/cluster_gpu.hip ../../swarm_amd/csrc/host_tables.cpp
 //   ./anchor_race [n=1000000] [rounds=20]
 //
 // Flows (each `rounds` times, fresh anchor buffers every round like a fresh context):
@@ -84,7 +84,9 @@ void make_db(Db & db, uint32_t n) {
 
 struct Anchor {
   unsigned long long * keys[2] = {};
-  uint32_t * counts[2] = {}, * cursor[2] = {}, * slot_of[2] = {}, * members[2] = {};
+  uint32_t * counts[2] = {}, * pos_of[2] = {}, * slot_of[2] = {}, * members[2] = {};
+  uint4 * minfo[2] = {};
+  uint64_t * fp[2] = {};
   uint64_t * offsets[2] = {};
   swa_item * items[2] = {};
   uint32_t * acounters = nullptr;
@@ -93,7 +95,8 @@ struct Anchor {
 
 void alloc_anchor(Anchor & a, uint32_t n, uint64_t asize, uint32_t tiles) {
   for (int w = 0; w < 2; ++w) {
-    CK(hipMalloc(&a.keys[w], asize * 8)); CK(hipMalloc(&a.counts[w], asize * 4)); CK(hipMalloc(&a.cursor[w], asize * 4));
+    CK(hipMalloc(&a.keys[w], asize * 8)); CK(hipMalloc(&a.counts[w], asize * 4)); CK(hipMalloc(&a.pos_of[w], (uint64_t)n * 4));
+    CK(hipMalloc(&a.minfo[w], (uint64_t)n * 16)); CK(hipMalloc(&a.fp[w], (uint64_t)n * 8));
     CK(hipMalloc(&a.offsets[w], (asize + 1) * 8)); CK(hipMalloc(&a.slot_of[w], (uint64_t)n * 4));
     CK(hipMalloc(&a.members[w], (uint64_t)n * 4)); CK(hipMalloc(&a.items[w], ((uint64_t)n + 128) * sizeof(swa_item)));
   }
@@ -103,7 +106,7 @@ void alloc_anchor(Anchor & a, uint32_t n, uint64_t asize, uint32_t tiles) {
 
 void free_anchor(Anchor & a) {
   for (int w = 0; w < 2; ++w) {
-    CK(hipFree(a.keys[w])); CK(hipFree(a.counts[w])); CK(hipFree(a.cursor[w])); CK(hipFree(a.offsets[w]));
+    CK(hipFree(a.keys[w])); CK(hipFree(a.counts[w])); CK(hipFree(a.pos_of[w])); CK(hipFree(a.minfo[w])); CK(hipFree(a.fp[w])); CK(hipFree(a.offsets[w]));
     CK(hipFree(a.slot_of[w])); CK(hipFree(a.members[w])); CK(hipFree(a.items[w]));
   }
   CK(hipFree(a.acounters)); CK(hipFree(a.scan_tmp));
@@ -181,19 +184,29 @@ int main(int argc, char ** argv) {
       }
       if (flow != 3) { alloc_anchor(a, n, asize, tiles); }     // swa_reserve of a fresh context: while kernels run
       CK(hipMemsetAsync(a.acounters, 0, 64 * 4, stream));
-      for (int which = 0; which < 2; ++which) {
-        k_anchor_clear<<<grid(asize), 256, 0, stream>>>(a.keys[which], a.counts[which], a.cursor[which], asize);
+      {
         AnchorBuildArgs b{};
-        b.seqs = d_seqs; b.seq_off = d_seq_off; b.seqlen = d_seqlen; b.n = n; b.which = which; b.first = 0; b.count = n;
-        b.keys = a.keys[which]; b.counts = a.counts[which]; b.amask = asize - 1; b.slot_of = a.slot_of[which];
-        b.owner_rank = 0; b.owner_world = 1; b.overflow = d_flags + 2;
-        k_anchor_insert<<<grid(n), 256, 0, stream>>>(b);
-        k_scan_tiles<<<tiles, kScanBlock, 0, stream>>>(a.counts[which], (uint32_t)asize, a.scan_tmp);
-        k_scan_sums<<<1, kScanBlock, 0, stream>>>(a.scan_tmp, tiles);
-        k_scan_apply<<<tiles, kScanBlock, 0, stream>>>(a.counts[which], (uint32_t)asize, a.scan_tmp, a.offsets[which]);
-        k_anchor_scatter<<<grid(n), 256, 0, stream>>>(a.slot_of[which], n, a.offsets[which], a.cursor[which], a.members[which]);
-        k_anchor_items<<<grid(asize), 256, 0, stream>>>(a.counts[which], a.offsets[which], asize, a.items[which], a.acounters + which,
-                                                       a.items[which] + (n / 2 + 64), a.acounters + 3 + which, 64u);
+        AnchorScatterArgs sc{};
+        b.seqs = d_seqs; b.seq_off = d_seq_off; b.seqlen = d_seqlen; b.n = n; b.first = 0; b.count = n; b.amask = asize - 1;
+        b.fingerprint = a.fp[0]; b.owner_rank = 0; b.owner_world = 1; b.flags = d_flags; b.minlen = kMinAnchoredLen;
+        for (int which = 0; which < 2; ++which) {
+          b.keys[which] = a.keys[which]; b.counts[which] = a.counts[which]; b.slot_of[which] = a.slot_of[which]; b.pos_of[which] = a.pos_of[which];
+          sc.slot_of[which] = a.slot_of[which]; sc.pos_of[which] = a.pos_of[which]; sc.offsets[which] = a.offsets[which];
+          sc.members[which] = a.members[which]; sc.minfo[which] = a.minfo[which];
+        }
+        sc.fingerprint = a.fp[0]; sc.member_fingerprint = a.fp[1]; sc.seqlen = d_seqlen; sc.rank = d_rank; sc.seq_off = d_seq_off; sc.n = n;
+        k_anchor_clear<<<grid(asize), 256, 0, stream>>>(a.keys[0], a.counts[0], a.keys[1], a.counts[1], asize);
+        k_anchor_place<true><<<grid(n), 256, 0, stream>>>(b);
+        for (int which = 0; which < 2; ++which) {
+          k_scan_tiles<<<tiles, kScanBlock, 0, stream>>>(a.counts[which], (uint32_t)asize, a.scan_tmp);
+          k_scan_sums<<<1, kScanBlock, 0, stream>>>(a.scan_tmp, tiles);
+          k_scan_apply<<<tiles, kScanBlock, 0, stream>>>(a.counts[which], (uint32_t)asize, a.scan_tmp, a.offsets[which]);
+        }
+        k_anchor_scatter<<<grid(n), 256, 0, stream>>>(sc);
+        for (int which = 0; which < 2; ++which) {
+          k_anchor_items<<<grid(asize), 256, 0, stream>>>(a.counts[which], a.offsets[which], asize, a.items[which], a.acounters + which,
+                                                         a.items[which] + (n / 2 + 64), a.acounters + 3 + which, 64u);
+        }
       }
       CK(hipGetLastError());
       CK(hipStreamSynchronize(stream));
