@@ -159,6 +159,7 @@ static void invalidate(swa_ctx * ctx) {
   ctx->full_index = false;
   ctx->aux_complete = false;
   ctx->anchor_ready = false;
+  ctx->anchor_slack = 0;
   ctx->anchor_a = ctx->anchor_b = 0;
   ctx->qgram_ready = false;
   ctx->scan_ready = false;

@@ -875,14 +875,50 @@ static uint64_t items_capacity(uint32_t n) { return std::max<uint64_t>(uint64_t(
 constexpr uint32_t kSmallChunkPrefix = 16;  // prefix pass: seeds per small item (a seed walks its whole sequence)
 constexpr uint32_t kSmallChunkSuffix = 64;  // suffix pass: 32 positions per seed, the table build dominates: no split
 
+// small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_group_pairs), else by
+// enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
+static int pairs_width_for(const swa_ctx * ctx) {
+  const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
+  const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;       // (only chosen when the pair kernels apply)
+  if (env_enum != nullptr && env_enum[0] == '1' && !window_mode) { return 0; }
+  return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0);
+}
+// groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
+// them to the enumerating / tiled kernel (test switch)
+static uint32_t pair_big_limit() {
+  const char * env = getenv("SWA_D1_PAIR_BIG");
+  return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env))) : kPairBigCap;
+}
+
+// the work lists of the pair kernels and of the duplicate check (k_anchor_items_classes), made with the index
+static void launch_pair_lists(swa_ctx * ctx) {
+  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
+  for (int which = 0; which < 2; ++which) {
+    PairLists l{};
+    l.items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
+    for (uint32_t c = 0; c <= kPairClasses; ++c) { l.region[c] = pair_region(c, ctx->db.n); }
+    l.counters = acounters + 32 + 8 * which;
+    l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
+    l.chunk_counter = acounters + which;
+    l.pair_big = pair_big_limit();
+    hipLaunchKernelGGL(k_anchor_items_classes, dim3(grid_for(ctx, ctx->anchor_slots, 256, 8)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
+                       static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), ctx->anchor_slots, l);
+  }
+}
+
 // (re)builds the two anchor indexes for the query range [first, first + count)
 static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   ctx->anchor_ready = false;
   const uint32_t n = ctx->db.n;
-  // load <= 0.5 for the anchors that get a slot: all of the range, or this rank's share of them
-  // (hashed ownership: 25 % headroom, and k_anchor_insert reports a table that is still too small)
-  const bool by_share = ctx->owner_world > 1 && ctx->anchor_slack == 0;
-  const uint64_t share = by_share ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count;
+  // Key tables: load <= 0.5 if every anchor that gets a slot were its own group — all of the range, or (a rank of a
+  // multi-GPU job, hashed ownership) this rank's share of them with 25 % headroom: keys then sit at most 1024 slots
+  // from home and k_anchor_place reports a table that turns out too small (anchor_slack: the next build sizes it for
+  // the whole range).  Smaller tables were tried for the single GPU (amplicon sets have far fewer groups than
+  // members): every pass over the table gets cheaper, but the placing atomics crowd into fewer cache lines and the
+  // build as a whole is slower (10 M: 4.4 ms against 3.75).
+  const bool optimistic = ctx->owner_world > 1 && ctx->anchor_slack == 0;
+  const uint64_t share = optimistic ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count;
   uint64_t asize = 64;
   while (asize < 2ull * share) { asize <<= 1; }
   ctx->anchor_slots = asize;
@@ -907,7 +943,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   AnchorBuildArgs b{};
   AnchorScatterArgs sc{};
   b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n;
-  b.first = first; b.count = count; b.amask = asize - 1;
+  b.first = first; b.count = count; b.amask = asize - 1; b.probe_limit = optimistic ? std::min<uint64_t>(1024, asize - 1) : asize - 1;
   b.fingerprint = static_cast<uint64_t *>(ctx->d_afp[0].ptr);
   b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.flags = dflags;
   b.win_a = ctx->anchor_a; b.win_b = ctx->anchor_b;
@@ -931,6 +967,8 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   if (count < n) {
     hipLaunchKernelGGL(k_anchor_place<false>, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
   }
+  // (a table that turned out too small — flags[2] — still leaves a consistent index of the amplicons placed before
+  // that: what follows runs on it harmlessly until the host looks at the flag, at the next point where it waits anyway)
   for (int which = 0; which < 2; ++which) {
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize,
                        static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
@@ -939,26 +977,13 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
                        static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), static_cast<uint64_t *>(ctx->d_aoffsets[which].ptr));
   }
   hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, sc);
+  ctx->pair_lists = pairs_width_for(ctx) != 0;
+  if (ctx->pair_lists) { launch_pair_lists(ctx); }
   SWA_HIP(ctx, hipGetLastError());
   ctx->anchor_first = first;
   ctx->anchor_count = count;
   ctx->anchor_ready = true;
   return SWA_OK;
-}
-
-// small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_group_pairs), else by
-// enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
-static int pairs_width_for(const swa_ctx * ctx) {
-  const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
-  const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;       // (only chosen when the pair kernels apply)
-  if (env_enum != nullptr && env_enum[0] == '1' && !window_mode) { return 0; }
-  return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0);
-}
-// groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
-// them to the enumerating / tiled kernel (test switch)
-static uint32_t pair_big_limit() {
-  const char * env = getenv("SWA_D1_PAIR_BIG");
-  return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env))) : kPairBigCap;
 }
 
 // anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
@@ -971,7 +996,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
   // item counts [0,1] big / [3,4] small, fallback count [2], work counters of both passes [16..32)
-  SWA_HIP(ctx, hipMemsetAsync(acounters, 0, 64 * sizeof(uint32_t), ctx->stream));
+  const int pairs_width = ctx->pair_lists ? pairs_width_for(ctx) : 0;
+  // (with pair lists, made at index build: [0], [1] and [32..48) are the index's)
+  SWA_HIP(ctx, hipMemsetAsync(acounters + (pairs_width != 0 ? 2 : 0), 0, (pairs_width != 0 ? 30 : 32) * sizeof(uint32_t), ctx->stream));
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
   auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
@@ -979,24 +1006,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   // work items: every group of the index (it was built for exactly this query range)
   const uint64_t asize = ctx->anchor_slots;
   const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;
-  const int pairs_width = pairs_width_for(ctx);
   const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");                    // test switch: tiled pair kernel for the big groups in any mode
   const bool tiled_big = pairs_width != 0 && (window_mode || (env_tiled != nullptr && env_tiled[0] == '1'));
-  const uint32_t pair_big = pair_big_limit();
-  for (int which = 0; which < 2; ++which) {
-    if (pairs_width != 0) {
-      PairLists l{};
-      l.items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
-      for (uint32_t c = 0; c <= kPairClasses; ++c) { l.region[c] = pair_region(c, ctx->db.n); }
-      l.counters = acounters + 32 + 8 * which;
-      l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
-      l.chunk_counter = acounters + which;
-      l.pair_big = pair_big;
-      hipLaunchKernelGGL(k_anchor_items_classes, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                         static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
-                         static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize, l);
-      continue;
-    }
+  for (int which = 0; which < 2 && pairs_width == 0; ++which) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                        static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
                        static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
@@ -1061,7 +1073,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     else { hipLaunchKernelGGL((k_d1_anchor<false, 1>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     SWA_HIP(ctx, hipGetLastError());
   }
-  // seeds (or halves of seeds) the anchored passes skipped
+  // seeds (or halves of seeds) the anchored passes skipped (a lean build has made sure there are none: no sequence
+  // too short, no oversized group — and what holds for the whole database holds for every part of it)
+  if (ctx->full_index)
   hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
                      count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
                      static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
@@ -1233,10 +1247,12 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
                      asize, dflags, pairs_width_for(ctx) != 0 ? pair_big_limit() : 0u);
   // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
   swa_t0(ctx, 2);
-  hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                     static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
-                     asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
-                     static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
+  if (!ctx->pair_lists) {
+    hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
+                       asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
+                       static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
+  }
   DupArgs da{};
   da.seqs = ctx->db.seqs; da.seq_off = ctx->db.seq_off; da.seqlen = ctx->db.seqlen;
   da.minfo = static_cast<const uint4 *>(ctx->d_ainfo[0].ptr);
@@ -1246,10 +1262,20 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   // seen by exactly one rank); a single GPU honours the slice it was asked about
   da.first = ctx->owner_world > 1 ? 0u : first;
   da.count = ctx->owner_world > 1 ? n : count;
-  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n);
-  da.item_count = acounters + 3;
-  hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
-  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);
+  if (ctx->pair_lists) {
+    da.pair_items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);
+    for (uint32_t c = 0; c <= kPairClasses; ++c) { da.pair_region[c] = pair_region(c, n); }
+    da.pair_counters = acounters + 32;
+    hipLaunchKernelGGL(k_dup_bundles, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
+    da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + pair_region(kPairClasses, n);   // groups of 65..pair_big
+    da.item_count = acounters + 32 + kPairClasses;
+    hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
+  } else {
+    da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n);
+    da.item_count = acounters + 3;
+    hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
+  }
+  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);             // chunks of the groups beyond
   da.item_count = acounters + 0;
   hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
   SWA_HIP(ctx, hipGetLastError());
@@ -1261,11 +1287,10 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
   if (shortest != nullptr) { *shortest = 0xFFFFFFFFu - flags[6]; }
-  if (flags[2] != 0) {                                      // skewed ownership: share-sized key tables too small
+  if (flags[2] != 0 && ctx->anchor_slack == 0) {            // the optimistic key tables were too small: once more, safe size
     ctx->anchor_slack = 1;
-    ctx->anchor_ready = false;
-    *needs_table = true;                                     // (rare) take the full route for this build
-    return SWA_OK;
+    SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
+    return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
   }
   *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
   // Zobrist hashes and XOR streams of the members: only the enumerating kernels read them (the pair kernels compare

@@ -65,6 +65,7 @@ struct swa_ctx {
   uint64_t anchor_slots = 0;
   bool full_index = false;       // d_seqhash / d_aux cover ALL amplicons and d_table / d_bloom are built (ensure_full_index)
   bool aux_members = false;      // d_seqhash / d_aux hold the members of the anchor indexes (lean build that needed them)
+  bool pair_lists = false;       // the anchor indexes carry the work lists of the pair kernels (k_anchor_items_classes)
   bool aux_needed = true;        // some anchor group is served by the enumerating kernels (they read d_seqhash / d_aux)
   bool aux_complete = false;     // d_seqhash / d_aux cover every amplicon that has an anchor (lean build with world = 1)
   uint32_t owner_rank = 0, owner_world = 1;   // swa_d1_set_ownership: this context serves the anchor groups of one rank

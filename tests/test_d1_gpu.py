@@ -508,3 +508,78 @@ def test_tiled_pair_kernel_on_big_groups(tmp_path, monkeypatch):
         assert len(nb) > 2000
     finally:
         ctx.close()
+
+
+def test_every_anchor_its_own_group(gpu_ctx):
+    """30 000 unrelated sequences (plus a few neighbours so that there is a network): as many anchor groups as
+    amplicons, the fullest the key tables get."""
+    rng = np.random.default_rng(808)
+    seqs = set()
+    while len(seqs) < 30000:
+        seqs.add("".join(rng.choice(list("ACGT"), size=int(rng.integers(90, 130)))))
+    seqs = sorted(seqs)
+    extra = set()
+    for s in seqs[:400]:
+        p = int(rng.integers(0, len(s)))
+        extra.add(s[:p] + s[p + 1:])
+    seqs = sorted(set(seqs) | extra)
+    db = S.build_db([(f"s{i}_{1 + (i * 7) % 23}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    off, nb = _check_vs_oracle(gpu_ctx, db)
+    assert len(nb) >= 400
+
+
+def _family(rng, length, members, max_edits=2, alphabet="ACGT"):
+    cent = "".join(rng.choice(list(alphabet), length))
+    seqs = {cent}
+    while len(seqs) < members:
+        s = cent
+        for _ in range(int(rng.integers(1, max_edits + 1))):
+            p = int(rng.integers(0, len(s)))
+            k = int(rng.integers(0, 3))
+            b = str(rng.choice(list("ACGT")))
+            s = s[:p] + b + s[p + 1:] if k == 0 else (s[:p] + s[p + 1:] if k == 1 else s[:p] + b + s[p:])
+        seqs.add(s)
+    return seqs
+
+
+@pytest.mark.parametrize("length,sizes", [(150, [70, 100, 128, 129, 200, 255, 256, 257, 300]),        # one workgroup per group
+                                          (240, [66, 130, 250, 270]),                                  # 8 words per member
+                                          (150, [2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65] * 3),   # every size class
+                                          (90, [4, 8, 16, 32, 64, 90])])
+def test_pair_kernel_group_sizes(gpu_ctx, length, sizes):
+    """k_d1_group_pairs: groups on both sides of every class boundary (4, 8, 16, 32, 64 | one workgroup up to 256 |
+    enumerating kernel beyond), ties in abundance, both widths of the member records."""
+    rng = np.random.default_rng(length * 1000 + len(sizes))
+    seqs = set()
+    for g in sizes:
+        seqs |= _family(rng, length, g)
+    seqs = sorted(seqs)
+    db = S.build_db([(f"s{i}_{1 + (i * 11) % 5}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    for ncb in (False, True):
+        off, nb = _check_vs_oracle(gpu_ctx, db, ncb)
+    assert len(nb) > len(seqs) // 2
+
+
+def test_pair_kernel_on_runs_and_length_extremes(gpu_ctx):
+    """Low-complexity families (homopolymer runs: an indel anywhere in a run is the same sequence; the end-aligned
+    comparison sees them from the other side), members of 33..160 nt in the same groups, sequences that are prefixes /
+    suffixes of one another."""
+    rng = np.random.default_rng(4242)
+    seqs = set()
+    for length in (70, 100, 159, 160):
+        seqs |= _family(rng, length, 40, max_edits=2, alphabet="AC")
+    for _ in range(20):                                       # run-heavy centroids
+        cent = "".join(str(rng.choice(list("ACGT"))) * int(rng.integers(1, 9)) for _ in range(40))[:150]
+        seqs.add(cent)
+        for _ in range(25):
+            p = int(rng.integers(0, len(cent)))
+            k = int(rng.integers(0, 3))
+            b = str(rng.choice(list("ACGT")))
+            seqs.add(cent[:p] + b + cent[p + 1:] if k == 0 else (cent[:p] + cent[p + 1:] if k == 1 else cent[:p] + b + cent[p:]))
+    base = "".join(rng.choice(list("ACGT"), 160))
+    for cut in range(1, 60):                                  # chains of prefixes and of suffixes (lengths 101..160)
+        seqs.add(base[:160 - cut]); seqs.add(base[cut:])
+    seqs = sorted(s for s in seqs if 1 <= len(s) <= 160)
+    db = S.build_db([(f"s{i}_{1 + (i * 3) % 4}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    for ncb in (False, True):
+        _check_vs_oracle(gpu_ctx, db, ncb)
