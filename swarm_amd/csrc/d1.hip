@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
                                                  const uint32_t * __restrict__ seqlen,
                                                  const uint64_t * __restrict__ zobrist, uint32_t zlen,
                                                  uint32_t n, uint64_t * __restrict__ seqhash,
-                                                 swa_aux * __restrict__ aux, const uint32_t * __restrict__ list,
+                                                 swa_aux * __restrict__ aux, const uint4 * __restrict__ list,
                                                  const uint64_t * __restrict__ list_count) {
   extern __shared__ uint64_t lds[];
   const uint64_t * zob = zobrist;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
   // waves, work proportional to the rank's share instead of a walk over the whole replicated database)
   const uint32_t todo = list != nullptr ? (uint32_t)*list_count : n;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < todo; k += gridDim.x * blockDim.x) {
-    const uint32_t a = list != nullptr ? list[k] : k;
+    const uint32_t a = list != nullptr ? list[k].x : k;
     const uint64_t * s = seqs + seq_off[a];
     const uint32_t len = seqlen[a];
     uint64_t h = 0, dall = 0, iall = 0;
@@ -928,7 +928,6 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     SWA_TRY(swa_reserve(ctx, ctx->d_aoffsets[which], (asize + 1) * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aslot[which], uint64_t(n) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_apos[which], uint64_t(n) * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_amembers[which], uint64_t(n) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], items_capacity(n) * sizeof(swa_item)));
     SWA_TRY(swa_reserve(ctx, ctx->d_ainfo[which], uint64_t(n) * sizeof(uint4)));
   }
@@ -956,7 +955,6 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     b.pos_of[which] = static_cast<uint32_t *>(ctx->d_apos[which].ptr);
     sc.slot_of[which] = b.slot_of[which]; sc.pos_of[which] = b.pos_of[which];
     sc.offsets[which] = static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr);
-    sc.members[which] = static_cast<uint32_t *>(ctx->d_amembers[which].ptr);
     sc.minfo[which] = static_cast<uint4 *>(ctx->d_ainfo[which].ptr);
   }
   sc.fingerprint = b.fingerprint; sc.member_fingerprint = static_cast<uint64_t *>(ctx->d_afp[1].ptr);
@@ -1024,7 +1022,6 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.zlen = ctx->zobrist_len; a.maxwords = maxwords;
     a.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
     a.rank = static_cast<const uint32_t *>(ctx->d_arank.ptr);
-    a.members = static_cast<const uint32_t *>(ctx->d_amembers[pass].ptr);
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
     a.item_count = acounters + pass;
     a.pass = pass;
@@ -1144,7 +1141,7 @@ static int launch_seqhash(swa_ctx * ctx, bool members_only) {
   swa_t0(ctx, 0);
   // members_only: the member lists of the two anchor indexes (an amplicon in both is hashed twice: same values)
   for (int pass = 0; pass < (members_only ? 2 : 1); ++pass) {
-    const uint32_t * list = members_only ? static_cast<const uint32_t *>(ctx->d_amembers[pass].ptr) : nullptr;
+    const uint4 * list = members_only ? static_cast<const uint4 *>(ctx->d_ainfo[pass].ptr) : nullptr;
     const uint64_t * list_count = members_only ? static_cast<const uint64_t *>(ctx->d_aoffsets[pass].ptr) + ctx->anchor_slots : nullptr;
     const uint64_t upper = members_only && ctx->owner_world > 1 ? (uint64_t(n) / ctx->owner_world) * 2 + 1024 : n;
     const int hgrid = grid_for(ctx, upper, 256, 8);

@@ -192,7 +192,7 @@ int main(int argc, char ** argv) {
         for (int which = 0; which < 2; ++which) {
           b.keys[which] = a.keys[which]; b.counts[which] = a.counts[which]; b.slot_of[which] = a.slot_of[which]; b.pos_of[which] = a.pos_of[which];
           sc.slot_of[which] = a.slot_of[which]; sc.pos_of[which] = a.pos_of[which]; sc.offsets[which] = a.offsets[which];
-          sc.members[which] = a.members[which]; sc.minfo[which] = a.minfo[which];
+          sc.minfo[which] = a.minfo[which];
         }
         sc.fingerprint = a.fp[0]; sc.member_fingerprint = a.fp[1]; sc.seqlen = d_seqlen; sc.rank = d_rank; sc.seq_off = d_seq_off; sc.n = n;
         k_anchor_clear<<<grid(asize), 256, 0, stream>>>(a.keys[0], a.counts[0], a.keys[1], a.counts[1], asize);

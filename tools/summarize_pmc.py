@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """tools/summarize_pmc.py <dir with pmc*.csv from tools/profile_d1.sh> <steps+warmup> <workload tag> <out.json>
 
-Per-dispatch averages of every collected counter for the kernels of the d=1 network, and the
-HBM traffic of ONE bench step (= one launch of the kernel group the roofline is quoted on):
+Per-dispatch averages of every collected counter for the kernels of the d=1 step, and the
+HBM traffic of ONE bench step (= one launch of the kernel group the roofline is quoted on: index
+build + pair kernels + CSR):
     hbm_bytes_per_launch = sum over the group's dispatches of (2 x FETCH_SIZE + WRITE_SIZE) KiB-units x 1024 / steps
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; FETCH_SIZE is doubled as
 /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950 (128-B requests
@@ -24,8 +25,8 @@ def main() -> None:
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
-                if "k_d1_" in name:
-                    m = re.search(r"(k_d1_\w+<[^>]*>)", name)
+                if "anonymous namespace" in name:           # every kernel of the library (not the harness's fills / copies)
+                    m = re.search(r"(k_\w+(<[^>(]*>)?)", name)
                     short = m.group(1) if m else name
                     per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     kernels = {}
@@ -38,7 +39,7 @@ def main() -> None:
     corrected = (2.0 * fetch_kib + write_kib) * 1024.0 / steps
     rec = {"workload": tag, "bench_steps_profiled": steps,
            "hbm_bytes_per_launch": corrected, "hbm_bytes_per_launch_uncorrected": raw,
-           "note": "launch = one bench step = all k_d1_pairs / k_d1_anchor / k_d1_probe dispatches of the step; "
+           "note": "launch = one bench step = every dispatch of the library's kernels in the step; "
                    "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported",
            "kernels": kernels}
     with open(out, "w") as fh:
