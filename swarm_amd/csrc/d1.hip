@@ -1004,8 +1004,13 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   // work items: every group of the index (it was built for exactly this query range)
   const uint64_t asize = ctx->anchor_slots;
   const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;
-  const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");                    // test switch: tiled pair kernel for the big groups in any mode
-  const bool tiled_big = pairs_width != 0 && (window_mode || (env_tiled != nullptr && env_tiled[0] == '1'));
+  // groups beyond pair_big: the tiled pair kernel, unless some group is so large (> kPairTiledCap) that the index build
+  // prepared hashes and XOR streams for the enumerating kernel — which then takes the whole list (window mode has
+  // only the pair kernels).  SWA_D1_PAIRS_TILED=1 / 0: test switches
+  const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");
+  const bool aux_ready = ctx->full_index || ctx->aux_members;
+  const bool tiled_big = pairs_width != 0 && (window_mode || !aux_ready || (env_tiled != nullptr && env_tiled[0] == '1')) &&
+                         !(env_tiled != nullptr && env_tiled[0] == '0' && aux_ready && !window_mode);
   for (int which = 0; which < 2 && pairs_width == 0; ++which) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                        static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
@@ -1241,7 +1246,7 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                      static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
-                     asize, dflags, pairs_width_for(ctx) != 0 ? pair_big_limit() : 0u);
+                     asize, dflags, pairs_width_for(ctx) != 0 ? kPairTiledCap : 0u);
   // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
   swa_t0(ctx, 2);
   if (!ctx->pair_lists) {

@@ -545,7 +545,9 @@ def _family(rng, length, members, max_edits=2, alphabet="ACGT"):
 @pytest.mark.parametrize("length,sizes", [(150, [70, 100, 128, 129, 200, 255, 256, 257, 300]),        # one workgroup per group
                                           (240, [66, 130, 250, 270]),                                  # 8 words per member
                                           (150, [2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65] * 3),   # every size class
-                                          (90, [4, 8, 16, 32, 64, 90])])
+                                          (90, [4, 8, 16, 32, 64, 90]),
+                                          (150, [300, 600, 1000]),            # tiled pair kernel, no hashes built
+                                          (150, [300, 700, 1100])])           # a group beyond its range: enumerating kernel for all three
 def test_pair_kernel_group_sizes(gpu_ctx, length, sizes):
     """k_d1_group_pairs: groups on both sides of every class boundary (4, 8, 16, 32, 64 | one workgroup up to 256 |
     enumerating kernel beyond), ties in abundance, both widths of the member records."""
