@@ -395,12 +395,19 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   }
 
   timer.lap("entry index");
+  // The two table-based checks below only read the parsed entries and produce an error or nothing: they run on their
+  // own threads next to the sort and the gather (at 10 M amplicons 50-100 ms that used to sit on the critical path);
+  // their verdict is taken where the sequential order of the checks puts it.
+  std::string check_error;
+  int check_rc = SWA_OK;
+  const unsigned check_threads = std::max(1u, threads / 2);     // (the sort next to them is the critical path)
+  std::thread checker([&]() {
   // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
   {
     const uint64_t tsize = n ? 2ull * n : 1;
     std::unique_ptr<std::atomic<uint32_t>[]> idtab(new std::atomic<uint32_t>[tsize]);   // filled in parallel below
-    run_parallel(threads, [&](unsigned t) {
-      for (uint64_t i = tsize * t / threads; i < tsize * (t + 1) / threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
+    run_parallel(check_threads, [&](unsigned t) {
+      for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
     });
     auto id_span = [&](const RawEntry * e, const char *& s, uint32_t & l) {
       const char * hdr = hdr_of(e);
@@ -408,11 +415,11 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
       else { s = hdr + e->ab_end; l = e->hdr_len - (uint32_t)e->ab_end; }
     };
     std::atomic<uint32_t> dup_entry{0xFFFFFFFFu};
-    run_parallel(threads, [&](unsigned t) {
+    run_parallel(check_threads, [&](unsigned t) {
       // entries and headers stream in file order; the table slot is the one random access per
       // amplicon, so the slots of the next few identifiers are requested ahead of their turn
       constexpr uint64_t kAhead = 8;
-      const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
+      const uint64_t lo = n64 * t / check_threads, hi = n64 * (t + 1) / check_threads;
       uint64_t ring[kAhead];
       auto slot_of = [&](uint64_t i) {
         const char * ids; uint32_t idl;
@@ -448,23 +455,23 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     if (dup_entry.load() != 0xFFFFFFFFu) {
       const char * ids; uint32_t idl;
       id_span(ent[dup_entry.load()], ids, idl);
-      db->error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
-      return SWA_E_ARG;
+      check_error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
+      check_rc = SWA_E_ARG;
+      return;
     }
   }
 
-  timer.lap("identifier uniqueness");
   // duplicated sequences are checked here only for d > 1 (db.cc:763-790); d = 1 finds
   // them while building the amplicon table (algod1.cc:1131-1150 / swa_d1_index_build)
   if (check_dup_seqs && n > 1) {
     const uint64_t tsize = 2ull * n;
     std::unique_ptr<std::atomic<uint32_t>[]> tab(new std::atomic<uint32_t>[tsize]);
-    run_parallel(threads, [&](unsigned t) {
-      for (uint64_t i = tsize * t / threads; i < tsize * (t + 1) / threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
+    run_parallel(check_threads, [&](unsigned t) {
+      for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
     });
     std::atomic<bool> dup{false};
-    run_parallel(threads, [&](unsigned t) {
-      for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads && !dup.load(std::memory_order_relaxed); ++i) {
+    run_parallel(check_threads, [&](unsigned t) {
+      for (uint64_t i = n64 * t / check_threads; i < n64 * (t + 1) / check_threads && !dup.load(std::memory_order_relaxed); ++i) {
         const RawEntry * e = ent[i];
         const uint64_t * w = words_of(e);
         const uint32_t nw = (e->seqlen + 31u) >> 5;
@@ -483,15 +490,24 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
       }
     });
     if (dup.load()) {
-      db->error = "\nError: some fasta entries have identical sequences.\n"
+      check_error = "\nError: some fasta entries have identical sequences.\n"
                   "Swarm expects dereplicated fasta files.\n"
                   "Such files can be produced with swarm or vsearch:\n"
                   " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
                   "or\n"
                   " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
-      return SWA_E_DUPLICATES;
+      check_rc = SWA_E_DUPLICATES;
+      return;
     }
   }
+
+  });
+  struct JoinChecker { std::thread & t; ~JoinChecker() { if (t.joinable()) { t.join(); } } } join_checker{checker};
+  auto checks_verdict = [&]() {
+    if (checker.joinable()) { checker.join(); }
+    if (check_rc != SWA_OK) { db->error = check_error; }
+    return check_rc;
+  };
 
   {                                                                                  // db.cc:369-385
     uint64_t missing = 0;
@@ -502,6 +518,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
       missing += pc.missing;
     }
     if (missing != 0) {
+      if (const int rc_checks = checks_verdict()) { return rc_checks; }     // (an identifier / sequence error comes first)
       db->error = "\nError: Abundance annotations not found for " + std::to_string(missing) +
                   " sequences, starting on line " + std::to_string(missing_line) + ".\n>" + missing_hdr + "\n" +
                   "Fasta headers must end with abundance annotations (_INT or ;size=INT).\n"
@@ -605,6 +622,8 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   });
   db->seqs[woff] = 0;
   timer.lap("gather into db order");
+  if (const int rc_checks = checks_verdict()) { return rc_checks; }
+  timer.lap("identifier / sequence checks (waited for)");
   // The parse buffers, the sort records and the input mapping (≈ 3 GB at 10 M amplicons) are NOT returned to the
   // kernel now: that takes as long as the sort, and done by a detached thread (as it was) it holds the process's
   // memory-map lock just when the caller starts allocating and copying on the GPU (measured: the first upload

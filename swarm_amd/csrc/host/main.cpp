@@ -16,7 +16,11 @@
 
 #include <getopt.h>
 #include <sys/resource.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+#include <cerrno>
+#include <csignal>
 
 #include <algorithm>
 #include <cinttypes>
@@ -221,6 +225,51 @@ void check_writer(int rc, const char * what) {
   if (rc != SWA_OK) { die(std::string("Unable to open ") + what + " file for writing."); }
 }
 
+// Process exit is not free here: after the last output file is closed the kernel still has ~5 GB of page tables and the
+// amdgpu / KFD side of the process to take apart, and on the same box that takes anything from 30 ms to 400 ms (measured,
+// 10 M amplicons; freeing host or device memory first changes nothing).  Nobody should wait for that: the program runs
+// as a WORKER child; the FRONT process — the one the caller started — returns as soon as the worker reports that every
+// output file is complete and closed, with the worker's status, and otherwise with whatever the worker ended with
+// (error exit, signal).  SWARM_AMD_FOREGROUND_EXIT=1: one process, as before.
+int g_done_fd = -1;
+pid_t g_worker = -1;
+
+void forward_signal(int sig) { if (g_worker > 0) { (void)kill(g_worker, sig); } }
+
+void front_and_worker() {
+  if (std::getenv("SWARM_AMD_FOREGROUND_EXIT") != nullptr) { return; }
+  int fds[2];
+  if (pipe(fds) != 0) { return; }
+  const pid_t pid = fork();                    // (no threads, no HIP runtime yet)
+  if (pid < 0) { close(fds[0]); close(fds[1]); return; }
+  if (pid == 0) { close(fds[0]); g_done_fd = fds[1]; return; }
+  g_worker = pid;
+  close(fds[1]);
+  for (int sig : {SIGINT, SIGTERM, SIGHUP, SIGQUIT}) { (void)std::signal(sig, forward_signal); }
+  unsigned char code = 0;
+  ssize_t got;
+  do { got = read(fds[0], &code, 1); } while (got < 0 && errno == EINTR);
+  if (got == 1) { _exit(code); }               // results complete: the worker finishes on its own
+  int status = 0;
+  while (waitpid(pid, &status, 0) < 0 && errno == EINTR) { }
+  if (WIFEXITED(status)) { _exit(WEXITSTATUS(status)); }
+  if (WIFSIGNALED(status)) { (void)std::signal(WTERMSIG(status), SIG_DFL); (void)raise(WTERMSIG(status)); }
+  _exit(EXIT_FAILURE);
+}
+
+// the worker's last act before it leaves the rest to the kernel: every output is flushed and closed
+void report_complete() {
+  if (g_done_fd < 0) { return; }
+  std::fflush(nullptr);
+  (void)close(STDOUT_FILENO);                  // (a caller reading our stdout / stderr through pipes gets its end-of-file
+  (void)close(STDERR_FILENO);                  //  from the front process, not from this one's slow end)
+  const unsigned char ok = EXIT_SUCCESS;
+  ssize_t put;
+  do { put = write(g_done_fd, &ok, 1); } while (put < 0 && errno == EINTR);
+  (void)close(g_done_fd);
+  g_done_fd = -1;
+}
+
 }  // namespace
 
 int main(int argc, char ** argv) {
@@ -233,6 +282,7 @@ int main(int argc, char ** argv) {
     setenv("SWARM_AMD_NO_REEXEC", "1", 1);
     execv("/proc/self/exe", argv);             // (falls through if it cannot)
   }
+  front_and_worker();
   stamp("start");
   Options o = parse(argc, argv);
   validate(o);
@@ -501,6 +551,12 @@ int main(int argc, char ** argv) {
   if (std::getenv("SWARM_AMD_FULL_TEARDOWN") == nullptr) {
     if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
     std::fflush(nullptr);
+    if (const char * mode = std::getenv("SWARM_AMD_EXIT_MODE")) {       // experiment: what the kernel is left with
+      const int m = std::atoi(mode);
+      if ((m & 1) != 0) { if (multi != nullptr) { swa_multi_destroy(multi); } else if (ctx != nullptr) { swa_ctx_destroy(ctx); } stamp("device released"); }
+      if ((m & 2) != 0) { swa_hostdb_free(db); stamp("host database released"); }
+    }
+    report_complete();
     std::_Exit(EXIT_SUCCESS);
   }
   if (multi != nullptr) { swa_multi_destroy(multi); }
