@@ -687,6 +687,109 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t * __re
   }
 }
 
+// ---- the same scan over the group sizes of an anchor index, making the work lists of the pair kernels on the way
+// (what a list kernel and k_needs_plain_kernel did in passes of their own over the 2 x 33 M table slots):
+// the tile pass also counts, per tile, the groups of every list; the sums pass turns those into the tile's first
+// place in each list (no atomics: list order is the table order, the same from run to run, up to the order inside a
+// tile); the apply pass writes the offsets and drops every group into its place.
+constexpr uint32_t kListKinds = kPairClasses + 2;           // size classes | 65..pair_big | 64-seed chunks of larger groups
+
+__device__ __forceinline__ uint32_t list_kind(uint32_t g, uint32_t pair_big) {      // kListKinds: none
+  if (g < 2u || g > kGroupCap) { return kListKinds; }
+  if (g <= kSmallGroup) { return pair_class(g); }
+  return g <= pair_big ? kPairClasses : kPairClasses + 1u;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles_lists(const uint32_t * __restrict__ counts, uint32_t n,
+                                                                 uint64_t * __restrict__ tile_sums, uint32_t * __restrict__ tile_kinds,
+                                                                 uint32_t tiles, uint32_t pair_big, uint32_t tiled_cap, uint32_t * flags) {
+  __shared__ uint64_t smem[4];
+  __shared__ uint32_t cnt[kListKinds];
+  if (threadIdx.x < kListKinds) { cnt[threadIdx.x] = 0u; }
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint64_t v = 0;
+  bool oversized = false, enumerated = false;
+  uint32_t mass = 0;
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) {
+      const uint32_t g = counts[base + i];
+      v += g;
+      const uint32_t kind = list_kind(g, pair_big);
+      if (kind < kListKinds) { atomicAdd(&cnt[kind], kind == kPairClasses + 1u ? (g + kSeedsPerItem - 1u) / kSeedsPerItem : 1u); }
+      if (g > kGroupCap) { oversized = true; mass += g; }
+      enumerated |= g > tiled_cap;
+    }
+  }
+  uint64_t total;
+  (void)block_exclusive_scan(v, smem, total);                // (its barriers also cover cnt[])
+  if (threadIdx.x == 0) { tile_sums[blockIdx.x] = total; }
+  if (threadIdx.x < kListKinds) { tile_kinds[threadIdx.x * tiles + blockIdx.x] = cnt[threadIdx.x]; }
+  // [4] oversized group [5] members of oversized groups [7] a group for the enumerating kernels (k_needs_plain_kernel's flags)
+  if (oversized) { atomicOr(flags + 4, 1u); atomicAdd(flags + 5, mass); }
+  if (enumerated) { flags[7] = 1u; }
+}
+
+// block 0: the tile sums; block 1 + k: the tiles' counts of list k -> first place of each tile in the list, the list's length
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums_lists(uint64_t * tile_sums, uint32_t * tile_kinds, uint32_t tiles,
+                                                                uint32_t * list_counters, uint32_t * chunk_counter) {
+  __shared__ uint64_t smem[4];
+  uint64_t carry = 0;
+  const uint32_t kind = blockIdx.x - 1u;
+  for (uint32_t base = 0; base < tiles; base += kScanBlock) {
+    const uint32_t i = base + threadIdx.x;
+    uint64_t v = 0;
+    if (i < tiles) { v = blockIdx.x == 0 ? tile_sums[i] : tile_kinds[kind * tiles + i]; }
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan(v, smem, total);
+    if (i < tiles) {
+      if (blockIdx.x == 0) { tile_sums[i] = carry + ex; } else { tile_kinds[kind * tiles + i] = (uint32_t)(carry + ex); }
+    }
+    carry += total;
+  }
+  if (blockIdx.x != 0 && threadIdx.x == 0) {
+    if (kind <= kPairClasses) { list_counters[kind] = (uint32_t)carry; } else { *chunk_counter = (uint32_t)carry; }
+  }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply_lists(const uint32_t * __restrict__ counts, uint32_t n,
+                                                                 const uint64_t * __restrict__ tile_sums,
+                                                                 const uint32_t * __restrict__ tile_kinds, uint32_t tiles,
+                                                                 uint64_t * __restrict__ offsets, const PairLists l) {
+  __shared__ uint64_t smem[4];
+  __shared__ uint32_t cnt[kListKinds];
+  if (threadIdx.x < kListKinds) { cnt[threadIdx.x] = tile_kinds[threadIdx.x * tiles + blockIdx.x]; }
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  uint32_t c[kScanItems];
+  uint64_t v = 0;
+  for (int i = 0; i < kScanItems; ++i) {
+    c[i] = (base + i < n) ? counts[base + i] : 0u;
+    v += c[i];
+  }
+  uint64_t total;
+  uint64_t run = tile_sums[blockIdx.x] + block_exclusive_scan(v, smem, total);     // (barriers: cnt[] is set)
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) {
+      offsets[base + i] = run;
+      const uint32_t g = c[i];
+      const uint32_t kind = list_kind(g, l.pair_big);
+      if (kind < kListKinds) {
+        swa_item it;
+        it.begin = (uint32_t)run; it.size = g; it.chunk = 0;
+        if (kind <= kPairClasses) {
+          l.items[l.region[kind] + atomicAdd(&cnt[kind], 1u)] = it;
+        } else {
+          const uint32_t chunks = (g + kSeedsPerItem - 1u) / kSeedsPerItem;
+          const uint32_t at = atomicAdd(&cnt[kind], chunks);
+          for (uint32_t k = 0; k < chunks; ++k) { it.chunk = k; l.chunk_items[at + k] = it; }
+        }
+      }
+    }
+    run += c[i];
+    if (base + i + 1 == n) { offsets[n] = run; }
+  }
+}
+
 // total and largest fill of the per-wave edge segments -> out[0], out[1]
 __global__ __launch_bounds__(256) void k_seg_reduce(const uint32_t * __restrict__ seg_fill, uint32_t nseg,
                                                     unsigned long long * out) {
@@ -862,7 +965,7 @@ static bool anchor_applicable(const swa_ctx * ctx) {
 
 // work items of an index.  d_aitems: 64-seed chunks of the groups served by the enumerating / tiled kernels (fewer
 // than n / 32) at the start, from small_items_at on EITHER the small-group items of k_anchor_items (at most n / 2 +
-// n / kSmallChunkPrefix) OR the lists of k_anchor_items_classes (pair_region: groups of a class have at least
+// n / kSmallChunkPrefix) OR the lists of k_scan_apply_lists (pair_region: groups of a class have at least
 // 2, 5, 9, 17, 33 and 65 members, which bounds each list); sized for both
 static uint64_t small_items_at(uint32_t n) { return uint64_t(n) / 8 + 32; }
 static uint64_t pair_region(uint32_t c, uint32_t n) {
@@ -888,23 +991,6 @@ static int pairs_width_for(const swa_ctx * ctx) {
 static uint32_t pair_big_limit() {
   const char * env = getenv("SWA_D1_PAIR_BIG");
   return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env))) : kPairBigCap;
-}
-
-// the work lists of the pair kernels and of the duplicate check (k_anchor_items_classes), made with the index
-static void launch_pair_lists(swa_ctx * ctx) {
-  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
-  for (int which = 0; which < 2; ++which) {
-    PairLists l{};
-    l.items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
-    for (uint32_t c = 0; c <= kPairClasses; ++c) { l.region[c] = pair_region(c, ctx->db.n); }
-    l.counters = acounters + 32 + 8 * which;
-    l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
-    l.chunk_counter = acounters + which;
-    l.pair_big = pair_big_limit();
-    hipLaunchKernelGGL(k_anchor_items_classes, dim3(grid_for(ctx, ctx->anchor_slots, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
-                       static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), ctx->anchor_slots, l);
-  }
 }
 
 // (re)builds the two anchor indexes for the query range [first, first + count)
@@ -935,7 +1021,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   SWA_TRY(swa_reserve(ctx, ctx->d_afp[1], uint64_t(n) * sizeof(uint64_t)));      // prefix index, group order
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
   const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
-  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * (sizeof(uint64_t) + kListKinds * sizeof(uint32_t))));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
   SWA_HIP(ctx, hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), ctx->stream));
@@ -967,16 +1053,34 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   }
   // (a table that turned out too small — flags[2] — still leaves a consistent index of the amplicons placed before
   // that: what follows runs on it harmlessly until the host looks at the flag, at the next point where it waits anyway)
+  ctx->pair_lists = pairs_width_for(ctx) != 0;
+  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   for (int which = 0; which < 2; ++which) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize,
-                       static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize,
-                       static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), static_cast<uint64_t *>(ctx->d_aoffsets[which].ptr));
+    auto * tsums = static_cast<uint64_t *>(ctx->d_scan_tmp.ptr);
+    auto * offs = static_cast<uint64_t *>(ctx->d_aoffsets[which].ptr);
+    if (ctx->pair_lists) {
+      // offsets and the work lists of the pair kernels / the duplicate check in the same three launches
+      auto * tkinds = reinterpret_cast<uint32_t *>(tsums + tiles);
+      PairLists l{};
+      l.items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
+      for (uint32_t c = 0; c <= kPairClasses; ++c) { l.region[c] = pair_region(c, n); }
+      l.counters = acounters + 32 + 8 * which;
+      l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
+      l.chunk_counter = acounters + which;
+      l.pair_big = pair_big_limit();
+      hipLaunchKernelGGL(k_scan_tiles_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums,
+                         tkinds, tiles, l.pair_big, kPairTiledCap, dflags);
+      hipLaunchKernelGGL(k_scan_sums_lists, dim3(1 + kListKinds), dim3(kScanBlock), 0, ctx->stream, tsums, tkinds, tiles, l.counters,
+                         l.chunk_counter);
+      hipLaunchKernelGGL(k_scan_apply_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums,
+                         tkinds, tiles, offs, l);
+      continue;
+    }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, tsums, tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums, offs);
   }
   hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, sc);
-  ctx->pair_lists = pairs_width_for(ctx) != 0;
-  if (ctx->pair_lists) { launch_pair_lists(ctx); }
   SWA_HIP(ctx, hipGetLastError());
   ctx->anchor_first = first;
   ctx->anchor_count = count;
@@ -988,7 +1092,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 // the plain kernel; edges / counts / edge counter as launch_network leaves them
 static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count) {
   // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items [16..32) work counters
-  // [32 + 8 pass + c] lists of k_anchor_items_classes
+  // [32 + 8 pass + c] lists of k_scan_apply_lists
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
@@ -1244,9 +1348,11 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   swa_t1(ctx, 7);
   const uint64_t asize = ctx->anchor_slots;
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
-  hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                     static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
-                     asize, dflags, pairs_width_for(ctx) != 0 ? kPairTiledCap : 0u);
+  if (!ctx->pair_lists) {                                   // (with pair lists the scan over the group sizes has set these flags)
+    hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
+                       asize, dflags, 0u);
+  }
   // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
   swa_t0(ctx, 2);
   if (!ctx->pair_lists) {
