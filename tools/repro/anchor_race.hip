@@ -187,7 +187,7 @@ int main(int argc, char ** argv) {
       {
         AnchorBuildArgs b{};
         AnchorScatterArgs sc{};
-        b.seqs = d_seqs; b.seq_off = d_seq_off; b.seqlen = d_seqlen; b.n = n; b.first = 0; b.count = n; b.amask = asize - 1;
+        b.seqs = d_seqs; b.seq_off = d_seq_off; b.seqlen = d_seqlen; b.n = n; b.first = 0; b.count = n; b.amask = asize - 1; b.probe_limit = asize - 1;
         b.fingerprint = a.fp[0]; b.owner_rank = 0; b.owner_world = 1; b.flags = d_flags; b.minlen = kMinAnchoredLen;
         for (int which = 0; which < 2; ++which) {
           b.keys[which] = a.keys[which]; b.counts[which] = a.counts[which]; b.slot_of[which] = a.slot_of[which]; b.pos_of[which] = a.pos_of[which];
