@@ -27,5 +27,5 @@ done
 # keep the merged directory small: drop everything but the CSV summaries and logs
 find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 ls -la "$OUT"
-python $REPO/tools/summarize_pmc.py "$OUT" $((STEPS+1)) "${3:-10000000x150_s1}" "$OUT/d1_network_pmc.json"
+python $REPO/tools/summarize_pmc.py "$OUT" $((STEPS+1)) "${3:-10000000x150_s1}" "$OUT/d1_step_pmc.json"
 head -8 "$OUT/kernel_stats.csv"
