@@ -58,6 +58,12 @@ struct Piece {            // what one thread parsed
   std::string error;      // first error of the piece (line numbers still local)
   uint32_t error_line = 0;
   int error_kind = 0;     // 0 none, 1 message carries a \x01 where the absolute line number goes, 2 final
+  // second-phase errors (abundance value, empty identifier): the reference finds them only after it has read the whole
+  // file (db.cc:676-694), so an illegal character anywhere comes first; the first one of the piece is kept
+  std::string late_error;
+  uint32_t late_line = 0;
+  int late_kind = 0;      // as error_kind
+  uint64_t late_entry = 0;   // index of the entry inside the piece
   uint64_t missing = 0;   // entries without abundance annotation
   uint32_t missing_line = 0;
   std::string missing_hdr;
@@ -258,11 +264,15 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
     int32_t s = 0, t = 0;
     int64_t number = 0, abundance = 0;
     const bool found = usearch ? usearch_abundance(hdr, hlen, s, t, number) : swarm_abundance(hdr, hlen, s, t, number);
+    auto fail_late = [&](const std::string & msg, int kind) {
+      if (out.late_kind == 0) { out.late_error = msg; out.late_line = e.lineno; out.late_kind = kind; out.late_entry = out.entries.size(); }
+    };
+    bool entry_failed = false;
     if (found) {
       if (number <= 0) {
-        fail(std::string("\nError: Illegal abundance value on line \x01:\n") + hdr + "\nAbundance values should be positive integers.\n",
-             e.lineno, 1);
-        break;
+        fail_late(std::string("\nError: Illegal abundance value on line \x01:\n") + hdr + "\nAbundance values should be positive integers.\n", 1);
+        entry_failed = true;
+        number = 1;                              // (reading goes on: a first-phase error further down outranks this one)
       }
       abundance = number;
     }
@@ -275,10 +285,7 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
     e.abundance = (uint64_t)abundance;
     e.ab_start = s;
     e.ab_end = t;
-    if (e.ab_start == 0 && e.ab_end == (int32_t)hlen) {
-      fail("\nError: Empty sequence identifier.\n", e.lineno, 2);
-      break;
-    }
+    if (!entry_failed && e.ab_start == 0 && e.ab_end == (int32_t)hlen) { fail_late("\nError: Empty sequence identifier.\n", 2); }
     out.entries.push_back(e);
   }
   out.lines = lineno - 1;
@@ -377,6 +384,22 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   // ---- global view of the entries
   std::vector<uint64_t> piece_first(threads + 1, 0);
   for (unsigned t = 0; t < threads; ++t) { piece_first[t + 1] = piece_first[t] + pieces[t].entries.size(); }
+  // the first second-phase error in file order (abundance value / empty identifier), as entry index + text
+  uint64_t late_at = ~0ull;
+  std::string late_error;
+  {
+    uint64_t lines = 0;
+    for (unsigned t = 0; t < threads && late_at == ~0ull; ++t) {
+      const Piece & pc = pieces[t];
+      if (pc.late_kind != 0) {
+        late_at = piece_first[t] + pc.late_entry;
+        late_error = pc.late_error;
+        const size_t at = late_error.find('\x01');
+        if (pc.late_kind == 1 && at != std::string::npos) { late_error.replace(at, 1, std::to_string(pc.late_line + lines)); }
+      }
+      lines += pc.lines;
+    }
+  }
   const uint64_t n64 = piece_first[threads];
   if (n64 > 0xFFFFFFFEull) { db->error = "\nError: too many sequences.\n"; return SWA_E_ARG; }
   const uint32_t n = (uint32_t)n64;
@@ -398,8 +421,8 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   // The two table-based checks below only read the parsed entries and produce an error or nothing: they run on their
   // own threads next to the sort and the gather (at 10 M amplicons 50-100 ms that used to sit on the critical path);
   // their verdict is taken where the sequential order of the checks puts it.
-  std::string check_error;
-  int check_rc = SWA_OK;
+  std::string dup_id_error, dup_seq_error;
+  uint64_t dup_id_at = ~0ull, dup_seq_at = ~0ull;           // entry indices (the later entry of the earliest repetition)
   const unsigned check_threads = std::max(1u, threads / 2);     // (the sort next to them is the critical path)
   std::thread checker([&]() {
   // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
@@ -455,9 +478,8 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     if (dup_entry.load() != 0xFFFFFFFFu) {
       const char * ids; uint32_t idl;
       id_span(ent[dup_entry.load()], ids, idl);
-      check_error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
-      check_rc = SWA_E_ARG;
-      return;
+      dup_id_error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
+      dup_id_at = dup_entry.load();
     }
   }
 
@@ -469,9 +491,9 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     run_parallel(check_threads, [&](unsigned t) {
       for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
     });
-    std::atomic<bool> dup{false};
+    std::atomic<uint32_t> dup{0xFFFFFFFFu};                  // the earliest entry that repeats an earlier one's sequence
     run_parallel(check_threads, [&](unsigned t) {
-      for (uint64_t i = n64 * t / check_threads; i < n64 * (t + 1) / check_threads && !dup.load(std::memory_order_relaxed); ++i) {
+      for (uint64_t i = n64 * t / check_threads; i < n64 * (t + 1) / check_threads; ++i) {
         const RawEntry * e = ent[i];
         const uint64_t * w = words_of(e);
         const uint32_t nw = (e->seqlen + 31u) >> 5;
@@ -484,31 +506,44 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
             if (tab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
           }
           const RawEntry * o = ent[cur];
-          if (o->seqlen == e->seqlen && std::memcmp(words_of(o), w, nw * 8ull) == 0) { dup.store(true); break; }
+          if (o->seqlen == e->seqlen && std::memcmp(words_of(o), w, nw * 8ull) == 0) {
+            const uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
+            uint32_t seen = dup.load();
+            while (later < seen && !dup.compare_exchange_weak(seen, later)) { }
+            break;
+          }
           slot = (slot + 1) % tsize;
         }
       }
     });
-    if (dup.load()) {
-      check_error = "\nError: some fasta entries have identical sequences.\n"
+    if (dup.load() != 0xFFFFFFFFu) {
+      dup_seq_at = dup.load();
+      dup_seq_error = "\nError: some fasta entries have identical sequences.\n"
                   "Swarm expects dereplicated fasta files.\n"
                   "Such files can be produced with swarm or vsearch:\n"
                   " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
                   "or\n"
                   " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
-      check_rc = SWA_E_DUPLICATES;
-      return;
     }
   }
 
   });
   struct JoinChecker { std::thread & t; ~JoinChecker() { if (t.joinable()) { t.join(); } } } join_checker{checker};
+  // The reference walks the entries once (db.cc:676-795): abundance value, empty identifier, repeated identifier are
+  // fatal at the entry where they occur, a repeated sequence (d > 1) ends the walk there and is reported after it.
+  // Hence: the earliest entry with any of them decides; at the same entry in that order.
   auto checks_verdict = [&]() {
     if (checker.joinable()) { checker.join(); }
-    if (check_rc != SWA_OK) { db->error = check_error; }
-    return check_rc;
+    if (late_at != ~0ull && late_at <= dup_id_at && late_at <= dup_seq_at) { db->error = late_error; return (int)SWA_E_ARG; }
+    if (dup_id_at != ~0ull && dup_id_at <= dup_seq_at) { db->error = dup_id_error; return (int)SWA_E_ARG; }
+    if (dup_seq_at != ~0ull) { db->error = dup_seq_error; return (int)SWA_E_DUPLICATES; }
+    return (int)SWA_OK;
   };
 
+  if (late_at != ~0ull) {                                   // (no point in sorting: some error will be reported)
+    const int rc_checks = checks_verdict();
+    return rc_checks;
+  }
   {                                                                                  // db.cc:369-385
     uint64_t missing = 0;
     uint32_t missing_line = 0;

@@ -281,3 +281,29 @@ def test_order_free_clustering_equals_the_walk_on_random_graphs(tmp_path, seed, 
     off = np.cumsum(off).astype(np.uint64)
     nb = pairs[:, 1].astype(np.uint32)
     _cluster_both_ways(hdb, off, nb, tmp_path)
+
+
+@pytest.mark.skipif(not S.have_reference(), reason="compiled reference not available")
+@pytest.mark.parametrize("text,d", [
+    (">a_0\nACGT\n>b_1\nAC\nGN\n", 1),                       # illegal abundance on line 1, illegal character on line 5: the read comes first
+    (">_3\nACGT\n>b_1\nACXT\n", 1),                          # empty identifier, then an illegal character
+    (">a_1\nACGT\n>a_2\nACGA\n>c_0\nACGG\n", 1),             # repeated identifier (entry 2) before an illegal abundance (entry 3)
+    (">a_1\nACGT\n>c_0\nACGG\n>a_2\nACGA\n", 1),             # the other way round
+    (">a_1\nACGT\n>b_1\nACGT\n>c_0\nACGG\n", 2),             # d = 2: repeated sequence at entry 2 ends the walk before entry 3
+    (">a_1\nACGT\n>c_0\nACGG\n>b_1\nACGT\n", 2),             # illegal abundance at entry 2 comes before the repeated sequence
+    (">a_1\nACGT\n>a_1\nACGT\n", 2),                          # same entry: identifier before sequence
+    (">a\nACGT\n>b_0\nACGA\n", 1),                            # missing annotation (reported after the walk) vs illegal value (during it)
+    (">a\nACGT\n>b_1\nACGA\n>b_2\nACGG\n", 1),                # missing annotation vs repeated identifier
+])
+def test_hostdb_errors_in_the_reference_order(tmp_path, text, d):
+    """Inputs with more than one defect: the message is the one the reference gives (it reads the whole file first,
+    then walks the entries once)."""
+    fa = tmp_path / "bad.fa"
+    fa.write_text(text)
+    r = S.run_ref_swarm(["-d", d, "-o", "/dev/null", "-l", "/dev/null", fa])
+    assert r.returncode != 0
+    want = [ln for ln in r.stderr.splitlines() if ln.startswith("Error:")]
+    assert want, r.stderr
+    with pytest.raises(SwaError) as e:
+        HostDb(fa, check_duplicate_sequences=d > 1)
+    assert want[0].strip() in str(e.value), (want[0], str(e.value))
