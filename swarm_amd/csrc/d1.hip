@@ -643,12 +643,14 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t * 
   return wave_off + incl - v;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const uint32_t * __restrict__ counts, uint32_t n,
+// (T = uint32_t: plain counts; T = unsigned long long: the slots of an anchor table, whose low halves are the group sizes)
+template <class T>
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const T * __restrict__ counts, uint32_t n,
                                                            uint64_t * __restrict__ tile_sums) {
   __shared__ uint64_t smem[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   uint64_t v = 0;
-  for (int i = 0; i < kScanItems; ++i) { if (base + i < n) { v += counts[base + i]; } }
+  for (int i = 0; i < kScanItems; ++i) { if (base + i < n) { v += (uint32_t)counts[base + i]; } }
   uint64_t total;
   (void)block_exclusive_scan(v, smem, total);
   if (threadIdx.x == 0) { tile_sums[blockIdx.x] = total; }
@@ -667,7 +669,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_sums(uint64_t * tile_sums, 
   }
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t * __restrict__ counts, uint32_t n,
+template <class T>
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const T * __restrict__ counts, uint32_t n,
                                                            const uint64_t * __restrict__ tile_sums,
                                                            uint64_t * __restrict__ offsets) {
   __shared__ uint64_t smem[4];
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t * __re
   uint32_t c[kScanItems];
   uint64_t v = 0;
   for (int i = 0; i < kScanItems; ++i) {
-    c[i] = (base + i < n) ? counts[base + i] : 0u;
+    c[i] = (base + i < n) ? (uint32_t)counts[base + i] : 0u;
     v += c[i];
   }
   uint64_t total;
@@ -700,7 +703,7 @@ __device__ __forceinline__ uint32_t list_kind(uint32_t g, uint32_t pair_big) {  
   return g <= pair_big ? kPairClasses : kPairClasses + 1u;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_tiles_lists(const uint32_t * __restrict__ counts, uint32_t n,
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles_lists(const unsigned long long * __restrict__ counts, uint32_t n,
                                                                  uint64_t * __restrict__ tile_sums, uint32_t * __restrict__ tile_kinds,
                                                                  uint32_t tiles, uint32_t pair_big, uint32_t tiled_cap, uint32_t * flags) {
   __shared__ uint64_t smem[4];
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tiles_lists(const uint32_t 
   uint32_t mass = 0;
   for (int i = 0; i < kScanItems; ++i) {
     if (base + i < n) {
-      const uint32_t g = counts[base + i];
+      const uint32_t g = (uint32_t)counts[base + i];
       v += g;
       const uint32_t kind = list_kind(g, pair_big);
       if (kind < kListKinds) { atomicAdd(&cnt[kind], kind == kPairClasses + 1u ? (g + kSeedsPerItem - 1u) / kSeedsPerItem : 1u); }
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_sums_lists(uint64_t * tile_
   }
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply_lists(const uint32_t * __restrict__ counts, uint32_t n,
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply_lists(const unsigned long long * __restrict__ counts, uint32_t n,
                                                                  const uint64_t * __restrict__ tile_sums,
                                                                  const uint32_t * __restrict__ tile_kinds, uint32_t tiles,
                                                                  uint64_t * __restrict__ offsets, const PairLists l) {
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply_lists(const uint32_t 
   uint32_t c[kScanItems];
   uint64_t v = 0;
   for (int i = 0; i < kScanItems; ++i) {
-    c[i] = (base + i < n) ? counts[base + i] : 0u;
+    c[i] = (base + i < n) ? (uint32_t)counts[base + i] : 0u;
     v += c[i];
   }
   uint64_t total;
@@ -1009,8 +1012,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   while (asize < 2ull * share) { asize <<= 1; }
   ctx->anchor_slots = asize;
   for (int which = 0; which < 2; ++which) {
-    SWA_TRY(swa_reserve(ctx, ctx->d_akeys[which], asize * sizeof(uint64_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_acounts[which], asize * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_acounts[which], asize * sizeof(uint64_t)));      // slots: tag | group size
     SWA_TRY(swa_reserve(ctx, ctx->d_aoffsets[which], (asize + 1) * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_aslot[which], uint64_t(n) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_apos[which], uint64_t(n) * sizeof(uint32_t)));
@@ -1035,8 +1037,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   b.minlen = ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen;
   b.window_mode = (ctx->anchor_a != 0 || ctx->anchor_b != 0) ? 1u : 0u;
   for (int which = 0; which < 2; ++which) {
-    b.keys[which] = static_cast<unsigned long long *>(ctx->d_akeys[which].ptr);
-    b.counts[which] = static_cast<uint32_t *>(ctx->d_acounts[which].ptr);
+    b.slots[which] = static_cast<unsigned long long *>(ctx->d_acounts[which].ptr);
     b.slot_of[which] = static_cast<uint32_t *>(ctx->d_aslot[which].ptr);
     b.pos_of[which] = static_cast<uint32_t *>(ctx->d_apos[which].ptr);
     sc.slot_of[which] = b.slot_of[which]; sc.pos_of[which] = b.pos_of[which];
@@ -1045,8 +1046,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   }
   sc.fingerprint = b.fingerprint; sc.member_fingerprint = static_cast<uint64_t *>(ctx->d_afp[1].ptr);
   sc.seqlen = ctx->db.seqlen; sc.rank = static_cast<const uint32_t *>(ctx->d_arank.ptr); sc.seq_off = ctx->db.seq_off; sc.n = n;
-  hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, b.keys[0], b.counts[0],
-                     b.keys[1], b.counts[1], asize);
+  hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, b.slots[0], b.slots[1], asize);
   hipLaunchKernelGGL(k_anchor_place<true>, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
   if (count < n) {
     hipLaunchKernelGGL(k_anchor_place<false>, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
@@ -1068,17 +1068,17 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
       l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
       l.chunk_counter = acounters + which;
       l.pair_big = pair_big_limit();
-      hipLaunchKernelGGL(k_scan_tiles_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums,
+      hipLaunchKernelGGL(k_scan_tiles_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums,
                          tkinds, tiles, l.pair_big, kPairTiledCap, dflags);
       hipLaunchKernelGGL(k_scan_sums_lists, dim3(1 + kListKinds), dim3(kScanBlock), 0, ctx->stream, tsums, tkinds, tiles, l.counters,
                          l.chunk_counter);
-      hipLaunchKernelGGL(k_scan_apply_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums,
+      hipLaunchKernelGGL(k_scan_apply_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums,
                          tkinds, tiles, offs, l);
       continue;
     }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums);
+    hipLaunchKernelGGL((k_scan_tiles<unsigned long long>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, tsums, tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.counts[which], (uint32_t)asize, tsums, offs);
+    hipLaunchKernelGGL((k_scan_apply<unsigned long long>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums, offs);
   }
   hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, sc);
   SWA_HIP(ctx, hipGetLastError());
@@ -1117,7 +1117,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
                          !(env_tiled != nullptr && env_tiled[0] == '0' && aux_ready && !window_mode);
   for (int which = 0; which < 2 && pairs_width == 0; ++which) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint32_t *>(ctx->d_acounts[which].ptr),
+                       static_cast<const unsigned long long *>(ctx->d_acounts[which].ptr),
                        static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr), acounters + which,
                        static_cast<swa_item *>(ctx->d_aitems[which].ptr) + small_items_at(ctx->db.n), acounters + 3 + which,
@@ -1183,8 +1183,8 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   // too short, no oversized group — and what holds for the whole database holds for every part of it)
   if (ctx->full_index)
   hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
-                     count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[0].ptr),
-                     static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
+                     count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr),
+                     static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
                      static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world,
                      ctx->db.seqs, ctx->db.seq_off, ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen, window_mode ? 1u : 0u);
   NetArgs f{};
@@ -1350,14 +1350,14 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   if (!ctx->pair_lists) {                                   // (with pair lists the scan over the group sizes has set these flags)
     hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint32_t *>(ctx->d_acounts[1].ptr),
+                       static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
                        asize, dflags, 0u);
   }
   // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
   swa_t0(ctx, 2);
   if (!ctx->pair_lists) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint32_t *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
+                       static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
                        asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
                        static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
   }
@@ -1642,10 +1642,10 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
                          static_cast<const uint64_t *>(ctx->d_edges.ptr), static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
                          nseg, ctx->seg_cap, static_cast<const unsigned long long *>(ctx->d_seg_base.ptr), d_edge_list, cap);
     } else {
-      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((k_scan_tiles<uint32_t>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
                          static_cast<const uint32_t *>(ctx->d_counts.ptr), count, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
-      hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((k_scan_apply<uint32_t>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
                          static_cast<const uint32_t *>(ctx->d_counts.ptr), count,
                          static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), d_offsets);
       if (d_neighbours != nullptr && cap > 0) {
@@ -1942,9 +1942,9 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
       else if (type == 1) { hipLaunchKernelGGL(k_fg_light<1>, gn, b, 0, ctx->stream, g); hipLaunchKernelGGL(k_fg_heavy<1>, gn, b, 0, ctx->stream, g); }
       else { hipLaunchKernelGGL(k_fg_light<2>, gn, b, 0, ctx->stream, g); hipLaunchKernelGGL(k_fg_heavy<2>, gn, b, 0, ctx->stream, g); }
       hipLaunchKernelGGL(k_fg_totals, ga, b, 0, ctx->stream, cnt_l, cnt_h, asize, tot);
-      hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, tot, (uint32_t)asize, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
+      hipLaunchKernelGGL((k_scan_tiles<uint32_t>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream, tot, (uint32_t)asize, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr), tiles);
-      hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, tot, (uint32_t)asize,
+      hipLaunchKernelGGL((k_scan_apply<uint32_t>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream, tot, (uint32_t)asize,
                          static_cast<const uint64_t *>(ctx->d_scan_tmp.ptr), offsets);
       if (type == 0) { hipLaunchKernelGGL(k_fg_scatter<0>, gn, b, 0, ctx->stream, g, offsets, cur_l, cur_h, members); }
       else if (type == 1) { hipLaunchKernelGGL(k_fg_scatter<1>, gn, b, 0, ctx->stream, g, offsets, cur_l, cur_h, members); }

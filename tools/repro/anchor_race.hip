@@ -37,6 +37,9 @@ uint64_t h_anchor_key(const uint64_t * seq, uint32_t len, int which) {
   return h_mix64(v ^ (which ? 0x9E3779B97F4A7C15ull : 0ull)) & 0x7FFFFFFFFFFFFFFFull;
 }
 
+// what a table slot keeps of a key: the high 32 bits of its mix (the low bits choose the slot)
+uint64_t h_anchor_tag(const uint64_t * seq, uint32_t len, int which) { return h_mix64(h_anchor_key(seq, len, which)) >> 32; }
+
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #expr, hipGetErrorString(e_)); exit(2); } } while (0)
 
 struct Db {
@@ -83,7 +86,7 @@ void make_db(Db & db, uint32_t n) {
 }
 
 struct Anchor {
-  unsigned long long * keys[2] = {};
+  unsigned long long * slots[2] = {};
   uint32_t * counts[2] = {}, * pos_of[2] = {}, * slot_of[2] = {}, * members[2] = {};
   uint4 * minfo[2] = {};
   uint64_t * fp[2] = {};
@@ -95,7 +98,7 @@ struct Anchor {
 
 void alloc_anchor(Anchor & a, uint32_t n, uint64_t asize, uint32_t tiles) {
   for (int w = 0; w < 2; ++w) {
-    CK(hipMalloc(&a.keys[w], asize * 8)); CK(hipMalloc(&a.counts[w], asize * 4)); CK(hipMalloc(&a.pos_of[w], (uint64_t)n * 4));
+    CK(hipMalloc(&a.slots[w], asize * 8)); CK(hipMalloc(&a.pos_of[w], (uint64_t)n * 4));
     CK(hipMalloc(&a.minfo[w], (uint64_t)n * 16)); CK(hipMalloc(&a.fp[w], (uint64_t)n * 8));
     CK(hipMalloc(&a.offsets[w], (asize + 1) * 8)); CK(hipMalloc(&a.slot_of[w], (uint64_t)n * 4));
     CK(hipMalloc(&a.members[w], (uint64_t)n * 4)); CK(hipMalloc(&a.items[w], ((uint64_t)n + 128) * sizeof(swa_item)));
@@ -106,7 +109,7 @@ void alloc_anchor(Anchor & a, uint32_t n, uint64_t asize, uint32_t tiles) {
 
 void free_anchor(Anchor & a) {
   for (int w = 0; w < 2; ++w) {
-    CK(hipFree(a.keys[w])); CK(hipFree(a.counts[w])); CK(hipFree(a.pos_of[w])); CK(hipFree(a.minfo[w])); CK(hipFree(a.fp[w])); CK(hipFree(a.offsets[w]));
+    CK(hipFree(a.slots[w])); CK(hipFree(a.pos_of[w])); CK(hipFree(a.minfo[w])); CK(hipFree(a.fp[w])); CK(hipFree(a.offsets[w]));
     CK(hipFree(a.slot_of[w])); CK(hipFree(a.members[w])); CK(hipFree(a.items[w]));
   }
   CK(hipFree(a.acounters)); CK(hipFree(a.scan_tmp));
@@ -155,7 +158,7 @@ int main(int argc, char ** argv) {
   std::vector<uint64_t> want[2];
   for (int w = 0; w < 2; ++w) {
     want[w].resize(n);
-    for (uint32_t i = 0; i < n; ++i) { want[w][i] = h_anchor_key(db.seqs.data() + db.seq_off[i], db.seqlen[i], w); }
+    for (uint32_t i = 0; i < n; ++i) { want[w][i] = h_anchor_tag(db.seqs.data() + db.seq_off[i], db.seqlen[i], w); }
   }
   printf("device: %s, %d CUs; n = %u, longest %u, anchor slots %llu\n", prop.name, cus, n, db.longest, (unsigned long long)asize);
 
@@ -190,21 +193,21 @@ int main(int argc, char ** argv) {
         b.seqs = d_seqs; b.seq_off = d_seq_off; b.seqlen = d_seqlen; b.n = n; b.first = 0; b.count = n; b.amask = asize - 1; b.probe_limit = asize - 1;
         b.fingerprint = a.fp[0]; b.owner_rank = 0; b.owner_world = 1; b.flags = d_flags; b.minlen = kMinAnchoredLen;
         for (int which = 0; which < 2; ++which) {
-          b.keys[which] = a.keys[which]; b.counts[which] = a.counts[which]; b.slot_of[which] = a.slot_of[which]; b.pos_of[which] = a.pos_of[which];
+          b.slots[which] = a.slots[which]; b.slot_of[which] = a.slot_of[which]; b.pos_of[which] = a.pos_of[which];
           sc.slot_of[which] = a.slot_of[which]; sc.pos_of[which] = a.pos_of[which]; sc.offsets[which] = a.offsets[which];
           sc.minfo[which] = a.minfo[which];
         }
         sc.fingerprint = a.fp[0]; sc.member_fingerprint = a.fp[1]; sc.seqlen = d_seqlen; sc.rank = d_rank; sc.seq_off = d_seq_off; sc.n = n;
-        k_anchor_clear<<<grid(asize), 256, 0, stream>>>(a.keys[0], a.counts[0], a.keys[1], a.counts[1], asize);
+        k_anchor_clear<<<grid(asize), 256, 0, stream>>>(a.slots[0], a.slots[1], asize);
         k_anchor_place<true><<<grid(n), 256, 0, stream>>>(b);
         for (int which = 0; which < 2; ++which) {
-          k_scan_tiles<<<tiles, kScanBlock, 0, stream>>>(a.counts[which], (uint32_t)asize, a.scan_tmp);
+          k_scan_tiles<unsigned long long><<<tiles, kScanBlock, 0, stream>>>(a.slots[which], (uint32_t)asize, a.scan_tmp);
           k_scan_sums<<<1, kScanBlock, 0, stream>>>(a.scan_tmp, tiles);
-          k_scan_apply<<<tiles, kScanBlock, 0, stream>>>(a.counts[which], (uint32_t)asize, a.scan_tmp, a.offsets[which]);
+          k_scan_apply<unsigned long long><<<tiles, kScanBlock, 0, stream>>>(a.slots[which], (uint32_t)asize, a.scan_tmp, a.offsets[which]);
         }
         k_anchor_scatter<<<grid(n), 256, 0, stream>>>(sc);
         for (int which = 0; which < 2; ++which) {
-          k_anchor_items<<<grid(asize), 256, 0, stream>>>(a.counts[which], a.offsets[which], asize, a.items[which], a.acounters + which,
+          k_anchor_items<<<grid(asize), 256, 0, stream>>>(a.slots[which], a.offsets[which], asize, a.items[which], a.acounters + which,
                                                          a.items[which] + (n / 2 + 64), a.acounters + 3 + which, 64u);
         }
       }
@@ -212,12 +215,12 @@ int main(int argc, char ** argv) {
       CK(hipStreamSynchronize(stream));
       int bad_this = 0;
       for (int which = 0; which < 2; ++which) {
-        CK(hipMemcpy(h_keys.data(), a.keys[which], asize * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h_keys.data(), a.slots[which], asize * 8, hipMemcpyDeviceToHost));
         CK(hipMemcpy(h_slot.data(), a.slot_of[which], (uint64_t)n * 4, hipMemcpyDeviceToHost));
         uint32_t wrong = 0, shown = 0, first_bad = 0, last_bad = 0;
         for (uint32_t i = 0; i < n; ++i) {
           const uint32_t s = h_slot[i];
-          const uint64_t got = s < asize ? h_keys[s] : ~0ull;
+          const uint64_t got = s < asize ? h_keys[s] >> 32 : ~0ull;      // the slot's tag
           if (got == want[which][i]) { continue; }
           if (wrong == 0) { first_bad = i; }
           last_bad = i;
@@ -230,11 +233,11 @@ int main(int argc, char ** argv) {
             for (int64_t j = (int64_t)i - 512; j <= (int64_t)i + 512 && what[0] == 'u'; ++j) {
               if (j < 0 || j >= (int64_t)n) { continue; }
               for (int w2 = 0; w2 < 2; ++w2) {
-                if (h_anchor_key(db.seqs.data() + db.seq_off[j], db.seqlen[j], w2) == got) { snprintf(buf, sizeof buf, "key %d of amplicon i%+lld", w2, (long long)(j - (int64_t)i)); what = buf; }
+                if (h_anchor_tag(db.seqs.data() + db.seq_off[j], db.seqlen[j], w2) == got) { snprintf(buf, sizeof buf, "key %d of amplicon i%+lld", w2, (long long)(j - (int64_t)i)); what = buf; }
               }
             }
             for (uint32_t l2 = 32; l2 <= db.longest && what[0] == 'u'; ++l2) {
-              if (l2 <= db.seqlen[i] + 32 && h_anchor_key(db.seqs.data() + db.seq_off[i], l2, which) == got) { snprintf(buf, sizeof buf, "own sequence read with len %u (true %u)", l2, db.seqlen[i]); what = buf; }
+              if (l2 <= db.seqlen[i] + 32 && h_anchor_tag(db.seqs.data() + db.seq_off[i], l2, which) == got) { snprintf(buf, sizeof buf, "own sequence read with len %u (true %u)", l2, db.seqlen[i]); what = buf; }
             }
             printf("    which %d amplicon %u (block %u, wave %u of its block) slot %u: got %016llx want %016llx — %s\n", which, i, i / 256, (i % 256) / 64, s,
                    (unsigned long long)got, (unsigned long long)want[which][i], what);
