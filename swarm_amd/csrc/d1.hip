@@ -1000,14 +1000,18 @@ static uint32_t pair_big_limit() {
 static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   ctx->anchor_ready = false;
   const uint32_t n = ctx->db.n;
-  // Key tables: load <= 0.5 if every anchor that gets a slot were its own group — all of the range, or (a rank of a
-  // multi-GPU job, hashed ownership) this rank's share of them with 25 % headroom: keys then sit at most 1024 slots
-  // from home and k_anchor_place reports a table that turns out too small (anchor_slack: the next build sizes it for
-  // the whole range).  Smaller tables were tried for the single GPU (amplicon sets have far fewer groups than
-  // members): every pass over the table gets cheaper, but the placing atomics crowd into fewer cache lines and the
-  // build as a whole is slower (10 M: 4.4 ms against 3.75).
-  const bool optimistic = ctx->owner_world > 1 && ctx->anchor_slack == 0;
-  const uint64_t share = optimistic ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count;
+  // Slot tables.  Safe size (anchor_slack = 1): load <= 0.5 if every anchor that gets a slot were its own group.
+  // Amplicon sets are nothing like that — ten million amplicons make two million groups — and with one word per slot
+  // a table that fits the last-level cache is worth a quarter of the build (10 M: 3.2 ms at the safe size, 2.75 at a
+  // quarter of it, 2.57 at an eighth), so the first build of a database is optimistic: a quarter of the safe size
+  // (SWA_D1_TABLE_DIV), for a rank of a multi-GPU job of its share of the anchors (hashed ownership, 25 % headroom),
+  // keys at most 64 slots from home.  k_anchor_place reports a table that turns out too small (few members per group,
+  // skewed ownership): everything built on it is discarded and the next build — at once, and from then on for this
+  // database — takes the safe size.
+  const char * env_div = getenv("SWA_D1_TABLE_DIV");
+  const uint64_t div = ctx->anchor_slack == 0 ? (uint64_t)std::max(1, env_div != nullptr ? atoi(env_div) : 4) : 1;
+  const bool optimistic = (ctx->owner_world > 1 || div > 1) && ctx->anchor_slack == 0;
+  const uint64_t share = (ctx->owner_world > 1 && ctx->anchor_slack == 0 ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count) / div + 64;
   uint64_t asize = 64;
   while (asize < 2ull * share) { asize <<= 1; }
   ctx->anchor_slots = asize;
@@ -1030,7 +1034,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   AnchorBuildArgs b{};
   AnchorScatterArgs sc{};
   b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n;
-  b.first = first; b.count = count; b.amask = asize - 1; b.probe_limit = optimistic ? std::min<uint64_t>(1024, asize - 1) : asize - 1;
+  b.first = first; b.count = count; b.amask = asize - 1; b.probe_limit = optimistic ? std::min<uint64_t>(64, asize - 1) : asize - 1;
   b.fingerprint = static_cast<uint64_t *>(ctx->d_afp[0].ptr);
   b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.flags = dflags;
   b.win_a = ctx->anchor_a; b.win_b = ctx->anchor_b;
