@@ -996,6 +996,22 @@ static uint32_t pair_big_limit() {
   return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env))) : kPairBigCap;
 }
 
+// abundance rank of every amplicon (k_abundance_rank: three streaming passes); flags[1] is raised when the database is
+// not in abundance order
+static int launch_abundance_rank(swa_ctx * ctx) {
+  const uint32_t n = ctx->db.n;
+  const uint32_t tiles = (n + 255u) / 256u;
+  SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_rank_tmp, uint64_t(tiles) * sizeof(uint32_t)));
+  auto * rank = static_cast<uint32_t *>(ctx->d_arank.ptr);
+  auto * tile_last = static_cast<uint32_t *>(ctx->d_rank_tmp.ptr);
+  hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n, rank,
+                     static_cast<uint32_t *>(ctx->d_flags.ptr), tile_last);
+  hipLaunchKernelGGL(k_abundance_rank_carry, dim3(1), dim3(256), 0, ctx->stream, tile_last, tiles);
+  hipLaunchKernelGGL(k_abundance_rank_fill, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, n, rank, tile_last);
+  return SWA_OK;
+}
+
 // (re)builds the two anchor indexes for the query range [first, first + count)
 static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   ctx->anchor_ready = false;
@@ -1344,9 +1360,7 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   const uint32_t n = ctx->db.n;
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
   SWA_TRY(prepare_hashing(ctx));
-  SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
-  hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
-                     static_cast<uint32_t *>(ctx->d_arank.ptr), dflags);
+  SWA_TRY(launch_abundance_rank(ctx));
   swa_t0(ctx, 7);
   SWA_TRY(build_anchor_index(ctx, 0, n));
   swa_t1(ctx, 7);
@@ -1499,9 +1513,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     // the anchored index itself is built by the first network call, for that call's query range
     ctx->anchor_ready = false;
     if (ctx->anchor_usable) {
-      SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
-      hipLaunchKernelGGL(k_abundance_rank, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.abundance, n,
-                         static_cast<uint32_t *>(ctx->d_arank.ptr), static_cast<uint32_t *>(ctx->d_flags.ptr));
+      SWA_TRY(launch_abundance_rank(ctx));
       SWA_HIP(ctx, hipGetLastError());
     }
     uint32_t flags[2] = {0, 0};                             // [0] duplicates [1] abundances not in descending order

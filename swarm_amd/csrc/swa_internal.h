@@ -72,7 +72,7 @@ struct swa_ctx {
   uint32_t anchor_slack = 0;     // 1 after a share-sized anchor table overflowed: size for the whole range
   uint32_t anchor_a = 0, anchor_b = 0;   // anchor windows moved inwards by this many nt ("window mode", chosen at index build)
   swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_acursor[2], d_aoffsets[2], d_aslot[2], d_aitems[2], d_ainfo[2], d_apos[2], d_afp[2];
-  swa_dbuf d_acounters, d_afallback, d_arank;
+  swa_dbuf d_acounters, d_afallback, d_arank, d_rank_tmp;
   swa_dbuf d_seg_fill;           // u32 fill of every per-wave edge segment
   swa_dbuf d_seg_base;           // u64 start of every segment in the compacted edge list (swa_d1_network_edges_device)
   uint64_t seg_cap = 0;          // entries per segment

@@ -131,7 +131,7 @@ int main(int argc, char ** argv) {
   auto grid = [&](uint64_t items) { uint64_t b = (items + 255) / 256; const uint64_t cap = (uint64_t)cus * 8; return (int)std::max<uint64_t>(1, std::min(b, cap)); };
 
   uint64_t * d_seqs, * d_seq_off, * d_abund, * d_zob, * d_seqhash, * d_bloom, * d_pat;
-  uint32_t * d_seqlen, * d_rank, * d_flags;
+  uint32_t * d_seqlen, * d_rank, * d_flags, * d_rank_tmp;
   swa_aux * d_aux;
   swa_slot * d_table;
   const uint32_t zlen = db.longest + 2;
@@ -142,7 +142,7 @@ int main(int argc, char ** argv) {
   const uint64_t bwords = (tsize < 8 ? 8 : tsize) >> 3;
   CK(hipMalloc(&d_seqs, db.seqs.size() * 8)); CK(hipMalloc(&d_seq_off, ((uint64_t)n + 1) * 8)); CK(hipMalloc(&d_abund, (uint64_t)n * 8));
   CK(hipMalloc(&d_seqlen, (uint64_t)n * 4)); CK(hipMalloc(&d_zob, zob.size() * 8)); CK(hipMalloc(&d_seqhash, (uint64_t)n * 8));
-  CK(hipMalloc(&d_aux, (uint64_t)n * sizeof(swa_aux))); CK(hipMalloc(&d_rank, (uint64_t)n * 4)); CK(hipMalloc(&d_flags, 64));
+  CK(hipMalloc(&d_aux, (uint64_t)n * sizeof(swa_aux))); CK(hipMalloc(&d_rank, (uint64_t)n * 4)); CK(hipMalloc(&d_rank_tmp, ((uint64_t)n / 256 + 1) * 4)); CK(hipMalloc(&d_flags, 64));
   CK(hipMalloc(&d_table, tsize * sizeof(swa_slot))); CK(hipMalloc(&d_bloom, bwords * 8)); CK(hipMalloc(&d_pat, 1024 * 8));
   CK(hipMemcpyAsync(d_seqs, db.seqs.data(), db.seqs.size() * 8, hipMemcpyHostToDevice, stream));
   CK(hipMemcpyAsync(d_seq_off, db.seq_off.data(), ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, stream));
@@ -179,7 +179,9 @@ int main(int argc, char ** argv) {
         k_dup_check<<<grid(n), 256, 0, stream>>>(d_seqs, d_seq_off, d_seqlen, d_seqhash, 0, n, d_table, tsize - 1, d_flags);
       }
       if (flow == 2) { CK(hipStreamSynchronize(stream)); }
-      k_abundance_rank<<<grid(n), 256, 0, stream>>>(d_abund, n, d_rank, d_flags);
+      k_abundance_rank<<<grid(n), 256, 0, stream>>>(d_abund, n, d_rank, d_flags, d_rank_tmp);
+      k_abundance_rank_carry<<<1, 256, 0, stream>>>(d_rank_tmp, (n + 255u) / 256u);
+      k_abundance_rank_fill<<<grid(n), 256, 0, stream>>>(n, d_rank, d_rank_tmp);
       if (flow == 0) {
         uint32_t fl[2];
         CK(hipMemcpyAsync(fl, d_flags, 8, hipMemcpyDeviceToHost, stream));
