@@ -585,3 +585,23 @@ def test_pair_kernel_on_runs_and_length_extremes(gpu_ctx):
     db = S.build_db([(f"s{i}_{1 + (i * 3) % 4}".encode(), s.encode()) for i, s in enumerate(seqs)])
     for ncb in (False, True):
         _check_vs_oracle(gpu_ctx, db, ncb)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_pair_kernels_against_the_oracle_on_random_families(gpu_ctx, seed):
+    """Fuzz of the pair kernels: families of random size (1..400) and length (40..256), two- or four-letter alphabets,
+    one to three edits from the centroid (so that pairs at distance 0, 1, 2, .. sit in the same anchor groups), many
+    abundance ties, both settings of cluster breaking — the network must equal the oracle's."""
+    rng = np.random.default_rng(9000 + seed)
+    longest = int(rng.choice([90, 150, 160, 200, 256]))
+    seqs = set()
+    while len(seqs) < 2500:
+        length = int(rng.integers(40, longest - 3))
+        alphabet = "AC" if rng.random() < 0.3 else "ACGT"
+        size = int(rng.choice([1, 2, 3, 5, 9, 20, 40, 70, 130, 260, 400]))
+        fam = _family(rng, length, size, max_edits=3, alphabet=alphabet)
+        seqs |= {s for s in fam if 1 <= len(s) <= longest}
+    seqs = sorted(seqs)
+    ab = rng.choice([1, 1, 1, 2, 2, 3, 7, 50], size=len(seqs))
+    db = S.build_db([(f"s{i}_{int(ab[i])}".encode(), s.encode()) for i, s in enumerate(seqs)])
+    _check_vs_oracle(gpu_ctx, db, ncb=bool(seed & 1))
