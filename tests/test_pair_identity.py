@@ -1,0 +1,113 @@
+"""The identities the d=1 pair kernels (swarm_amd/csrc/d1_anchor.inc: pair_stage / pair_near) decide links with, pinned
+on the CPU against the definition the reference works from (src/variants.cc: b is a microvariant of a <=> one
+substitution, deletion or insertion turns a into b):
+
+    one edit apart  <=>  lcp + lcs == n - 1            equal lengths n (identical sequences: never)
+                         lcp + lcs >= n                lengths n and n + 1, lcp and lcs capped at n
+
+and, bit for bit, the way the kernels compute lcp and lcs: forward packed words (32 nt per 64-bit word, LSB first) and
+the same words END-ALIGNED (shifted up so that the last nucleotide is the top 2-bit group of word W - 1), first
+differing bit from the bottom (v_ffbl per dword, OR 32 k, minimum) resp. from the top (v_ffbh)."""
+import itertools
+
+import numpy as np
+import pytest
+
+CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def one_edit_apart(a: str, b: str) -> bool:
+    if a == b or abs(len(a) - len(b)) > 1:
+        return False
+    if len(a) == len(b):
+        return sum(x != y for x, y in zip(a, b)) == 1
+    s, l = (a, b) if len(a) < len(b) else (b, a)
+    return any(l[:p] + l[p + 1:] == s for p in range(len(l)))
+
+
+def lcp_lcs_rule(a: str, b: str) -> bool:
+    n = min(len(a), len(b))
+    apart = max(len(a), len(b)) - n
+    lcp = next((i for i in range(n) if a[i] != b[i]), n)
+    lcs = next((i for i in range(n) if a[-1 - i] != b[-1 - i]), n)
+    return (lcp + lcs == n - 1) if apart == 0 else (apart == 1 and lcp + lcs >= n)
+
+
+@pytest.mark.parametrize("alphabet,maxlen", [("AC", 7), ("ACG", 5)])
+def test_rule_equals_definition_exhaustively(alphabet, maxlen):
+    words = ["".join(t) for n in range(1, maxlen + 1) for t in itertools.product(alphabet, repeat=n)]
+    for a in words:
+        for b in words:
+            if abs(len(a) - len(b)) <= 1:
+                assert lcp_lcs_rule(a, b) == one_edit_apart(a, b), (a, b)
+
+
+def pack(seq: str, W: int):
+    """forward dwords (2 W of them) and end-aligned dwords, as pair_stage makes them"""
+    v = 0
+    for i, ch in enumerate(seq):
+        v |= CODE[ch] << (2 * i)
+    shift = 2 * (32 * W - len(seq))
+    t = (v << shift) & ((1 << (64 * W)) - 1)
+    dw = lambda x: [(x >> (32 * k)) & 0xFFFFFFFF for k in range(2 * W)]
+    return dw(v), dw(t)
+
+
+def ffbl(x):            # v_ffbl_b32: 0xFFFFFFFF for 0
+    return 0xFFFFFFFF if x == 0 else (x & -x).bit_length() - 1
+
+
+def ffbh(x):            # v_ffbh_u32
+    return 0xFFFFFFFF if x == 0 else 32 - x.bit_length()
+
+
+def kernel_near(a: str, b: str, W: int) -> bool:
+    wa, ta = pack(a, W)
+    wb, tb = pack(b, W)
+    f = l = 0xFFFFFFFF
+    for k in range(2 * W):
+        f = min(f, ffbl(wa[k] ^ wb[k]) | (32 * k))
+        l = min(l, ffbh(ta[k] ^ tb[k]) | (32 * (2 * W - 1 - k)))
+    n = min(len(a), len(b))
+    apart = max(len(a), len(b)) - n
+    total = min(f >> 1, n) + min(l >> 1, n)
+    return (total + 1 == n) if apart == 0 else (apart == 1 and total >= n)
+
+
+@pytest.mark.parametrize("W,alphabet", [(5, "ACGT"), (5, "AC"), (8, "ACGT"), (8, "A")])
+def test_bit_level_form_equals_definition(W, alphabet):
+    """random pairs at 0..3 edits, lengths around every word boundary up to 32 W, runs included"""
+    rng = np.random.default_rng(17 * W + len(alphabet))
+    lengths = sorted({1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 32 * W - 1, 32 * W})
+    for length in lengths:
+        if length > 32 * W:
+            continue
+        for _ in range(120):
+            a = "".join(rng.choice(list(alphabet), length))
+            b = a
+            for _ in range(int(rng.integers(0, 4))):
+                p = int(rng.integers(0, max(1, len(b))))
+                kind = int(rng.integers(0, 3))
+                ch = str(rng.choice(list("ACGT")))
+                b = b[:p] + ch + b[p + 1:] if kind == 0 else (b[:p] + b[p + 1:] if kind == 1 else b[:p] + ch + b[p:])
+            if not 1 <= len(b) <= 32 * W:
+                continue
+            assert kernel_near(a, b, W) == one_edit_apart(a, b), (a, b)
+            assert kernel_near(b, a, W) == one_edit_apart(a, b), (b, a)
+
+
+def test_division_between_the_passes_covers_every_link_once():
+    """A pair one edit apart (both >= 65 nt) shares its first 32 nt or its last 32 nt (or both): the prefix pass takes
+    the pairs with equal first windows, the suffix pass the others — which then share the last window."""
+    rng = np.random.default_rng(5)
+    for _ in range(3000):
+        length = int(rng.integers(65, 100))
+        a = "".join(rng.choice(list("AC" if rng.random() < 0.5 else "ACGT"), length))
+        p = int(rng.integers(0, len(a)))
+        kind = int(rng.integers(0, 3))
+        ch = str(rng.choice(list("ACGT")))
+        b = a[:p] + ch + a[p + 1:] if kind == 0 else (a[:p] + a[p + 1:] if kind == 1 else a[:p] + ch + a[p:])
+        if not one_edit_apart(a, b) or min(len(a), len(b)) < 65:
+            continue
+        same_prefix, same_suffix = a[:32] == b[:32], a[-32:] == b[-32:]
+        assert same_prefix or same_suffix, (a, b)
