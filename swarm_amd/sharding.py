@@ -50,23 +50,30 @@ def allgather_csr(local_offsets: torch.Tensor, local_nb: torch.Tensor, local_tot
     counts        : per-rank query counts (from partition_*), identical on all ranks
     Returns (offsets int64 [n + 1], neighbours int32 [total]) on the tensors' device.
 
-    Collectives: one all_gather of the hit counts (8 bytes per rank), one of the per-row link
-    counts (4 bytes per amplicon — not the 64-bit offsets: they are a prefix sum away) padded to the
-    largest slice, one of the hit lists padded to the largest hit count.
+    Collectives: one all_gather of the hit counts and longest rows (16 bytes per rank), one of the
+    per-row link counts (1 byte per amplicon, 4 if some row has more than 255 links — not the 64-bit
+    offsets: they are a prefix sum away) padded to the largest slice, one of the hit lists padded to
+    the largest hit count.
     """
     world = dist.get_world_size(group)
     dev = local_offsets.device
-    mine = torch.tensor([local_total], dtype=torch.int64, device=dev)
-    totals = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(totals, mine, group=group)
-    totals_host = [int(x) for x in totals.tolist()]
+    rows_here = local_offsets.numel() - 1
+    row_cnt = local_offsets[1:] - local_offsets[:-1]
+    longest = row_cnt.max() if rows_here > 0 else torch.zeros((), dtype=torch.int64, device=dev)
+    mine = torch.stack([torch.tensor(local_total, dtype=torch.int64, device=dev), longest.to(torch.int64)])
+    gathered = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    gathered_host = [int(x) for x in gathered.tolist()]
+    totals_host, longest_row = gathered_host[0::2], max(gathered_host[1::2])
     max_rows = max(max(counts), 1)
     max_hits = max(max(totals_host), 1)
 
-    rows_here = local_offsets.numel() - 1
-    pad_cnt = torch.zeros(max_rows, dtype=torch.int32, device=dev)
-    pad_cnt[:rows_here] = (local_offsets[1:] - local_offsets[:-1]).to(torch.int32)
-    all_cnt = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
+    # per-row link counts travel as bytes when every row of the network has at most 255 links (an amplicon has about
+    # two neighbours; a quarter of the traffic of 32-bit counts), else as 32-bit integers
+    cnt_dtype = torch.uint8 if longest_row <= 255 else torch.int32
+    pad_cnt = torch.zeros(max_rows, dtype=cnt_dtype, device=dev)
+    pad_cnt[:rows_here] = row_cnt.to(cnt_dtype)
+    all_cnt = torch.empty(world * max_rows, dtype=cnt_dtype, device=dev)
     dist.all_gather_into_tensor(all_cnt, pad_cnt, group=group)
 
     pad_nb = torch.zeros(max_hits, dtype=torch.int32, device=dev)

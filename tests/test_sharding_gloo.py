@@ -51,10 +51,27 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "length"), (3, "length")])
+def _star_fasta(path, arms=300):
+    """one centre with `arms` substitution neighbours: a row of more than 255 links (row counts then travel as 32-bit
+    integers, not bytes)"""
+    rng = np.random.default_rng(3)
+    centre = "".join(rng.choice(list("ACGT"), 120))
+    seqs = {centre}
+    while len(seqs) < arms + 1:
+        p = int(rng.integers(0, len(centre)))
+        seqs.add(centre[:p] + "ACGT"[("ACGT".index(centre[p]) + int(rng.integers(1, 4))) % 4] + centre[p + 1:])
+    recs = [(centre, 1000)] + [(s, 1 + i % 7) for i, s in enumerate(sorted(seqs - {centre}))]
+    path.write_text("".join(f">s{i}_{a}\n{s}\n" for i, (s, a) in enumerate(recs)))
+
+
+@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "length"), (3, "length"), (2, "star")])
 def test_sharded_network_equals_single(tmp_path, world, mode):
     fa = tmp_path / "in.fa"
-    S.gen_fasta(fa, 3001, 90, 77)
+    if mode == "star":
+        _star_fasta(fa)
+        mode = "even"
+    else:
+        S.gen_fasta(fa, 3001, 90, 77)
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
