@@ -128,6 +128,24 @@ int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int 
    owner call swa_d1_index_build[_range] again. */
 int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world);
 
+/* Routed index build of a multi-GPU job: no rank walks the whole (replicated) database any more.
+   (The reference has no counterpart: its threads share one table, src/algod1.cc:188-208; this is the distributed
+   form of that hash_insert loop.)
+   1. every rank keys ITS slice [first, first + count) of the amplicons: swa_d1_route_slice leaves, per anchor index
+      (0 = prefix side, 1 = suffix side) and per owning rank, the ids of the slice whose key that rank owns —
+      d_ids[(index * world + owner) * cap + ..], d_counts[index * world + owner]; d_counts[2 * world] != 0 reports a
+      region that was too small (cap >= 1.5 * count / world + 1024 never is, ownership being hashed).  Device
+      pointers; asynchronous on the context's stream.
+   2. the ranks exchange the lists all-to-all (RCCL / torch.distributed: 8 bytes per amplicon in total);
+   3. every rank builds its indexes from what it received: swa_d1_index_build_routed(ids of index 0, of index 1) —
+      as swa_d1_index_build under swa_d1_set_ownership(rank, world), which must have been called, but from the lists.
+      Databases the anchored passes cannot serve alone (sequences under 65 nt, oversized groups, not in abundance
+      order) take the database-wide route inside the call, as always. */
+int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint32_t * d_ids, uint64_t cap,
+                       uint32_t * d_counts);
+int swa_d1_index_build_routed(swa_ctx * ctx, const uint32_t * d_ids_prefix, uint32_t n_prefix, const uint32_t * d_ids_suffix,
+                              uint32_t n_suffix, int * has_duplicates);
+
 /* Neighbour lists of amplicons [first, first+count) as CSR: offsets[count+1],
    neighbours[offsets[count]]; row k = { j != first+k : seq_j is a microvariant of
    seq_(first+k) and (no_cluster_breaking or abundance[first+k] >= abundance[j]) },

@@ -43,7 +43,7 @@ class DbView(C.Structure):
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_d1_anchor_windows",
     "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_resident",
-    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device",
+    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
@@ -88,6 +88,8 @@ def load_library() -> C.CDLL:
     lib.swa_d1_network_edges_device.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
                                                 C.POINTER(C.c_uint64)]
     lib.swa_d1_set_ownership.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.swa_d1_route_slice.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.swa_d1_index_build_routed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
     lib.swa_d1_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.swa_d1_table_size.argtypes = [C.c_void_p]
     lib.swa_d1_table_size.restype = C.c_uint64
@@ -363,6 +365,22 @@ class Context:
         so a network call returns PARTIAL rows; sharding.exchange_owned_links merges the ranks' links.
         world = 1 restores the complete network."""
         self._check(self.lib.swa_d1_set_ownership(self.h, rank, world))
+
+    def d1_route_slice(self, first: int, count: int, world: int, d_ids, cap: int, d_counts) -> None:
+        """Routed multi-GPU index build, step 1 (swa_d1_route_slice): the ids of [first, first+count) grouped by the
+        rank that owns their prefix-side / suffix-side key.  d_ids: device int32/uint32 tensor [2 * world * cap],
+        d_counts: device tensor [2 * world + 1] (anything with data_ptr()); asynchronous on the context's stream."""
+        self._check(self.lib.swa_d1_route_slice(self.h, first, count, world, C.c_void_p(d_ids.data_ptr()), cap,
+                                                C.c_void_p(d_counts.data_ptr())))
+
+    def d1_index_build_routed(self, d_ids_prefix, n_prefix: int, d_ids_suffix, n_suffix: int) -> bool:
+        """Step 3 (swa_d1_index_build_routed): this rank's indexes from the member ids it received; ownership must be
+        set.  Returns True when duplicate sequences were found."""
+        dup = C.c_int(0)
+        self._check(self.lib.swa_d1_index_build_routed(self.h, C.c_void_p(d_ids_prefix.data_ptr() if n_prefix else 0), n_prefix,
+                                                       C.c_void_p(d_ids_suffix.data_ptr() if n_suffix else 0), n_suffix, C.byref(dup)),
+                    allow=(SWA_E_DUPLICATES,))
+        return bool(dup.value)
 
     def d1_network(self, no_cluster_breaking: bool = False, first: int = 0, count: int | None = None):
         """CSR over [first, first+count): (offsets u64[count+1], neighbours u32[total]), rows ascending."""

@@ -160,6 +160,10 @@ static void invalidate(swa_ctx * ctx) {
   ctx->aux_complete = false;
   ctx->anchor_ready = false;
   ctx->anchor_slack = 0;
+  ctx->rank_ready = false;
+  ctx->db_unordered = false;
+  ctx->props_ready = false;
+  ctx->windows_ready = false;
   ctx->anchor_a = ctx->anchor_b = 0;
   ctx->qgram_ready = false;
   ctx->scan_ready = false;

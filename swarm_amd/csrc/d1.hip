@@ -999,6 +999,11 @@ static uint32_t pair_big_limit() {
 // abundance rank of every amplicon (k_abundance_rank: three streaming passes); flags[1] is raised when the database is
 // not in abundance order
 static int launch_abundance_rank(swa_ctx * ctx) {
+  if (ctx->rank_ready) {                                    // (a fact of the uploaded database: once per upload)
+    if (ctx->db_unordered) { SWA_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(ctx->d_flags.ptr) + 1, 1, sizeof(uint32_t), ctx->stream)); }
+    return SWA_OK;
+  }
+  ctx->rank_ready = true;
   const uint32_t n = ctx->db.n;
   const uint32_t tiles = (n + 255u) / 256u;
   SWA_TRY(swa_reserve(ctx, ctx->d_arank, uint64_t(n) * sizeof(uint32_t)));
@@ -1009,6 +1014,26 @@ static int launch_abundance_rank(swa_ctx * ctx) {
                      static_cast<uint32_t *>(ctx->d_flags.ptr), tile_last);
   hipLaunchKernelGGL(k_abundance_rank_carry, dim3(1), dim3(256), 0, ctx->stream, tile_last, tiles);
   hipLaunchKernelGGL(k_abundance_rank_fill, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, n, rank, tile_last);
+  return SWA_OK;
+}
+
+__global__ void k_set_flags(uint32_t * flags, uint32_t unserved, uint32_t shortest_code) { flags[3] = unserved; flags[6] = shortest_code; }
+
+// shortest sequence / "some sequence starts with 32 equal nucleotides": facts of the uploaded database (k_db_properties),
+// what a routed build knows instead of finding out while it walks the database
+static int ensure_db_properties(swa_ctx * ctx) {
+  if (ctx->props_ready) { return SWA_OK; }
+  SWA_TRY(swa_reserve(ctx, ctx->d_rank_tmp, std::max<size_t>(ctx->d_rank_tmp.bytes, 64)));
+  auto * out = static_cast<uint32_t *>(ctx->d_rank_tmp.ptr);
+  SWA_HIP(ctx, hipMemsetAsync(out, 0, 2 * sizeof(uint32_t), ctx->stream));
+  hipLaunchKernelGGL(k_db_properties, dim3(grid_for(ctx, ctx->db.n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->db.seqlen, ctx->db.n, out);
+  uint32_t host[2] = {0, 0};
+  SWA_HIP(ctx, hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->db_shortest = 0xFFFFFFFFu - host[0];
+  ctx->db_run32 = host[1] != 0;
+  ctx->props_ready = true;
   return SWA_OK;
 }
 
@@ -1026,8 +1051,11 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   // database — takes the safe size.
   const char * env_div = getenv("SWA_D1_TABLE_DIV");
   const uint64_t div = ctx->anchor_slack == 0 ? (uint64_t)std::max(1, env_div != nullptr ? atoi(env_div) : 4) : 1;
+  const bool routed = ctx->route_ids[0] != nullptr;          // the members of this rank's groups came as id lists
   const bool optimistic = (ctx->owner_world > 1 || div > 1) && ctx->anchor_slack == 0;
-  const uint64_t share = (ctx->owner_world > 1 && ctx->anchor_slack == 0 ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count) / div + 64;
+  const uint64_t members = routed ? std::max(ctx->route_m[0], ctx->route_m[1])
+                                  : (ctx->owner_world > 1 && ctx->anchor_slack == 0 ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count);
+  const uint64_t share = (routed && ctx->anchor_slack != 0 ? members : members / div) + 64;
   uint64_t asize = 64;
   while (asize < 2ull * share) { asize <<= 1; }
   ctx->anchor_slots = asize;
@@ -1067,9 +1095,19 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   sc.fingerprint = b.fingerprint; sc.member_fingerprint = static_cast<uint64_t *>(ctx->d_afp[1].ptr);
   sc.seqlen = ctx->db.seqlen; sc.rank = static_cast<const uint32_t *>(ctx->d_arank.ptr); sc.seq_off = ctx->db.seq_off; sc.n = n;
   hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, b.slots[0], b.slots[1], asize);
-  hipLaunchKernelGGL(k_anchor_place<true>, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
-  if (count < n) {
-    hipLaunchKernelGGL(k_anchor_place<false>, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
+  if (routed) {
+    // unserved seeds / shortest sequence: facts of the database (the lists say nothing about amplicons that went elsewhere)
+    hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(1), 0, ctx->stream, dflags,
+                       (ctx->db_shortest < b.minlen || (b.window_mode == 0u && ctx->db_run32)) ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
+    for (int which = 0; which < 2; ++which) {
+      b.list = ctx->route_ids[which]; b.list_count = ctx->route_m[which]; b.list_which = which;
+      if (b.list_count != 0) { hipLaunchKernelGGL(k_anchor_place_list, dim3(grid_for(ctx, b.list_count, 256, 8)), dim3(256), 0, ctx->stream, b); }
+    }
+  } else {
+    hipLaunchKernelGGL(k_anchor_place<true>, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
+    if (count < n) {
+      hipLaunchKernelGGL(k_anchor_place<false>, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
+    }
   }
   // (a table that turned out too small — flags[2] — still leaves a consistent index of the amplicons placed before
   // that: what follows runs on it harmlessly until the host looks at the flag, at the next point where it waits anyway)
@@ -1100,7 +1138,16 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, tsums, tiles);
     hipLaunchKernelGGL((k_scan_apply<unsigned long long>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums, offs);
   }
-  hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, sc);
+  if (routed) {
+    for (int which = 0; which < 2; ++which) {
+      if (ctx->route_m[which] != 0) {
+        hipLaunchKernelGGL(k_anchor_scatter_list, dim3(grid_for(ctx, ctx->route_m[which], 256, 8)), dim3(256), 0, ctx->stream, sc, which,
+                           ctx->route_ids[which], ctx->route_m[which]);
+      }
+    }
+  } else {
+    hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, sc);
+  }
   SWA_HIP(ctx, hipGetLastError());
   ctx->anchor_first = first;
   ctx->anchor_count = count;
@@ -1349,6 +1396,18 @@ static int choose_anchor_windows(swa_ctx * ctx) {
   return SWA_OK;                                             // nothing qualifies: the ends it is (and the plain kernel for the giants)
 }
 
+// the anchor windows of this database: chosen from a sample once per upload (and corrected by the safety net of the
+// first build if the sample misjudged), then reused
+static int ensure_anchor_windows(swa_ctx * ctx) {
+  if (!ctx->windows_ready) {
+    SWA_TRY(choose_anchor_windows(ctx));
+    ctx->windows_chosen = ctx->anchor_a;
+    ctx->windows_ready = true;
+  }
+  ctx->anchor_a = ctx->anchor_b = ctx->windows_chosen;
+  return SWA_OK;
+}
+
 // Index build of a rank that serves only the anchor groups it owns (swa_d1_set_ownership,
 // world > 1), without anything proportional to the database except streaming passes: abundance
 // ranks, the anchor indexes of the owned groups (all their members), hashes and XOR streams of
@@ -1418,6 +1477,7 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
     SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
     return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
   }
+  if (flags[1] != 0) { ctx->db_unordered = true; }
   *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
   // Zobrist hashes and XOR streams of the members: only the enumerating kernels read them (the pair kernels compare
   // the sequences themselves, the duplicate check their fingerprints); the full route hashes everybody anyway
@@ -1467,8 +1527,9 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   if (ctx->anchor_usable && owned_index_enabled()) {
     bool needs_table = false;
     uint32_t mass = 0, shortest = 0;
-    SWA_TRY(choose_anchor_windows(ctx));
+    SWA_TRY(ensure_anchor_windows(ctx));
     const uint32_t sampled = ctx->anchor_a;
+    const bool routed = ctx->route_ids[0] != nullptr;        // (the lists were made under these windows: no second thoughts)
     SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &mass, &shortest));
     // Conserved flanks: when a noticeable part of the database sits in groups too large for LDS (everybody shares
     // the first or last 32 nt), the anchor windows move inwards, 32 nt at a time, as far as the shortest sequence
@@ -1476,7 +1537,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     // mode needs the pair kernels (sequences up to 256 nt); SWA_D1_WINDOWS=0 switches the search off.
     const char * env_win = getenv("SWA_D1_WINDOWS");
     // (safety net behind the sample: the real build still found too many stranded members — try the next offsets)
-    if (needs_table && mass > n / 64u && ctx->db.longest <= 256u && !(env_win != nullptr && env_win[0] == '0')) {
+    if (!routed && needs_table && mass > n / 64u && ctx->db.longest <= 256u && !(env_win != nullptr && env_win[0] == '0')) {
       uint32_t best = sampled, best_mass = mass;
       for (uint32_t w = sampled + 32u; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
         ctx->anchor_a = ctx->anchor_b = w;
@@ -1492,6 +1553,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
         SWA_TRY(build_owned_index(ctx, first, count, &needs_table));
       }
     }
+    ctx->windows_chosen = ctx->anchor_a;                     // (what the safety net settled on, for the next build)
     owned_ok = !needs_table;
     ctx->aux_complete = owned_ok && ctx->owner_world == 1 && (ctx->aux_members || !ctx->aux_needed);
     SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1520,7 +1582,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     SWA_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags.ptr, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     flag |= flags[0];
-    if (flags[1] != 0) { ctx->anchor_usable = false; }      // the anchored passes rely on the db order
+    if (flags[1] != 0) { ctx->anchor_usable = false; ctx->db_unordered = true; }   // the anchored passes rely on the db order
   }
   ctx->d1_ready = true;
   if (has_duplicates != nullptr) { *has_duplicates = flag != 0 ? 1 : 0; }
@@ -1725,6 +1787,43 @@ extern "C" int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breakin
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network_edges: bad range or null buffer");
   }
   return network_run(ctx, no_cluster_breaking, first, count, nullptr, nullptr, d_edge_list, cap, total);
+}
+
+extern "C" int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint32_t * d_ids, uint64_t cap,
+                                  uint32_t * d_counts) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice: no database"); }
+  if (first > ctx->db.n || count > ctx->db.n - first) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice: bad range"); }
+  if (world == 0 || world > kRouteMaxWorld || d_ids == nullptr || d_counts == nullptr || cap == 0) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice: bad argument (1..64 ranks)");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
+  SWA_TRY(ensure_anchor_windows(ctx));
+  SWA_HIP(ctx, hipMemsetAsync(d_counts, 0, (2ull * world + 1) * sizeof(uint32_t), ctx->stream));
+  if (count != 0) {
+    hipLaunchKernelGGL(k_anchor_route, dim3(grid_for(ctx, (count + kRoutePerThread - 1) / kRoutePerThread, 256, 8)), dim3(256), 0, ctx->stream,
+                       ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, first, count, world, ctx->anchor_a, ctx->anchor_b, d_ids, cap, d_counts);
+  }
+  SWA_HIP(ctx, hipGetLastError());
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_index_build_routed(swa_ctx * ctx, const uint32_t * d_ids_prefix, uint32_t n_prefix, const uint32_t * d_ids_suffix,
+                                         uint32_t n_suffix, int * has_duplicates) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_routed: no database"); }
+  if (ctx->owner_world <= 1) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_routed: call swa_d1_set_ownership(rank, world > 1) first"); }
+  if ((n_prefix != 0 && d_ids_prefix == nullptr) || (n_suffix != 0 && d_ids_suffix == nullptr)) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_routed: null list"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_TRY(ensure_db_properties(ctx));
+  static const uint32_t nothing = 0;                         // (an empty list still marks the build as routed)
+  ctx->route_ids[0] = n_prefix != 0 ? d_ids_prefix : &nothing; ctx->route_m[0] = n_prefix;
+  ctx->route_ids[1] = n_suffix != 0 ? d_ids_suffix : &nothing; ctx->route_m[1] = n_suffix;
+  const int rc = swa_d1_index_build_range(ctx, 0, ctx->db.n, has_duplicates);
+  ctx->route_ids[0] = ctx->route_ids[1] = nullptr;
+  ctx->route_m[0] = ctx->route_m[1] = 0;
+  return rc;
 }
 
 extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world) {

@@ -65,6 +65,17 @@ struct swa_ctx {
   uint64_t anchor_slots = 0;
   bool full_index = false;       // d_seqhash / d_aux cover ALL amplicons and d_table / d_bloom are built (ensure_full_index)
   bool aux_members = false;      // d_seqhash / d_aux hold the members of the anchor indexes (lean build that needed them)
+  // routed build (swa_d1_index_build_routed): the members of this rank's groups arrive as id lists; and what is a fact
+  // of the uploaded database rather than of one index build, kept until the next upload
+  const uint32_t * route_ids[2] = {nullptr, nullptr};
+  uint32_t route_m[2] = {0, 0};
+  bool rank_ready = false;       // d_arank holds the abundance ranks of this database
+  bool db_unordered = false;     // ... which is not in abundance order (the anchored passes are then not used)
+  bool props_ready = false;      // db_shortest / db_run32 below
+  uint32_t db_shortest = 0;      // shortest sequence
+  bool db_run32 = false;         // some sequence starts with 32 equal nucleotides
+  bool windows_ready = false;    // the anchor windows of this database are known (choose_anchor_windows + the safety net):
+  uint32_t windows_chosen = 0;   // anchor_a = anchor_b = this
   bool pair_lists = false;       // the anchor indexes carry the work lists of the pair kernels (k_anchor_items_classes)
   bool aux_needed = true;        // some anchor group is served by the enumerating kernels (they read d_seqhash / d_aux)
   bool aux_complete = false;     // d_seqhash / d_aux cover every amplicon that has an anchor (lean build with world = 1)

@@ -307,3 +307,36 @@ def poison_device_memory(chunks: int = 32, chunk_bytes: int = 1 << 28) -> None:
     assert hip.hipDeviceSynchronize() == 0 and len(held) > 0
     for ptr in held:
         assert hip.hipFree(ptr) == 0
+
+
+class DeviceArray:
+    """A plain device buffer through the HIP runtime the library uses (no torch): what the device-pointer entry
+    points of the C ABI take in the tests.  data_ptr() like a torch tensor."""
+
+    def __init__(self, count: int, dtype=np.uint32):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self.dtype, self.count = np.dtype(dtype), int(count)
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), max(1, self.count) * self.dtype.itemsize) == 0
+
+    def data_ptr(self) -> int:
+        return self.ptr.value
+
+    def to_host(self, count: int | None = None) -> np.ndarray:
+        out = np.empty(self.count if count is None else count, dtype=self.dtype)
+        assert self.hip.hipDeviceSynchronize() == 0
+        assert self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes, 2) == 0      # hipMemcpyDeviceToHost
+        return out
+
+    def from_host(self, a: np.ndarray) -> None:
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size <= self.count
+        assert self.hip.hipMemcpy(self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0           # hipMemcpyHostToDevice
+
+    def free(self) -> None:
+        if self.ptr:
+            self.hip.hipFree(self.ptr)
+            self.ptr = C.c_void_p()

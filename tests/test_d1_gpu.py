@@ -605,3 +605,66 @@ def test_pair_kernels_against_the_oracle_on_random_families(gpu_ctx, seed):
     ab = rng.choice([1, 1, 1, 2, 2, 3, 7, 50], size=len(seqs))
     db = S.build_db([(f"s{i}_{int(ab[i])}".encode(), s.encode()) for i, s in enumerate(seqs)])
     _check_vs_oracle(gpu_ctx, db, ncb=bool(seed & 1))
+
+
+@pytest.mark.parametrize("which,world", [("generated", 2), ("generated", 5), ("length_mix", 3), ("giant_groups", 2), ("flanks", 3)])
+def test_routed_index_build_equals_the_network(tmp_path, which, world):
+    """swa_d1_route_slice + swa_d1_index_build_routed: every rank keys only its slice, the ids travel to the owners of
+    their keys (here: through the host, one context playing the ranks in turn), every rank builds its indexes from the
+    lists it received — and over the ranks every link of the network appears exactly once.  Databases with sequences
+    under 65 nt or oversized groups take the database-wide route inside the call; conserved flanks move the windows."""
+    from swarm_amd import Context
+    if which == "generated":
+        fa = tmp_path / "in.fa"
+        S.gen_fasta(fa, 20000, 150, 43)
+        db = S.db_from_fasta(fa)
+    elif which == "flanks":
+        fa = tmp_path / "flank.fa"
+        _conserved_flank_set(fa, 20000, 77)
+        db = S.db_from_fasta(fa)
+    else:
+        db = _giant_group_db() if which == "giant_groups" else _length_mix_db()
+    woff, wnb, _ = _oracle_sorted_rows(db)
+    whole = _link_keys(woff, wnb)
+    ctx = Context(0)
+    try:
+        _upload(ctx, db)
+        n = db.n
+        cap = 3 * n // (2 * world) + 1024
+        # step 1 + 2: every slice routed, the lists collected per owner
+        bounds = [n * r // world for r in range(world + 1)]
+        inbox = [[[], []] for _ in range(world)]
+        d_ids, d_counts = S.DeviceArray(2 * world * cap), S.DeviceArray(2 * world + 1)
+        for r in range(world):
+            ctx.d1_route_slice(bounds[r], bounds[r + 1] - bounds[r], world, d_ids, cap, d_counts)
+            counts = d_counts.to_host()
+            assert counts[2 * world] == 0
+            ids = d_ids.to_host()
+            for index in range(2):
+                for owner in range(world):
+                    k = index * world + owner
+                    inbox[owner][index].append(ids[k * cap: k * cap + counts[k]])
+        d_ids.free(); d_counts.free()
+        # every amplicon long enough went to exactly one owner per index
+        for index in range(2):
+            everything = np.sort(np.concatenate([np.concatenate(inbox[o][index]) for o in range(world)]))
+            assert (np.diff(everything) > 0).all() and len(everything) <= n
+        # step 3: each rank from its lists
+        parts = []
+        for rank in range(world):
+            lists = [np.concatenate(inbox[rank][index]).astype(np.uint32) for index in range(2)]
+            bufs = [S.DeviceArray(max(1, len(l))) for l in lists]
+            for b, l in zip(bufs, lists):
+                b.from_host(l)
+            ctx.d1_set_ownership(rank, world)
+            assert ctx.d1_index_build_routed(bufs[0], len(lists[0]), bufs[1], len(lists[1])) is False
+            poff, pnb = ctx.d1_network()
+            parts.append(_link_keys(poff, pnb))
+            for b in bufs:
+                b.free()
+        merged = np.sort(np.concatenate(parts))
+        assert np.array_equal(merged, whole), (which, world)
+        if which in ("generated", "flanks"):
+            assert sum(len(p) > 0 for p in parts) == world
+    finally:
+        ctx.close()
