@@ -424,6 +424,10 @@ def main() -> None:
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="development aid: run rank 0's share of an N-GPU job on this one GPU (no collectives); "
                          "the JSON line is marked simulated and is not a result")
+    ap.add_argument("--build", default="routed", choices=["routed", "streamed"],
+                    help="N > 1, owned sharding: 'routed' = every rank keys its own slice and the ids travel all-to-all to the "
+                         "owners of their keys (swa_d1_route_slice + swa_d1_index_build_routed); 'streamed' = every rank walks the "
+                         "whole replicated database for the keys it owns")
     ap.add_argument("--shard", default="owned", choices=["owned", "range"],
                     help="N > 1: 'owned' = every rank serves the anchor groups it owns (swa_d1_set_ownership) and the "
                          "links are exchanged all-to-all by seed range; 'range' = every rank answers its contiguous query slice "
@@ -502,9 +506,37 @@ def main() -> None:
 
     dup_flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
+    # routed index build (owned sharding): a rank keys only its own slice, the ids travel all-to-all to the owners of
+    # their keys, every rank builds its indexes from what it received — no rank walks the whole database
+    routed = owned and args.build == "routed"
+    if routed:
+        w_all = sim_world or world
+        route_cap = 3 * count // (2 * w_all) + 1024
+        d_route = torch.zeros(2 * w_all * route_cap, dtype=torch.int32, device=dev)
+        d_route_counts = torch.zeros(2 * w_all + 1, dtype=torch.int32, device=dev)
+        sim_lists = None
+        if sim_world:
+            # one GPU playing rank 0 of N: what the other ranks would send does not change from step to step — made once,
+            # outside the timed region; the timed step routes rank 0's own slice and builds from the lists
+            inbox = ([], [])
+            for r, (f_r, c_r) in enumerate(parts):
+                ctx.d1_route_slice(f_r, c_r, w_all, d_route, route_cap, d_route_counts)
+                cts = d_route_counts.tolist()
+                assert cts[2 * w_all] == 0
+                for index in range(2):
+                    k = index * w_all + rank
+                    inbox[index].append(d_route[k * route_cap: k * route_cap + cts[k]].clone())
+            sim_lists = (torch.cat(inbox[0]).contiguous(), torch.cat(inbox[1]).contiguous())
+
     def step(record: bool) -> None:
         # every rank checks its own slice for duplicate sequences; the flags are OR-ed below
-        dup = ctx.d1_index_build(first, count)
+        if routed:
+            ctx.d1_route_slice(first, count, sim_world or world, d_route, route_cap, d_route_counts)
+            ids_p, ids_s = sim_lists if sim_world else sharding.exchange_routed_ids(d_route, d_route_counts, route_cap)
+            torch.cuda.current_stream(dev).synchronize()      # (the lists are torch's work; the context runs on its own stream)
+            dup = ctx.d1_index_build_routed(ids_p, int(ids_p.numel()), ids_s, int(ids_s.numel()))
+        else:
+            dup = ctx.d1_index_build(first, count)
         if world > 1:
             dup_flag.fill_(1 if dup else 0)
             dist.all_reduce(dup_flag, op=dist.ReduceOp.MAX)
@@ -593,7 +625,8 @@ def main() -> None:
                 "db_amplicons": n_total,
                 "step": "swa_d1_index_build + swa_d1_network_device (B1 seam), db and CSR resident in HBM"
                         + ("; ownership by anchor group, links exchanged all-to-all by seed range, RCCL all-gather of CSR slices"
-                           if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else ""),
+                           if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else "")
+                        + ("; routed index build (swa_d1_route_slice, ids all-to-all, swa_d1_index_build_routed)" if routed else ""),
                 "sharding": ("owned" if owned else "range") if (sim_world or world) > 1 else "none",
                 "neighbour_links": int(hits_seen[0]),
                 "phase_ms": {"seqhash": timings[0], "table_bloom_build": timings[1], "dup_check": timings[2],

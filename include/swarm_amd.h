@@ -135,7 +135,7 @@ int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world);
       (0 = prefix side, 1 = suffix side) and per owning rank, the ids of the slice whose key that rank owns —
       d_ids[(index * world + owner) * cap + ..], d_counts[index * world + owner]; d_counts[2 * world] != 0 reports a
       region that was too small (cap >= 1.5 * count / world + 1024 never is, ownership being hashed).  Device
-      pointers; asynchronous on the context's stream.
+      pointers; the lists and counts are complete when the call returns.
    2. the ranks exchange the lists all-to-all (RCCL / torch.distributed: 8 bytes per amplicon in total);
    3. every rank builds its indexes from what it received: swa_d1_index_build_routed(ids of index 0, of index 1) —
       as swa_d1_index_build under swa_d1_set_ownership(rank, world), which must have been called, but from the lists.

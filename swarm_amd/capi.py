@@ -369,7 +369,7 @@ class Context:
     def d1_route_slice(self, first: int, count: int, world: int, d_ids, cap: int, d_counts) -> None:
         """Routed multi-GPU index build, step 1 (swa_d1_route_slice): the ids of [first, first+count) grouped by the
         rank that owns their prefix-side / suffix-side key.  d_ids: device int32/uint32 tensor [2 * world * cap],
-        d_counts: device tensor [2 * world + 1] (anything with data_ptr()); asynchronous on the context's stream."""
+        d_counts: device tensor [2 * world + 1] (anything with data_ptr()); complete on return."""
         self._check(self.lib.swa_d1_route_slice(self.h, first, count, world, C.c_void_p(d_ids.data_ptr()), cap,
                                                 C.c_void_p(d_counts.data_ptr())))
 

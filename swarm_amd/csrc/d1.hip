@@ -1806,6 +1806,9 @@ extern "C" int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count,
                        ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, first, count, world, ctx->anchor_a, ctx->anchor_b, d_ids, cap, d_counts);
   }
   SWA_HIP(ctx, hipGetLastError());
+  // the caller reads the counts next (and may do so from another stream: a context without a caller's stream works on
+  // its own): they are final when this returns
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SWA_OK;
 }
 

@@ -135,6 +135,33 @@ def exchange_owned_links(links: torch.Tensor, counts: list, group=None):
     return offsets, neighbours
 
 
+def exchange_routed_ids(d_ids: torch.Tensor, d_counts: torch.Tensor, cap: int, group=None):
+    """Routed index build, step 2: what swa_d1_route_slice left on every rank — for each anchor index (0 prefix side,
+    1 suffix side) and each owning rank the ids of the rank's own slice, d_ids[(index * world + owner) * cap + ..],
+    d_counts[index * world + owner] — travels all-to-all; every rank gets back the members of the groups it owns.
+
+    Returns (ids_prefix int32 [m0], ids_suffix int32 [m1]) on the tensors' device: the arguments of
+    swa_d1_index_build_routed.  Collectives: all-to-all of the 2 counts per pair of ranks, all-to-all of the ids
+    (4 bytes per amplicon and index in total: nothing here is proportional to the database on any one rank)."""
+    world = dist.get_world_size(group)
+    dev = d_ids.device
+    assert int(d_counts[2 * world]) == 0, "swa_d1_route_slice: a destination region overflowed"
+    send = d_counts[:2 * world].to(torch.int64).view(2, world).t().contiguous()          # [owner, index]
+    recv = torch.empty_like(send)                                                          # [source, index]
+    dist.all_to_all_single(recv, send, group=group)
+    send_h, recv_h = send.tolist(), recv.tolist()
+    regions = d_ids.view(2 * world, cap)
+    out_buf = torch.cat([regions[index * world + owner, :send_h[owner][index]] for owner in range(world) for index in range(2)])
+    got = torch.empty(sum(a + b for a, b in recv_h), dtype=d_ids.dtype, device=dev)
+    dist.all_to_all_single(got, out_buf, output_split_sizes=[a + b for a, b in recv_h], input_split_sizes=[a + b for a, b in send_h],
+                           group=group)
+    pieces, at = ([], []), 0
+    for a, b in recv_h:
+        pieces[0].append(got[at: at + a]); pieces[1].append(got[at + a: at + a + b])
+        at += a + b
+    return torch.cat(pieces[0]).contiguous(), torch.cat(pieces[1]).contiguous()
+
+
 def combine_grafts(graft_cand, counters, device=None, group=None):
     """Fastidious pass split over ranks by heavy-amplicon slice (swa_d1_fastidious_shard):
     the reference keeps, per light amplicon, the smallest heavy id that reaches it

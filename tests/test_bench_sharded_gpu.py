@@ -21,11 +21,14 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def test_two_ranks_gather_the_whole_network():
+@pytest.mark.parametrize("build", ["routed", "streamed"])
+def test_two_ranks_gather_the_whole_network(build):
+    """build = routed: every rank keys its own slice, the ids travel all-to-all (sharding.exchange_routed_ids), the
+    indexes come from the lists; streamed: every rank walks the whole database for the keys it owns."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(S.ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--per-gpu", "150000", "--seed", "5", "--dev-backend", "gloo"]
+           "--per-gpu", "150000", "--seed", "5", "--dev-backend", "gloo", "--build", build]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
