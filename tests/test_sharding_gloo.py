@@ -187,3 +187,52 @@ def test_owned_links_merge_into_the_network(tmp_path, world, mode):
                         str(fa), mode], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == world
+
+
+ROUTE_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, sys.argv[1])
+    from swarm_amd import sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = 10007
+    owner = lambda ids, index: (ids * (2654435761 if index == 0 else 40503) >> 7) % world        # stands in for the key's owner
+    parts = sharding.partition_even(n, world)
+    first, count = parts[rank]
+    cap = 3 * count // (2 * world) + 1024
+    d_ids = torch.zeros(2 * world * cap, dtype=torch.int32)
+    d_counts = torch.zeros(2 * world + 1, dtype=torch.int32)
+    mine = np.arange(first, first + count, dtype=np.int64)
+    for index in range(2):
+        own = owner(mine, index)
+        for o in range(world):
+            sel = mine[own == o]
+            k = index * world + o
+            d_ids[k * cap: k * cap + len(sel)] = torch.from_numpy(sel.astype(np.int32))
+            d_counts[k] = len(sel)
+    got = sharding.exchange_routed_ids(d_ids, d_counts, cap)
+    everybody = np.arange(n, dtype=np.int64)
+    for index in range(2):
+        want = everybody[owner(everybody, index) == rank]                      # sources in rank order, ids ascending inside
+        assert np.array_equal(got[index].numpy().astype(np.int64), want), (rank, index)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+''')
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_routed_ids_reach_their_owners(tmp_path, world):
+    """sharding.exchange_routed_ids: what swa_d1_route_slice leaves on every rank (ids of its slice by owning rank and
+    index) arrives, all-to-all, as the member lists of swa_d1_index_build_routed."""
+    script = tmp_path / "route_worker.py"
+    script.write_text(ROUTE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), str(S.ROOT)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == world
