@@ -99,7 +99,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_fpatterns, &ctx->d_queue, &ctx->d_fcounters, &ctx->d_scan_est, &ctx->d_scan_swarmed,
                        &ctx->d_scan_targets, &ctx->d_scan_diffs, &ctx->d_scan_hits, &ctx->d_scan_counters, &ctx->d_scan_cand, &ctx->d_scan_seeds, &ctx->d_scan_compares, &ctx->d_aux, &ctx->d_acounters,
                        &ctx->d_afallback, &ctx->d_arank, &ctx->d_rank_tmp, &ctx->d_wfa, &ctx->d_long_rows, &ctx->d_seg_fill, &ctx->d_seg_base, &ctx->d_akeys[0], &ctx->d_akeys[1], &ctx->d_acounts[0], &ctx->d_acounts[1],
-                       &ctx->d_acursor[0], &ctx->d_acursor[1], &ctx->d_aoffsets[0], &ctx->d_aoffsets[1], &ctx->d_aslot[0],
+                       &ctx->d_aoffsets[0], &ctx->d_aoffsets[1], &ctx->d_aslot[0],
                        &ctx->d_aslot[1], &ctx->d_aitems[0], &ctx->d_aitems[1], &ctx->d_ainfo[0], &ctx->d_ainfo[1], &ctx->d_apos[0], &ctx->d_apos[1], &ctx->d_afp[0], &ctx->d_afp[1],
                        &ctx->d_frole, &ctx->d_fkeys, &ctx->d_fcnt, &ctx->d_foff, &ctx->d_fslot, &ctx->d_fmembers, &ctx->d_fitems,
                        &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster}) {

@@ -76,13 +76,15 @@ struct swa_ctx {
   bool db_run32 = false;         // some sequence starts with 32 equal nucleotides
   bool windows_ready = false;    // the anchor windows of this database are known (choose_anchor_windows + the safety net):
   uint32_t windows_chosen = 0;   // anchor_a = anchor_b = this
-  bool pair_lists = false;       // the anchor indexes carry the work lists of the pair kernels (k_anchor_items_classes)
+  bool pair_lists = false;       // the anchor indexes carry the work lists of the pair kernels (k_scan_apply_lists)
   bool aux_needed = true;        // some anchor group is served by the enumerating kernels (they read d_seqhash / d_aux)
   bool aux_complete = false;     // d_seqhash / d_aux cover every amplicon that has an anchor (lean build with world = 1)
   uint32_t owner_rank = 0, owner_world = 1;   // swa_d1_set_ownership: this context serves the anchor groups of one rank
   uint32_t anchor_slack = 0;     // 1 after a share-sized anchor table overflowed: size for the whole range
   uint32_t anchor_a = 0, anchor_b = 0;   // anchor windows moved inwards by this many nt ("window mode", chosen at index build)
-  swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_acursor[2], d_aoffsets[2], d_aslot[2], d_aitems[2], d_ainfo[2], d_apos[2], d_afp[2];
+  // d_acounts: the slot tables (tag | group size); d_akeys[0]: scratch of the window sample; d_ainfo: member records in
+  // group order; d_apos: position inside the group; d_afp: sequence fingerprints per amplicon / in group order
+  swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_aoffsets[2], d_aslot[2], d_aitems[2], d_ainfo[2], d_apos[2], d_afp[2];
   swa_dbuf d_acounters, d_afallback, d_arank, d_rank_tmp;
   swa_dbuf d_seg_fill;           // u32 fill of every per-wave edge segment
   swa_dbuf d_seg_base;           // u64 start of every segment in the compacted edge list (swa_d1_network_edges_device)
