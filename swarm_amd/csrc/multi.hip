@@ -32,6 +32,7 @@ struct swa_multi {
   std::vector<int> devices;
   std::vector<ncclComm_t> comms;       // empty: in-process copies (several ranks on one device)
   std::vector<swa_dbuf> links, gathered;
+  std::vector<swa_dbuf> routed, routed_counts, inbox;   // routed index build: a rank's outgoing id lists, their counts, what it received
   std::vector<uint64_t> link_cap;
   std::string err;
 };
@@ -143,6 +144,9 @@ extern "C" int swa_multi_create(const int * devices, int ndevices, swa_multi ** 
   }
   m->links.resize((size_t)ndevices);
   m->gathered.resize((size_t)ndevices);
+  m->routed.resize((size_t)ndevices);
+  m->routed_counts.resize((size_t)ndevices);
+  m->inbox.resize((size_t)ndevices);
   m->link_cap.assign((size_t)ndevices, 0);
   const std::set<int> distinct(m->devices.begin(), m->devices.end());
   const char * force = getenv("SWARM_AMD_FORCE_RCCL");       // test hook: RCCL even for a single rank
@@ -160,6 +164,9 @@ extern "C" void swa_multi_destroy(swa_multi * m) {
     (void)hipSetDevice(m->devices[r]);
     swa_release(m->links[r]);
     swa_release(m->gathered[r]);
+    swa_release(m->routed[r]);
+    swa_release(m->routed_counts[r]);
+    swa_release(m->inbox[r]);
   }
   for (auto & c : m->comms) { (void)ncclCommDestroy(c); }
   for (auto * c : m->ctx) { swa_ctx_destroy(c); }
@@ -178,6 +185,78 @@ extern "C" int swa_multi_db_upload(swa_multi * m, const swa_db_view * host) {
   return on_all(m, [&](int r) { return swa_db_upload(m->ctx[(size_t)r], host); });
 }
 
+// Index build of all ranks WITHOUT any of them walking the whole database (swa_d1_route_slice / swa_d1_index_build_routed):
+// every rank keys its own slice, the id lists travel all-to-all — grouped ncclSend / ncclRecv over RCCL, device-to-
+// device copies when the ranks share a device —, every rank builds its indexes from what it received.
+// *routed = false when a destination region overflowed (never with hashed ownership): the caller builds the other way.
+static int routed_index_build(swa_multi * m, std::vector<int> & dup, bool * routed) {
+  const int world = (int)m->ctx.size();
+  const uint32_t n = m->ctx[0]->db.n;
+  *routed = false;
+  std::vector<uint32_t> first((size_t)world + 1, 0);
+  for (int r = 0; r <= world; ++r) { first[(size_t)r] = (uint32_t)((uint64_t)n * (uint64_t)r / (uint64_t)world); }
+  const uint64_t cap = 3ull * ((uint64_t)n / (uint64_t)world + 1) / (2ull * (uint64_t)world) + 1024;
+  const size_t lists = 2 * (size_t)world;
+  std::vector<std::vector<uint32_t>> cnt((size_t)world, std::vector<uint32_t>(lists + 1, 0));
+  int rc = on_all(m, [&](int r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    SWA_HIP(c, hipSetDevice(c->device));
+    SWA_TRY(swa_d1_set_ownership(c, (uint32_t)r, (uint32_t)world));
+    SWA_TRY(swa_reserve(c, m->routed[(size_t)r], lists * cap * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(c, m->routed_counts[(size_t)r], (lists + 1) * sizeof(uint32_t)));
+    SWA_TRY(swa_d1_route_slice(c, first[(size_t)r], first[(size_t)r + 1] - first[(size_t)r], (uint32_t)world,
+                               static_cast<uint32_t *>(m->routed[(size_t)r].ptr), cap, static_cast<uint32_t *>(m->routed_counts[(size_t)r].ptr)));
+    SWA_HIP(c, hipMemcpy(cnt[(size_t)r].data(), m->routed_counts[(size_t)r].ptr, (lists + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return (int)SWA_OK;
+  });
+  if (rc != SWA_OK) { return rc; }
+  for (int r = 0; r < world; ++r) { if (cnt[(size_t)r][lists] != 0) { return SWA_OK; } }
+  // rank r receives, per index, the lists of the sources in rank order: inbox[r] = [index 0: s = 0, 1, ..][index 1: ..]
+  std::vector<uint32_t> m0((size_t)world, 0), m1((size_t)world, 0);
+  for (int r = 0; r < world; ++r) {
+    for (int s2 = 0; s2 < world; ++s2) { m0[(size_t)r] += cnt[(size_t)s2][(size_t)r]; m1[(size_t)r] += cnt[(size_t)s2][(size_t)world + (size_t)r]; }
+    swa_ctx * c = m->ctx[(size_t)r];
+    if (hipSetDevice(c->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+    rc = swa_reserve(c, m->inbox[(size_t)r], ((uint64_t)m0[(size_t)r] + m1[(size_t)r] + 1) * sizeof(uint32_t));
+    if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
+  }
+  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupStart()); }
+  for (int r = 0; r < world; ++r) {
+    uint64_t at[2] = {0, m0[(size_t)r]};
+    for (int s2 = 0; s2 < world; ++s2) {
+      for (int index = 0; index < 2; ++index) {
+        const size_t list = (size_t)index * (size_t)world + (size_t)r;
+        const uint32_t count = cnt[(size_t)s2][list];
+        if (count == 0) { continue; }
+        const uint32_t * src = static_cast<const uint32_t *>(m->routed[(size_t)s2].ptr) + list * cap;
+        uint32_t * dst = static_cast<uint32_t *>(m->inbox[(size_t)r].ptr) + at[index];
+        at[index] += count;
+        if (!m->comms.empty()) {
+          NCCL_OK(m, ncclSend(src, count, ncclUint32, r, m->comms[(size_t)s2], m->ctx[(size_t)s2]->stream));
+          NCCL_OK(m, ncclRecv(dst, count, ncclUint32, s2, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
+        } else {
+          if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess ||
+              hipMemcpyAsync(dst, src, (size_t)count * sizeof(uint32_t), hipMemcpyDefault, m->ctx[(size_t)r]->stream) != hipSuccess) {
+            return fail(m, SWA_E_DEVICE, "device-to-device copy of a routed id list failed");
+          }
+        }
+      }
+    }
+  }
+  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupEnd()); }
+  for (int k = 0; k < world; ++k) {
+    if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
+      return fail(m, SWA_E_DEVICE, "synchronising the exchange of the routed id lists failed");
+    }
+  }
+  *routed = true;
+  return on_all(m, [&](int r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    const uint32_t * in = static_cast<const uint32_t *>(m->inbox[(size_t)r].ptr);
+    return swa_d1_index_build_routed(c, in, m0[(size_t)r], in + m0[(size_t)r], m1[(size_t)r], &dup[(size_t)r]);
+  });
+}
+
 // the whole network of the database as a CSR on the host (buffers and capacity protocol of swa_d1_network)
 extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint64_t cap,
                                     uint64_t * total, int * has_duplicates) {
@@ -188,10 +267,21 @@ extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint
   // 1. every rank indexes and probes the anchor groups it owns
   std::vector<int> dup((size_t)world, 0);
   std::vector<uint64_t> count((size_t)world, 0);
-  int rc = on_all(m, [&](int r) {
+  // (SWARM_AMD_MULTI_BUILD=streamed: every rank walks the whole database for the keys it owns, as before the routed build)
+  const char * env_build = getenv("SWARM_AMD_MULTI_BUILD");
+  bool routed = false;
+  int rc = SWA_OK;
+  if (world > 1 && !(env_build != nullptr && env_build[0] == 's')) {
+    rc = routed_index_build(m, dup, &routed);
+    if (rc != SWA_OK) {
+      if (has_duplicates != nullptr) { *has_duplicates = 0; for (int d : dup) { *has_duplicates |= d; } }
+      return rc;
+    }
+  }
+  rc = on_all(m, [&](int r) {
     swa_ctx * c = m->ctx[(size_t)r];
     SWA_TRY(swa_d1_set_ownership(c, (uint32_t)r, (uint32_t)world));
-    int rc2 = swa_d1_index_build(c, &dup[(size_t)r]);
+    int rc2 = routed ? (int)SWA_OK : swa_d1_index_build(c, &dup[(size_t)r]);
     if (rc2 != SWA_OK) { return rc2; }
     if (m->link_cap[(size_t)r] == 0) { m->link_cap[(size_t)r] = 4ull * n / (uint64_t)world + 65536; }
     for (;;) {

@@ -33,11 +33,15 @@ def light_set(tmp_path_factory):
     return fa, hdb, off, nb, flags, stats, graft, counters
 
 
-@pytest.mark.parametrize("devices,rccl", [([0, 0], False), ([0, 0, 0], False), ([0], True)])
-def test_multi_matches_single(light_set, monkeypatch, devices, rccl):
+@pytest.mark.parametrize("devices,rccl,build", [([0, 0], False, "routed"), ([0, 0, 0], False, "routed"), ([0, 0, 0], False, "streamed"),
+                                                ([0], True, "routed")])
+def test_multi_matches_single(light_set, monkeypatch, devices, rccl, build):
+    """build: how the ranks get the members of their anchor groups — routed: every rank keys its slice and the ids travel
+    to the owners (swa_d1_route_slice / swa_d1_index_build_routed); streamed: every rank walks the whole database."""
     fa, hdb, off, nb, flags, stats, graft, counters = light_set
     if rccl:
         monkeypatch.setenv("SWARM_AMD_FORCE_RCCL", "1")
+    monkeypatch.setenv("SWARM_AMD_MULTI_BUILD", build)
     m = MultiContext(devices)
     assert m.uses_rccl() is rccl
     m.upload_hostdb(hdb)
