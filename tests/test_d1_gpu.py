@@ -27,7 +27,7 @@ def test_network_matches_oracle(gpu_ctx, tmp_path, n, L, seed, ncb):
     db = S.db_from_fasta(fa)
     _upload(gpu_ctx, db)
     assert gpu_ctx.d1_index_build() is False
-    # intermediates are bit-exact: Zobrist table, sequence hashes, Bloom bitmap
+    # intermediates are bit-exact: Zobrist table, sequence hashes, table size (the debug readers build the database-wide index)
     lib = S.oracle()
     zob = S.oracle_zobrist(db.longest + 2)
     assert np.array_equal(gpu_ctx.d1_debug(2, 4 * (db.longest + 2)), zob)
