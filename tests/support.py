@@ -224,6 +224,28 @@ def oracle_d1_network(db: Db, no_cluster_breaking: bool = False, first: int = 0,
         lib.orc_d1_index_free(ix)
 
 
+class OrcD1IndexHead(C.Structure):
+    """the leading fields of orc_d1_index (oracle/swarm_oracle.h): enough to read the Bloom bitmap"""
+    _fields_ = [("table_size", C.c_uint64), ("hash_values", C.c_void_p), ("hash_data", C.c_void_p), ("hash_occupied", C.c_void_p),
+                ("bloom", C.POINTER(C.c_uint64)), ("bloom_mask", C.c_uint64)]
+
+
+def oracle_d1_bloom(db: Db) -> np.ndarray:
+    """the blocked Bloom filter in front of the amplicon table as the oracle builds it (src/bloompat.cc; one bit per
+    table slot x 8 = table_size / 8 64-bit words, at least one)"""
+    lib = oracle()
+    odb = orc_db(db)
+    dup = C.c_int(0)
+    ix = lib.orc_d1_index_build(C.byref(odb), C.byref(dup))
+    assert ix
+    try:
+        head = C.cast(ix, C.POINTER(OrcD1IndexHead)).contents
+        words = int(head.bloom_mask) + 1
+        return np.ctypeslib.as_array(head.bloom, shape=(words,)).copy()
+    finally:
+        lib.orc_d1_index_free(ix)
+
+
 def oracle_derep(db: Db) -> np.ndarray:
     lib = oracle()
     lib.orc_derep.restype = C.c_int

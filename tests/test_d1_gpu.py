@@ -27,7 +27,8 @@ def test_network_matches_oracle(gpu_ctx, tmp_path, n, L, seed, ncb):
     db = S.db_from_fasta(fa)
     _upload(gpu_ctx, db)
     assert gpu_ctx.d1_index_build() is False
-    # intermediates are bit-exact: Zobrist table, sequence hashes, table size (the debug readers build the database-wide index)
+    # intermediates are bit-exact: Zobrist table, sequence hashes, table size, Bloom bitmap (the debug readers build the
+    # database-wide index)
     lib = S.oracle()
     zob = S.oracle_zobrist(db.longest + 2)
     assert np.array_equal(gpu_ctx.d1_debug(2, 4 * (db.longest + 2)), zob)
@@ -35,6 +36,8 @@ def test_network_matches_oracle(gpu_ctx, tmp_path, n, L, seed, ncb):
                           for i in range(db.n)], dtype=np.uint64)
     assert np.array_equal(gpu_ctx.d1_debug(0, db.n), want_hash)
     assert gpu_ctx.d1_table_size() == lib.orc_hashtable_size(db.n)
+    want_bloom = S.oracle_d1_bloom(db)
+    assert np.array_equal(gpu_ctx.d1_debug(1, len(want_bloom)), want_bloom)
     off, nb = gpu_ctx.d1_network(ncb)
     woff, wnb, _ = _oracle_sorted_rows(db, ncb)
     assert np.array_equal(off, woff)
