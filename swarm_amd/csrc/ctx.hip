@@ -105,6 +105,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster}) {
     swa_release(*b);
   }
+  for (auto & b : ctx->d_stream) { swa_release(b); }
   if (ctx->h_scan_pinned != nullptr) { (void)hipHostFree(ctx->h_scan_pinned); }
   if (ctx->ev_ready) { for (auto & e : ctx->ev) { (void)hipEventDestroy(e); } }
   if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); }
@@ -164,6 +165,9 @@ static void invalidate(swa_ctx * ctx) {
   ctx->db_unordered = false;
   ctx->props_ready = false;
   ctx->windows_ready = false;
+  ctx->lines_ready = false;
+  ctx->stream_index = false;
+  ctx->stream_extra_bits = 0;
   ctx->anchor_a = ctx->anchor_b = 0;
   ctx->qgram_ready = false;
   ctx->scan_ready = false;

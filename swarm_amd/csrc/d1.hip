@@ -1498,6 +1498,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n = ctx->db.n;
   ctx->d1_ready = false;
+  ctx->csr_ready = false;                                   // (a resident network belongs to the index it was made from)
   ctx->anchor_ready = false;
   ctx->full_index = false;
   ctx->aux_complete = false;
@@ -1536,8 +1537,11 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     // allows (every seed needs win_a + win_b + 65 nt), and the setting with the fewest stranded members wins.  Window
     // mode needs the pair kernels (sequences up to 256 nt); SWA_D1_WINDOWS=0 switches the search off.
     const char * env_win = getenv("SWA_D1_WINDOWS");
-    // (safety net behind the sample: the real build still found too many stranded members — try the next offsets)
-    if (!routed && needs_table && mass > n / 64u && ctx->db.longest <= 256u && !(env_win != nullptr && env_win[0] == '0')) {
+    // (safety net behind the sample: the real build still found too many stranded members — try the next offsets.
+    // Single GPU only: under ownership `mass` counts the oversized groups THIS rank owns, the ranks would settle on
+    // different windows and divide the pairs differently; there the sampled choice — the same on every rank — stands
+    // and oversized groups take the plain kernel)
+    if (!routed && ctx->owner_world == 1 && needs_table && mass > n / 64u && ctx->db.longest <= 256u && !(env_win != nullptr && env_win[0] == '0')) {
       uint32_t best = sampled, best_mass = mass;
       for (uint32_t w = sampled + 32u; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
         ctx->anchor_a = ctx->anchor_b = w;
@@ -1835,6 +1839,7 @@ extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world
   if (rank != ctx->owner_rank || world != ctx->owner_world) {
     ctx->owner_rank = rank;
     ctx->owner_world = world;
+    ctx->csr_ready = false;
     ctx->anchor_ready = false;                               // the next network call indexes this rank's groups
     ctx->anchor_slack = 0;
   }
@@ -1845,6 +1850,7 @@ extern "C" int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t f
                               uint64_t * offsets, uint32_t * neighbours, uint64_t cap, uint64_t * total) {
   if (ctx == nullptr) { return SWA_E_ARG; }
   if (offsets == nullptr || total == nullptr) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: null buffer"); }
+  ctx->csr_ready = false;                                   // (d_offsets_tmp / d_nb_tmp are about to hold this call's rows)
   SWA_TRY(swa_reserve(ctx, ctx->d_offsets_tmp, (uint64_t(count) + 1) * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_nb_tmp, (cap > 0 ? cap : 1) * sizeof(uint32_t)));
   const int rc = swa_d1_network_device(ctx, no_cluster_breaking, first, count,

@@ -559,6 +559,7 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
   }
   const uint64_t nedges = ctx->dn_edges;
   *total = nedges;
+  ctx->csr_ready = false;                                   // (d_offsets_tmp / d_nb_tmp now hold this graph)
   SWA_TRY(swa_reserve(ctx, ctx->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
   const unsigned long long * sorted = ctx->dn_work != 0 ? static_cast<const unsigned long long *>(ctx->d_dn_keys.ptr) + ctx->dn_work : nullptr;
   const uint32_t * svals = ctx->dn_work != 0 ? static_cast<const uint32_t *>(ctx->d_dn_vals.ptr) + ctx->dn_work : nullptr;

@@ -15,6 +15,7 @@
 #include "../../../include/swarm_amd_host.h"
 
 #include <getopt.h>
+#include <sys/prctl.h>
 #include <sys/resource.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -227,22 +228,28 @@ void check_writer(int rc, const char * what) {
 
 // Process exit is not free here: after the last output file is closed the kernel still has ~5 GB of page tables and the
 // amdgpu / KFD side of the process to take apart, and on the same box that takes anything from 30 ms to 400 ms (measured,
-// 10 M amplicons; freeing host or device memory first changes nothing).  Nobody should wait for that: the program runs
-// as a WORKER child; the FRONT process — the one the caller started — returns as soon as the worker reports that every
-// output file is complete and closed, with the worker's status, and otherwise with whatever the worker ended with
-// (error exit, signal).  SWARM_AMD_FOREGROUND_EXIT=1: one process, as before.
+// 10 M amplicons; freeing host or device memory first changes nothing).  By default the program is ONE process, like the
+// reference: whoever waits for it waits for that too, a kill reaches the GPU work, resource accounting sees everything.
+// SWARM_AMD_DETACHED_EXIT=1 (opt-in, for an interactive caller who only wants the files): the program runs as a WORKER
+// child (killed with the front: PR_SET_PDEATHSIG) and the FRONT process — the one the caller started — returns as soon
+// as the worker reports that every output file is complete and closed, with the worker's status, and otherwise with
+// whatever the worker ended with (error exit, signal).
 int g_done_fd = -1;
 pid_t g_worker = -1;
 
 void forward_signal(int sig) { if (g_worker > 0) { (void)kill(g_worker, sig); } }
 
 void front_and_worker() {
-  if (std::getenv("SWARM_AMD_FOREGROUND_EXIT") != nullptr) { return; }
+  const char * detached = std::getenv("SWARM_AMD_DETACHED_EXIT");
+  if (detached == nullptr || detached[0] != '1') { return; }
   int fds[2];
   if (pipe(fds) != 0) { return; }
   const pid_t pid = fork();                    // (no threads, no HIP runtime yet)
   if (pid < 0) { close(fds[0]); close(fds[1]); return; }
-  if (pid == 0) { close(fds[0]); g_done_fd = fds[1]; return; }
+  if (pid == 0) {
+    (void)prctl(PR_SET_PDEATHSIG, SIGKILL);    // (a front that is killed outright cannot forward anything)
+    close(fds[0]); g_done_fd = fds[1]; return;
+  }
   g_worker = pid;
   close(fds[1]);
   for (int sig : {SIGINT, SIGTERM, SIGHUP, SIGQUIT}) { (void)std::signal(sig, forward_signal); }
@@ -355,7 +362,11 @@ int main(int argc, char ** argv) {
       if (swa_multi_create(devices.data(), (int)devices.size(), &multi) != SWA_OK) {
         die(multi != nullptr ? swa_multi_last_error(multi) : "no usable gfx950 GPU (this build has no CPU fallback).");
       }
+      if (std::getenv("SWARM_AMD_MULTI_REPORT") != nullptr) {      // (tools/scale_check.sh asserts on this line)
+        std::fprintf(stderr, "multi: %d ranks, exchange = %s\n", swa_multi_size(multi), swa_multi_uses_rccl(multi) ? "rccl" : "device-to-device copies");
+      }
       if (swa_multi_db_upload(multi, &view) != SWA_OK) { die(swa_multi_last_error(multi)); }
+      stamp("database uploaded (all ranks)");
       ctx = swa_multi_ctx(multi, 0);
     } else {
       if (early_rc != SWA_OK || early_ctx == nullptr) { die("no usable gfx950 GPU (this build has no CPU fallback)."); }

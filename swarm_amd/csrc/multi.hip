@@ -136,18 +136,19 @@ extern "C" int swa_multi_create(const int * devices, int ndevices, swa_multi ** 
   auto * m = new swa_multi();
   *out = m;
   m->devices.assign(devices, devices + ndevices);
-  for (int r = 0; r < ndevices; ++r) {
-    swa_ctx * c = nullptr;
-    const int rc = swa_ctx_create(devices[r], nullptr, &c);
-    if (rc != SWA_OK) { m->err = "no usable gfx950 GPU with index " + std::to_string(devices[r]); return rc; }
-    m->ctx.push_back(c);
-  }
+  // (per-rank buffers first: swa_multi_destroy walks them for every context that exists, also after a failure below)
   m->links.resize((size_t)ndevices);
   m->gathered.resize((size_t)ndevices);
   m->routed.resize((size_t)ndevices);
   m->routed_counts.resize((size_t)ndevices);
   m->inbox.resize((size_t)ndevices);
   m->link_cap.assign((size_t)ndevices, 0);
+  for (int r = 0; r < ndevices; ++r) {
+    swa_ctx * c = nullptr;
+    const int rc = swa_ctx_create(devices[r], nullptr, &c);
+    if (rc != SWA_OK) { m->err = "no usable gfx950 GPU with index " + std::to_string(devices[r]); return rc; }
+    m->ctx.push_back(c);
+  }
   const std::set<int> distinct(m->devices.begin(), m->devices.end());
   const char * force = getenv("SWARM_AMD_FORCE_RCCL");       // test hook: RCCL even for a single rank
   if ((int)distinct.size() == ndevices && (ndevices > 1 || (force != nullptr && force[0] == '1'))) {
@@ -323,6 +324,7 @@ extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint
       SWA_TRY(swa_reserve(c0, c0->d_scan_hits, bytes + 16));
       SWA_HIP(c0, rocprim::radix_sort_keys(c0->d_scan_hits.ptr, bytes, keys_in, keys_out, all, 0, 64, c0->stream));
     }
+    c0->csr_ready = false;                                   // (d_offsets_tmp / d_nb_tmp now hold the gathered network)
     SWA_TRY(swa_reserve(c0, c0->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
     hipLaunchKernelGGL(k_links_offsets, dim3(blocks_for(c0, (uint64_t)n + 1)), dim3(256), 0, c0->stream, keys_out, all, n,
                        static_cast<uint64_t *>(c0->d_offsets_tmp.ptr));

@@ -124,6 +124,16 @@ struct swa_ctx {
   uint64_t dn_pair_cap = 0, dn_comparisons = 0, dn_aligned = 0, dn_launches = 0, dn_edges = 0, dn_work = 0;
   swa_dbuf d_dn_keys, d_dn_vals;
 
+  // streaming index build / CSR assembly (d1_stream.inc)
+  bool lines_ready = false;      // d_lines holds this database's amplicon lines (made once per upload), lines_w words each
+  int lines_w = 0;
+  bool stream_index = false;     // the anchor indexes in place were made by the streaming build: members = ids in d_members
+  uint32_t stream_extra_bits = 0;   // finer partition after a bucket held more distinct keys than the group kernel's table
+  // [0] lines [1..4] records ping / pong per index [5, 6] fingerprints ping / pong [7] table slots of big buckets
+  // [8, 9] flat counts [10, 11] tile tables [12, 13] chunk starts [14, 15] scan partials [16] scalars
+  // [17, 18] members [19] oversized-group bits [20, 21] items per kind [22] link sort: records ping [23] pong
+  swa_dbuf d_stream[24];
+
   // the d = 1 network kept in d_offsets_tmp / d_nb_tmp (swa_d1_network_resident) and its clustering (cluster_gpu.hip)
   bool csr_ready = false;
   uint64_t csr_total = 0;

@@ -109,6 +109,45 @@ def test_complete_network_equals_the_reference(tmp_path, n):
         c.close()
 
 
+BIG = 100_000_000           # BASELINE configs[4]: 100 M x 150, d = 1
+
+
+def _run_cli_100m(tmp_path, tag, env=None, files="osj"):
+    import os
+    gold = GOLD[str(BIG)]["runs"]["d1"]
+    cmd = [str(BIN)] + gold["args"]
+    for k in files:
+        cmd += [FLAG[k], str(tmp_path / f"{tag}.{k}")]
+    cmd += ["-l", str(tmp_path / f"{tag}.log"), str(bench_fasta(BIG))]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SWARM_AMD_TIMING="1", **(env or {})))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in files:
+        want = gold["files"][k]
+        assert (tmp_path / f"{tag}.{k}").stat().st_size == want["bytes"], (tag, k)
+        assert md5_of(tmp_path / f"{tag}.{k}") == want["md5"], (tag, k)
+        (tmp_path / f"{tag}.{k}").unlink()
+    log = (tmp_path / f"{tag}.log").read_text()
+    for line in gold["log"]:
+        assert line in log, line
+    return r.stderr
+
+
+@pytest.mark.skipif(str(BIG) not in GOLD, reason="no 100 M golden data in fullsize.json")
+def test_cli_100m_single_context_equals_the_reference(tmp_path):
+    """BASELINE configs[4] through ONE context: 100 M x 150 bp, d = 1.  -o, -s and the complete network (-j: every
+    link, by header, in db order) md5-equal to the unmodified reference's files (tests/golden/make_fullsize.py).
+    This is where 2^28-slot tables, > 2^32-byte buffers and 32-bit cursors are first stressed."""
+    _run_cli_100m(tmp_path, "one")
+
+
+@pytest.mark.skipif(str(BIG) not in GOLD, reason="no 100 M golden data in fullsize.json")
+def test_cli_100m_eight_ranks_on_one_device_equal_the_reference(tmp_path):
+    """... and as configs[4] names it: the database and the probing sharded over 8 ranks (swa_multi_*: routed index
+    build, ownership of anchor groups, link lists gathered) — on the one GPU a test box has, so the exchange runs as
+    device-to-device copies; tools/scale_check.sh is the same comparison over RCCL on an 8-GPU node."""
+    _run_cli_100m(tmp_path, "eight", {"SWARM_AMD_DEVICES": "0,0,0,0,0,0,0,0"}, files="oj")
+
+
 def test_regrown_link_segments_give_the_same_network(tmp_path, monkeypatch):
     """network_run's retry path: per-wave link segments that start far too small are regrown until a
     run completes cleanly (and an unfinished retry loop is an error, never a truncated network)."""
