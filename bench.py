@@ -1,39 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the d=1 neighbour-finding path (seam B1) on N MI355X.
 
-One "step" = one full pass of the hot path over the synthetic amplicon set, through the
-C ABI, with the packed database already resident in HBM and the CSR left in HBM:
-    swa_d1_index_build   (sequence hashes, amplicon hash table, Bloom filter, duplicate check)
-    swa_d1_network_device (microvariant hashes -> Bloom -> table probe -> verify -> CSR)
-and, for N > 1, a MAX all-reduce of the per-rank duplicate flags, the all-to-all merge of the
-ranks' links by seed range and the RCCL all-gather of the per-rank CSR slices over xGMI.
+One "step" = one full pass of the hot path over the synthetic amplicon set, through the C ABI, with the packed
+database already resident in HBM and the CSR left in HBM:
+    swa_d1_index_build    amplicon keys -> partition -> anchor groups + work lists (+ identical sequences)
+    swa_d1_network_device pair kernels over the groups -> links -> partition by source -> CSR
+(swarm_amd/csrc/d1_stream.inc; SWA_D1_BUILD=table / SWA_D1_CSR=table select round 2's hash-table kernels) and, for
+N > 1, a MAX all-reduce of the per-rank duplicate flags, the all-to-all merge of the ranks' links by seed range and the
+RCCL all-gather of the per-rank CSR slices over xGMI.
 
-Workload at N = 1: the size BASELINE.json's metric string names — 10 M synthetic amplicons x
-150 bp, d = 1 (configs[1], 1 M x 150, is measured in the same run and reported under
-config.configs1).  For N > 1 the job is weak-scaled: the database holds N x 10 M amplicons
-(N = 8: 80 M, the order of configs[4]), replicated on every GPU.  Default sharding ("owned"):
-rank r serves the anchor groups whose key maps to r — with all their members, so the per-group
-LDS tables are built once per job, not once per rank —, which leaves it a share of the
-links; they travel all-to-all by seed range, become the rank's slice of the CSR, and the slices
-are all-gathered.  `--shard range` is the older scheme (rank r answers its contiguous slice).
+Workload at N = 1: the size BASELINE.json's metric string names — 10 M synthetic amplicons x 150 bp, d = 1
+(configs[1], 1 M x 150, is measured in the same run and reported under config.configs1).  For N > 1 the job is
+weak-scaled: the database holds N x 10 M amplicons (N = 8: 80 M, the order of configs[4]), replicated on every GPU;
+rank r serves the anchor groups whose key maps to r (routed index build), the links travel all-to-all by seed range.
 
 At N = 1 the same run also measures, after the timed region (none of it enters `value`; --no-extras skips it):
-  config.configs1      BASELINE configs[1]: the step at 1 M x 150
-  config.configs2      BASELINE configs[2]: 10 M x 150 with 30 % light amplicons, d=1 --fastidious: whole pipeline
-                       + the fastidious kernels' own time and fraction of the HBM roofline
-  config.configs3      BASELINE configs[3]: 1 M x 400, d=3: q-gram comparisons/s, aligned pairs/s, DP cells/s
-  config.skewed        the headline step on a set whose centroids all share their first / last 40 nt (conserved flanks)
-  config.whole_run     FASTA -> -o through the drop-in command line, 1 M (md5 against the reference's -o) and 10 M
-  config.host_seam_ms  swa_db_upload + swa_d1_index_build + swa_d1_network from / to host buffers (PCIe inclusive)
-  roofline.traffic     HBM bytes per step from nested rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+  config.configs1 / configs2 / configs3   BASELINE configs[1..3]
+  config.skewed / config.heavy_tail        the headline step on conserved flanks / on Zipf-sized families
+  config.whole_run                         FASTA -> -o through the drop-in command line, 1 M (md5 vs the reference) and 10 M
+  config.host_seam_ms                      swa_db_upload + index + swa_d1_network from / to host buffers (PCIe inclusive)
+  roofline.traffic / roofline.kernels      HBM bytes and VALU instructions per kernel from nested rocprofv3 --pmc passes,
+                                           corrected per access pattern as calibrated (profiles/r03/ubench_ceilings_and_pmc_calibration.json)
+  roofline.ceilings                        tools/ubench_lines on this box: streaming copy, random lines/s, atomics/s, VALU issue
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     — SURVEY.md 8(d)'s algorithmic bytes of the step / the measured duration of the
-                   step's kernels (HIP events on the launch stream) vs the 8 TB/s HBM peak, the
-                   measured HBM traffic of all its kernels, and the same for the bytes this
-                   algorithm itself has to move (own_algorithm)
-  "cpu_baseline" — the unmodified reference (oracle/_ref/swarm, kind "reference") or the C
-                   oracle (kind "port") timed on this box's host cores on a bounded sample.
+  "roofline"     — for the dominant kernel (by time) of the step: its algorithmic bytes / its duration (HIP events on
+                   the launch stream) against the 8 TB/s HBM peak, and — since that kernel is bound by VALU issue, not by
+                   HBM — its instruction rate against the measured VALU ceiling; the same per kernel group; the step as
+                   a whole; SURVEY.md 8(d)'s figure kept as reference_equivalent_rate.
+  "cpu_baseline" — the unmodified reference (oracle/_ref/swarm, kind "reference") timed on this box's host cores on a
+                   bounded sample (1 M); cpu_baseline_10M: the same on the metric's own 10 M set, once.
 """
 from __future__ import annotations
 
@@ -72,7 +68,7 @@ def gen_tool() -> Path:
     return out
 
 
-def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0, flank: int = 0) -> Path:
+def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0, flank: int = 0, zipf: float = 0.0) -> Path:
     """The synthetic amplicon set (SURVEY.md section 8d shapes; tools/gen_amplicons.c), cached in
     the temp dir.  Sets above 2 M are generated as independent blocks of <= 2 M amplicons by
     parallel processes (disjoint header numbers, seeds derived from `seed`) and concatenated.
@@ -87,10 +83,12 @@ def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0
         return fasta
     # flank > 0: all centroids share their first and last `flank` nucleotides (GEN_FLANK of the generator): the skewed
     # case for anchors at the ends of the sequences
-    fasta = Path(tempfile.gettempdir()) / (f"swa_bench_{n}x{length}_s{seed}.fa" if flank == 0 else f"swa_bench_{n}x{length}_s{seed}_f{flank}.fa")
+    # zipf > 0: family sizes follow Zipf's law (GEN_ZIPF): the largest family of every 2 M block is that share of the block
+    tag = (f"_f{flank}" if flank else "") + (f"_z{zipf}" if zipf else "")
+    fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{length}_s{seed}{tag}.fa"
     if fasta.exists():
         return fasta
-    genv = dict(os.environ, GEN_FLANK=str(flank)) if flank else None
+    genv = dict(os.environ, **({"GEN_FLANK": str(flank)} if flank else {}), **({"GEN_ZIPF": str(zipf)} if zipf else {})) if (flank or zipf) else None
     tool = str(gen_tool())
     tmp = fasta.with_suffix(f".tmp{os.getpid()}")
     block = 2_000_000
@@ -166,10 +164,10 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
                 "sample": f"oracle/ C restatement, index build + network only, {sample_n} x {length} bp, {dt:.2f} s"}
 
 
-def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, flank: int = 0) -> dict:
+def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, flank: int = 0, zipf: float = 0.0) -> dict:
     """The bench step (index build + network, db and CSR resident) on n x length amplicons."""
     from swarm_amd import Context, HostDb
-    hdb = HostDb(gen_fasta(n, args.length, args.seed, 1, 0.0, flank))
+    hdb = HostDb(gen_fasta(n, args.length, args.seed, 1, 0.0, flank, zipf))
 
     def to_dev(a: np.ndarray, as_dtype):
         return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
@@ -196,13 +194,17 @@ def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, f
     k = float(np.mean(k_ms))
     abytes = algorithmic_bytes(hdb.seqlen, total)
     windows = ctx.d1_anchor_windows()
+    t8, st = ctx.timing_read(), ctx.timing_read_stream()
     ctx.close()
-    return {"workload": f"{hdb.n} synthetic amplicons x {args.length} bp, d=1" + (f", all centroids share their first / last {flank} nt" if flank else ""),
+    return {"workload": f"{hdb.n} synthetic amplicons x {args.length} bp, d=1" + (f", all centroids share their first / last {flank} nt" if flank else "")
+            + (f", Zipf family sizes (GEN_ZIPF={zipf}: the largest family of every 2 M block holds that share of it)" if zipf else ""),
             "anchor_windows_nt_from_the_ends": list(windows), "value": hdb.n * steps / elapsed,
             "unit": "amplicons/s", "steps": steps, "ms_per_step": 1000.0 * elapsed / steps, "network_kernels_ms": k,
             "neighbour_links": int(total),
-            # (as the headline's roofline.frac: section 8(d) bytes over the whole step, here its wall time)
-            "roofline_frac": abytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS}
+            "kernel_group_ms": {"keys": st[0], "partition_keys": st[1], "groups": st[2], "pairs0": st[3], "pairs1": st[4], "partition_links": st[5], "csr_rows": st[6],
+                                "plain_kernel_and_table": t8[0] + t8[1]},
+            # (SURVEY 8(d) bytes — the reference's probing loop — over the step's wall time: an equivalent rate, see roofline)
+            "reference_equivalent_GBs": abytes / (elapsed / steps) / 1e9}
 
 
 def md5_of(path) -> str:
@@ -359,26 +361,55 @@ def whole_run(args, n: int, ref_out_md5: str | None, sample_n: int) -> dict:
                 dt = time.perf_counter() - t0
                 best = dt if best is None or dt < best else best
             res[f"n{size}"] = {"seconds": round(best, 3), "amplicons_per_s": size / best}
+            # opt-in: the front process returns when the outputs are closed, the worker's teardown is nobody's wait
+            t0 = time.perf_counter()
+            subprocess.run([str(exe), "-d", "1", "-o", f"{tmp}/o2", "-l", "/dev/null", str(fa)], check=True, env=dict(os.environ, SWARM_AMD_DETACHED_EXIT="1"))
+            res[f"n{size}"]["seconds_detached_exit"] = round(time.perf_counter() - t0, 3)
+            time.sleep(0.5)                                  # (let that worker finish before the next timing)
             if size == sample_n and ref_out_md5 is not None:
                 res[f"n{size}"]["output_md5_equals_reference"] = md5_of(f"{tmp}/o") == ref_out_md5
-    res["what"] = "swarm_amd/bin/swarm -d 1 -o: process start, FASTA read + sort + pack, upload, index, network, download, host clustering, write"
+    res["what"] = ("swarm_amd/bin/swarm -d 1 -o as ONE process (the default): process start, FASTA read + sort + pack, upload, index, network, "
+                   "agglomeration on the GPU, write, process exit; seconds_detached_exit: with SWARM_AMD_DETACHED_EXIT=1")
     return res
 
 
-def measured_traffic(args) -> dict | None:
-    """HBM bytes of one bench step's network kernels from the PMC counters: two nested rocprofv3 passes
-    (FETCH_SIZE, WRITE_SIZE; separate --pmc runs) over a short run of this very script.  FETCH_SIZE is
-    doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950; both in KiB."""
+KERNEL_GROUPS = [          # (substring of the kernel name, group, FETCH_SIZE correction: 2 streaming / 1 random lines)
+    ("k_keys", "keys", 2.0), ("k_lines_build", "lines", 2.0),
+    ("k_part_", "partition", 2.0), ("k_flat_", "partition", 2.0), ("k_seg_starts", "partition", 2.0),      # (both partitions: the counters
+    # cannot tell the key records' launches from the links')
+    ("k_group_lists", "groups", 2.0), ("k_group", "groups", 2.0),
+    ("k_d1_group_pairs<0", "pairs0", 1.0), ("k_d1_group_pairs<1", "pairs1", 1.0), ("k_d1_pairs_tiled<0", "pairs0", 1.0),
+    ("k_d1_pairs_tiled<1", "pairs1", 1.0), ("k_csr_bucket", "csr_rows", 2.0), ("k_seg_reduce", "csr_rows", 2.0),
+    # round 2's kernels (SWA_D1_BUILD=table / SWA_D1_CSR=table)
+    ("k_anchor_place", "table_index", 1.0), ("k_anchor_scatter", "table_index", 1.0), ("k_scan_", "table_index", 2.0),
+    ("k_anchor_clear", "table_index", 2.0), ("k_dup_", "table_index", 1.0), ("k_scatter_edges", "table_csr", 1.0),
+    ("k_sort_", "table_csr", 2.0),
+]
+
+
+def kernel_group(name: str):
+    for sub, group, corr in KERNEL_GROUPS:
+        if sub in name:
+            return group, corr
+    return ("other", 2.0) if "anonymous namespace" in name else (None, 2.0)
+
+
+def measured_pmc(args) -> dict | None:
+    """Per kernel group of one bench step, from nested rocprofv3 passes over a short run of this very script (separate
+    --pmc runs: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU): HBM bytes and VALU wave-instructions.  FETCH_SIZE is reported
+    in 64-byte requests: a wide streaming read shows half its bytes (x 2, MI355X_MICROARCH.md), a random line read
+    shows 64 bytes per access (x 1) — calibrated with tools/ubench_lines (profiles/r03); the pair kernels' fetches are
+    random lines, everything else streams.  WRITE_SIZE is taken as reported (exact for streaming stores)."""
     import csv
     import glob
     import shutil
     if shutil.which("rocprofv3") is None:
         return None
     steps, warm = 2, 1
-    sums = {}
+    groups: dict = {}
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, TMPDIR="/tmp")
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", f"{tmp}/{counter}", "-o", "t", "--",
                    sys.executable, str(ROOT / "bench.py"), "--steps", str(steps), "--warmup", str(warm), "--no-extras",
                    "--per-gpu", str(args.per_gpu), "--length", str(args.length), "--seed", str(args.seed)]
@@ -386,26 +417,64 @@ def measured_traffic(args) -> dict | None:
                 subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
             except Exception:
                 return None
-            total = pairs = 0.0
             rows = 0
             for f in glob.glob(f"{tmp}/{counter}/**/*counter_collection.csv", recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        # every kernel of the library (anonymous namespace; not the fills / copies of the harness)
-                        if row["Counter_Name"] == counter and "anonymous namespace" in row["Kernel_Name"]:
-                            total += float(row["Counter_Value"])
-                            rows += 1
-                            if "k_d1_" in row["Kernel_Name"]:
-                                pairs += float(row["Counter_Value"])
+                        if row["Counter_Name"] != counter:
+                            continue
+                        group, corr = kernel_group(row["Kernel_Name"])
+                        if group is None or group == "lines":          # (the lines are made once per upload, not per step)
+                            continue
+                        g = groups.setdefault(group, {"fetch_bytes": 0.0, "write_bytes": 0.0, "valu_wave_instructions": 0.0})
+                        v = float(row["Counter_Value"]) / (steps + warm)
+                        if counter == "FETCH_SIZE":
+                            g["fetch_bytes"] += v * 1024.0 * corr
+                        elif counter == "WRITE_SIZE":
+                            g["write_bytes"] += v * 1024.0
+                        else:
+                            g["valu_wave_instructions"] += v
+                        rows += 1
             if rows == 0:
                 return None
-            sums[counter] = total * 1024.0 / (steps + warm)
-            sums[counter + "_pairs"] = pairs * 1024.0 / (steps + warm)
-    return {"hbm_bytes_per_launch": 2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"], "fetch_bytes_uncorrected": sums["FETCH_SIZE"],
-            "write_bytes": sums["WRITE_SIZE"],
-            "pair_kernels_only": 2.0 * sums["FETCH_SIZE_pairs"] + sums["WRITE_SIZE_pairs"],
-            "how": "nested rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py "
-            f"--steps {steps} --warmup {warm}, all kernels of the step (index build, pair kernels, CSR), per step; FETCH_SIZE doubled (gfx950 correction)"}
+    for g in groups.values():
+        g["hbm_bytes"] = g["fetch_bytes"] + g["write_bytes"]
+    return {"per_kernel_group": groups, "hbm_bytes_per_step": sum(g["hbm_bytes"] for g in groups.values()),
+            "how": f"nested rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) over bench.py --steps {steps} --warmup {warm}, per step; "
+                   "FETCH_SIZE x 2 for the streaming kernels, x 1 for the pair kernels (random 64-byte lines), as calibrated by tools/ubench_lines"}
+
+
+def measured_ceilings() -> dict | None:
+    """tools/ubench_lines (quick): what this box's memory system and VALUs deliver for the access patterns of the step."""
+    exe = ROOT / "tools" / "ubench_lines"
+    if not exe.exists():
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            subprocess.run([str(exe), f"{tmp}/u.json", "quick"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            res = json.loads(Path(f"{tmp}/u.json").read_text())["results"]
+    except Exception:
+        return None
+    out = {}
+    for r in res:
+        out[r["test"]] = {"rate": r["rate"], "unit": r["unit"].split(" ")[0], "working_set_mb": r["working_set_mb"]}
+    return out
+
+
+def step_byte_model(n: int, links: int, index_levels: int, link_levels: int) -> dict:
+    """Algorithmic bytes of the kernel groups of one streaming step: what each group has to read
+    and write given its inputs and outputs — 64-byte amplicon lines, 8-byte key records (+ 4-byte fingerprints on the
+    prefix index), 4-byte member ids, 8-byte links."""
+    n, e = float(n), float(links)
+    return {
+        "keys": 64 * n + 20 * n,                                   # lines in; two record arrays + fingerprints out
+        "partition_keys": index_levels * (16 * n + 2 * 20 * n),    # per level: histogram pass + scatter in / out (two record sets + fingerprints)
+        "partition_links": link_levels * (8 * e + 2 * 8 * e),
+        "groups": 20 * n + 8 * n,                                  # records + fingerprints in, members out (work items: a few %)
+        "pairs0": 68 * n + 4 * e,                                  # id + line per member; half the links out
+        "pairs1": 68 * n + 4 * e,
+        "csr_rows": 8 * e + 4 * e + 8 * n,                         # links in; targets + offsets out
+    }
 
 
 def main() -> None:
@@ -593,18 +662,50 @@ def main() -> None:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = n_total * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
-        # the step's kernels: the HIP-event windows of its phases (hashes / table only when built, duplicate check,
-        # anchor indexes + work lists, pair kernels, CSR)
+        # the step's kernels: the HIP-event windows of its phases (table route: hashes / table only when built, duplicate
+        # check, anchor indexes, pair kernels, CSR; streaming route: slot 7 = keys + partition + groups, slot 4 = link
+        # partition + CSR rows) and, for the streaming route, of its kernel groups
         step_kernel_ms = float(timings[0] + timings[1] + timings[2] + timings[7] + k_ms + timings[4])
+        st = ctx.timing_read_stream()
+        streaming = st[0] > 0.0
+        group_ms = {"keys": st[0], "partition_keys": st[1], "groups": st[2], "pairs0": st[3], "pairs1": st[4], "partition_links": st[5], "csr_rows": st[6]}
         if owned:   # this rank's share of the probes: the groups it owns, about 1 / world of everything
             abytes = algorithmic_bytes(hdb.seqlen, 0) / (sim_world or world) + 4.0 * hits_seen[0]
         else:
             abytes = algorithmic_bytes(hdb.seqlen[first:first + count], hits_seen[0])
-        achieved = abytes / (step_kernel_ms * 1e-3) / 1e9
-        # what THIS algorithm has to move per amplicon: place 100 B, scatter 104 B, two pair passes
-        # 2 x 56 B + links, CSR 16 B per link + 12 B
-        own_bytes = 328.0 * count + 28.0 * hits_seen[0]
-        traffic = None                     # measured below (nested rocprofv3 PMC passes), N = 1 only
+        # levels of the two partitions (the library's arithmetic: buckets of <= 700 key records; 2^8 sources per link bucket)
+        bits = 1
+        while (count >> bits) > 700:
+            bits += 1
+        nbits = max(1, int(np.ceil(np.log2(max(2, q_count)))))
+        model = step_byte_model(count, hits_seen[0], (bits + 8) // 9, (max(1, nbits - min(8, nbits - 1)) + 8) // 9)
+        kernels = {}
+        for g, ms in group_ms.items():
+            if ms > 0.0:
+                kernels[g] = {"ms": ms, "algorithmic_bytes": model[g], "GB/s": model[g] / (ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": model[g] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        dominant = max(kernels, key=lambda g: kernels[g]["ms"]) if kernels else None
+        names = {"keys": "k_keys", "partition_keys": "k_part_hist / k_flat_* / k_part_scatter over the key records", "groups": "k_group + k_group_lists",
+                 "partition_links": "k_part_hist / k_flat_* / k_part_scatter over the links",
+                 "pairs0": "k_d1_group_pairs<0> (prefix groups)", "pairs1": "k_d1_group_pairs<1> (suffix groups)", "csr_rows": "k_csr_bucket"}
+        if streaming and dominant is not None:
+            dk = kernels[dominant]
+            roof = {"bound": "hbm", "kernel": names[dominant] + ": the kernel group with the largest share of the step's time",
+                    "achieved": dk["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dk["frac_of_hbm_peak"], "traffic": None,
+                    "algorithmic_bytes_per_launch": dk["algorithmic_bytes"], "avg_kernel_ms": dk["ms"],
+                    "kernels": kernels,
+                    "step": {"ms": step_kernel_ms, "algorithmic_bytes": sum(model.values()),
+                             "GB/s": sum(model.values()) / (step_kernel_ms * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": sum(model.values()) / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "reference_equivalent_rate": {"bytes_per_step": abytes, "GB/s": abytes / (step_kernel_ms * 1e-3) / 1e9,
+                                                  "note": "SURVEY.md 8(d) prices the REFERENCE's probing loop (one 8-byte membership word per microvariant, "
+                                                          "8.2 KB per amplicon); the pair kernels never materialise microvariants, so this is an "
+                                                          "equivalent rate, not a roofline fraction"}}
+        else:
+            achieved = abytes / (step_kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "the d=1 step of round 2's table route as one kernel group", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes,
+                    "avg_kernel_ms": step_kernel_ms, "frac_note": "SURVEY.md 8(d) bytes (the reference's probing loop), not a bound for this route"}
         out = {
             "metric": "amplicons/sec clustered (d=1)",
             "value": value,
@@ -627,26 +728,14 @@ def main() -> None:
                         + ("; ownership by anchor group, links exchanged all-to-all by seed range, RCCL all-gather of CSR slices"
                            if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else "")
                         + ("; routed index build (swa_d1_route_slice, ids all-to-all, swa_d1_index_build_routed)" if routed else ""),
+                "route": "streaming (d1_stream.inc)" if streaming else "table (round 2)",
                 "sharding": ("owned" if owned else "range") if (sim_world or world) > 1 else "none",
                 "neighbour_links": int(hits_seen[0]),
                 "phase_ms": {"seqhash": timings[0], "table_bloom_build": timings[1], "dup_check": timings[2],
                              "anchor_index_build": timings[7], "network_kernels": k_ms, "csr": timings[4]},
+                "kernel_group_ms": group_ms if streaming else None,
             },
-            "roofline": {"bound": "hbm",
-                         "kernel": "the d=1 step as one kernel group: anchor indexes (k_anchor_place, scans, k_anchor_scatter, work lists) + "
-                                   "k_d1_group_pairs x (prefix, suffix pass) + CSR (k_scatter_edges, k_sort_rows); no kernel holds more than 30 % of it; "
-                                   "duration = the HIP-event windows of the step's phases",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": abytes, "avg_kernel_ms": step_kernel_ms,
-                         "frac_note": "SURVEY.md section 8(d) prices the REFERENCE's algorithm (one 8-byte membership word per microvariant, "
-                                      "8.2 KB per amplicon). The pair kernels never materialise the microvariants, so that figure no longer "
-                                      "bounds the traffic: frac > 1 = faster than any implementation of the reference's probing could be on "
-                                      "this HBM. What bounds the step now is under own_algorithm.",
-                         "own_algorithm": {"bytes_per_launch": own_bytes, "achieved": own_bytes / (step_kernel_ms * 1e-3) / 1e9,
-                                           "frac": own_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
-                                           "bound": "64-byte random accesses and device-scope atomics (k_anchor_place, k_anchor_scatter, "
-                                                    "k_scatter_edges: 2 x 10 M CAS + counting adds, 17 M cursor adds), not streaming bandwidth",
-                                           "pair_kernels_ms": k_ms}},
+            "roofline": roof,
         }
         extras = world == 1 and not sim_world and not args.no_extras
         if world == 1 and not sim_world and not args.no_configs1 and not args.no_cpu_baseline:
@@ -668,7 +757,15 @@ def main() -> None:
                 # thread settings it is tried with inside the 10-30 s budget
                 out["cpu_baseline"] = cpu_baseline(gen_fasta(sample_n, args.length, args.seed), sample_n, args.length, args.seed)
                 ref_md5 = out["cpu_baseline"].pop("output_md5", None)
+            if not args.no_cpu_baseline and n_total > sample_n and (ROOT / "oracle" / "_ref" / "swarm").exists():
+                # the reference on the metric's own set, once (about half a minute on 16 threads)
+                t0 = time.perf_counter()
+                subprocess.run([str(ROOT / "oracle" / "_ref" / "swarm"), "-d", "1", "-t", "16", "-o", "/dev/null", "-l", "/dev/null", str(fasta)], check=True)
+                dt = time.perf_counter() - t0
+                out["cpu_baseline_10M"] = {"value": n_total / dt, "unit": "amplicons/s", "cores": 16, "kind": "reference", "seconds": round(dt, 2),
+                                           "sample": f"unmodified reference swarm 3.1.6 -d 1 -t 16, whole run on the {n_total} x {args.length} bp set of the headline"}
             for name, fn in (("skewed", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 40)),
+                             ("heavy_tail", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 0, 0.1)),
                              ("host_seam_ms", lambda: host_seam(args, n_total)),
                              ("whole_run", lambda: whole_run(args, n_total, ref_md5, sample_n)),
                              ("configs2", lambda: config2_fastidious(args, args.per_gpu)),
@@ -677,11 +774,51 @@ def main() -> None:
                     out["config"][name] = fn()
                 except Exception as e:                    # an extra must never cost the headline line
                     out["config"][name] = {"error": f"{type(e).__name__}: {e}"}
-            t = measured_traffic(args)
-            if t is not None:
-                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            ceil = measured_ceilings()
+            if ceil is not None:
+                out["roofline"]["ceilings"] = ceil
+            t = measured_pmc(args)
+            if t is not None and "kernels" in out["roofline"]:
+                per = t["per_kernel_group"]
                 out["roofline"]["traffic_detail"] = t
-                out["roofline"]["own_algorithm"]["measured_traffic_frac"] = t["hbm_bytes_per_launch"] / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                dom = max(out["roofline"]["kernels"], key=lambda g: out["roofline"]["kernels"][g]["ms"])
+                if dom in per:
+                    out["roofline"]["traffic"] = per[dom]["hbm_bytes"]
+                if "partition" in per:                          # (split over the two partitions by their algorithmic bytes)
+                    kk = out["roofline"]["kernels"]
+                    both = sum(kk[g]["algorithmic_bytes"] for g in ("partition_keys", "partition_links") if g in kk)
+                    for g in ("partition_keys", "partition_links"):
+                        if g in kk:
+                            per[g] = {k: v * kk[g]["algorithmic_bytes"] / both for k, v in per["partition"].items()}
+                for g, rec in out["roofline"]["kernels"].items():
+                    if g in per:
+                        rec["hbm_bytes_measured"] = per[g]["hbm_bytes"]
+                        rec["traffic_over_algorithmic"] = per[g]["hbm_bytes"] / rec["algorithmic_bytes"]
+                        if per[g]["valu_wave_instructions"] > 0:
+                            rec["valu_wave_instructions"] = per[g]["valu_wave_instructions"]
+                            rec["valu_wave_instructions_per_s"] = per[g]["valu_wave_instructions"] / (rec["ms"] * 1e-3)
+                # the fitting ceiling of every group: HBM streaming for the streaming kernels (the copy rate this box reaches),
+                # VALU issue for the pair kernels (and their line fetches against the random-line rate)
+                if ceil is not None:
+                    copy = ceil.get("stream_copy", {}).get("rate")
+                    valu = ceil.get("valu_3op", {}).get("rate")
+                    lines = ceil.get("gather64", {}).get("rate")
+                    for g, rec in out["roofline"]["kernels"].items():
+                        if g.startswith("pairs"):
+                            if valu and "valu_wave_instructions_per_s" in rec:
+                                rec["frac_of_valu_ceiling"] = rec["valu_wave_instructions_per_s"] / valu
+                            if lines:
+                                rec["frac_of_random_line_ceiling"] = (count / (rec["ms"] * 1e-3)) / lines
+                            rec["bound"] = "VALU issue"
+                        elif copy:
+                            rec["frac_of_measured_copy_rate"] = rec["GB/s"] / copy
+                            rec["bound"] = "HBM streaming"
+                    out["roofline"]["frac_calibrated"] = out["roofline"]["kernels"][dom].get("frac_of_valu_ceiling",
+                                                                                            out["roofline"]["kernels"][dom].get("frac_of_measured_copy_rate"))
+                    out["roofline"]["frac_calibrated_note"] = ("the dominant kernel group against the ceiling that fits it, measured on this box in this run "
+                                                               "(tools/ubench_lines): VALU wave-instructions/s for the pair kernels, float4 copy rate for the streaming kernels")
+                out["roofline"]["step"]["hbm_bytes_measured"] = t["hbm_bytes_per_step"]
+                out["roofline"]["step"]["traffic_over_algorithmic"] = t["hbm_bytes_per_step"] / out["roofline"]["step"]["algorithmic_bytes"]
         elif world == 1 and not sim_world and not args.no_cpu_baseline:
             sample_n = min(n_total, 1_000_000)
             out["cpu_baseline"] = cpu_baseline(gen_fasta(sample_n, args.length, args.seed), sample_n, args.length, args.seed)

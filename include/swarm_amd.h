@@ -89,6 +89,11 @@ int  swa_ctx_warmup(swa_ctx * ctx);
    of the most recent launches. */
 int  swa_timing_enable(swa_ctx * ctx, int on);
 int  swa_timing_read(swa_ctx * ctx, float * ms8);
+/* the kernel groups of the streaming d = 1 step (swarm_amd/csrc/d1_stream.inc), same mechanism: ms[0] amplicon keys,
+   [1] partition of the key records, [2] groups + work lists (+ identical sequences), [3] pair kernels of the prefix
+   groups, [4] of the suffix groups, [5] partition of the links by source, [6] CSR rows, [7] amplicon lines (once per
+   uploaded database) — durations of the most recent launches, 0 for a group that did not run. */
+int  swa_timing_read_stream(swa_ctx * ctx, float * ms8);
 
 /* ---- L2: database residency ---------------------------------------------------- */
 /* copy a host-resident database into HBM (replicated on this context's GPU) */
@@ -302,6 +307,22 @@ int  swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint64_t * off
 /* = swa_d1_fastidious */
 int  swa_multi_d1_fastidious(swa_multi * m, const uint8_t * is_light, uint64_t light_nt, uint32_t bloom_bits,
                              uint32_t * graft_cand, uint64_t * counters);
+
+
+/* ---- d >= 2 on several GPUs (second paragraph) --------------------------------------------------
+   Replaces the scan fan-out of src/scan.cc:221-256 under the loop of src/algo.cc:505-602.  swa_dn_set_ownership(rank,
+   world): this context makes only the window groups of swa_dn_graph whose key maps to `rank`; a pair is reported
+   through the first window it shares, and that window's group lives on one rank, so over all ranks every pair of the
+   graph is found exactly once.  swa_multi_dn_begin = swa_qgram_build + swa_search_begin on every rank;
+   swa_multi_dn_graph = swa_dn_graph: every rank finds and aligns its share, the accepted (query, target, diff)
+   triples travel to rank 0 (RCCL send / receive over xGMI, device-to-device copies for ranks sharing a GPU), which
+   sorts them into the CSR; same buffers and capacity protocol as swa_dn_graph. */
+int  swa_dn_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world);
+int  swa_multi_dn_begin(swa_multi * m, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, uint64_t d);
+int  swa_multi_dn_graph_supported(swa_multi * m);
+int  swa_multi_dn_graph(swa_multi * m, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint8_t * diffs,
+                        uint64_t cap, uint64_t * total);
+int  swa_multi_dn_graph_totals(swa_multi * m, uint64_t * out3);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,9 @@ typedef struct swa_dn_result swa_dn_result;
    Penalties after the reference's gcd reduction (src/swarm.cc:466-483). */
 int  swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
                     uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out);
+/* the same on the GPUs of a swa_multi (d >= 2 graph divided by ownership of window groups, swa_multi_dn_graph) */
+int  swa_dn_cluster_multi(swa_multi * multi, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
+                          uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out);
 void swa_dn_result_free(swa_dn_result * res);
 const char * swa_dn_result_error(const swa_dn_result * res);
 /* out3 = {number of swarms, largest swarm, max generations} (src/algo.cc:699-705) */

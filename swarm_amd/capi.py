@@ -323,6 +323,14 @@ class Context:
     def timing_enable(self, on: bool = True) -> None:
         self._check(self.lib.swa_timing_enable(self.h, int(on)))
 
+    def timing_read_stream(self) -> list:
+        """ms of the kernel groups of the streaming d=1 step: keys, partition, groups + lists, pair pass 0, pair pass 1,
+        link partition, CSR rows, amplicon lines"""
+        ms = (C.c_float * 8)()
+        self.lib.swa_timing_read_stream.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        self._check(self.lib.swa_timing_read_stream(self.h, ms))
+        return [float(x) for x in ms]
+
     def timing_read(self) -> list:
         ms = (C.c_float * 8)()
         self._check(self.lib.swa_timing_read(self.h, ms))
@@ -500,7 +508,9 @@ _DN_EXPORTS = ["swa_dn_cluster", "swa_dn_result_free", "swa_dn_result_error", "s
                "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_batch", "swa_scan_fetch", "swa_scan_totals",
                "swa_dn_graph_supported", "swa_dn_graph", "swa_dn_graph_totals",
                "swa_multi_create", "swa_multi_destroy", "swa_multi_size", "swa_multi_uses_rccl", "swa_multi_ctx", "swa_multi_last_error",
-               "swa_multi_db_upload", "swa_multi_d1_network", "swa_multi_d1_fastidious"]
+               "swa_multi_db_upload", "swa_multi_d1_network", "swa_multi_d1_fastidious", "swa_dn_set_ownership", "swa_multi_dn_begin",
+               "swa_multi_dn_graph_supported", "swa_multi_dn_graph", "swa_multi_dn_graph_totals", "swa_dn_cluster_multi",
+               "swa_timing_read_stream"]
 EXPORTS.extend(_DN_EXPORTS)
 
 
@@ -740,6 +750,25 @@ class MultiContext:
             if rc == SWA_OK:
                 return offsets, nb[:total.value]
             cap = int(total.value)
+
+    def dn_graph(self, d: int, no_cluster_breaking: bool = False, mismatch: int = 18, gapopen: int = 24, gapextend: int = 13):
+        """swa_multi_dn_begin + swa_multi_dn_graph: (offsets, neighbours, diffs) of the whole d >= 2 graph, or None when a
+        sequence is too short for d + 1 windows."""
+        lib = self.lib
+        lib.swa_multi_dn_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        lib.swa_multi_dn_graph_supported.argtypes = [C.c_void_p]
+        lib.swa_multi_dn_graph.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p]
+        self._check(lib.swa_multi_dn_begin(self.h, mismatch, gapopen, gapextend, d))
+        if not lib.swa_multi_dn_graph_supported(self.h):
+            return None
+        offsets = np.zeros(self.n + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        rc = self._check(lib.swa_multi_dn_graph(self.h, int(no_cluster_breaking), _ptr(offsets), None, None, 0, C.byref(total)), allow=(SWA_E_CAPACITY,))
+        nb = np.zeros(max(1, total.value), dtype=np.uint32)
+        df = np.zeros(max(1, total.value), dtype=np.uint8)
+        if rc == SWA_E_CAPACITY:
+            self._check(lib.swa_multi_dn_graph(self.h, int(no_cluster_breaking), _ptr(offsets), _ptr(nb), _ptr(df), total.value, C.byref(total)))
+        return offsets, nb[:total.value], df[:total.value]
 
     def d1_fastidious(self, is_light: np.ndarray, light_nt: int, bloom_bits: int = 16):
         is_light = np.ascontiguousarray(is_light, dtype=np.uint8)

@@ -127,16 +127,19 @@ extern "C" int swa_timing_enable(swa_ctx * ctx, int on) {
   return SWA_OK;
 }
 
-extern "C" int swa_timing_read(swa_ctx * ctx, float * ms8) {
-  if (ctx == nullptr || ms8 == nullptr) { return SWA_E_ARG; }
+static int timing_read(swa_ctx * ctx, float * ms, int first, int count) {
+  if (ctx == nullptr || ms == nullptr) { return SWA_E_ARG; }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int s = 0; s < 8; ++s) {
-    ms8[s] = 0.0f;
-    if (ctx->ev_ready && ctx->ev_used[s]) { (void)hipEventElapsedTime(&ms8[s], ctx->ev[2 * s], ctx->ev[2 * s + 1]); }
+  for (int s = 0; s < count; ++s) {
+    ms[s] = 0.0f;
+    if (ctx->ev_ready && ctx->ev_used[first + s]) { (void)hipEventElapsedTime(&ms[s], ctx->ev[2 * (first + s)], ctx->ev[2 * (first + s) + 1]); }
   }
   return SWA_OK;
 }
+
+extern "C" int swa_timing_read(swa_ctx * ctx, float * ms8) { return timing_read(ctx, ms8, 0, 8); }
+extern "C" int swa_timing_read_stream(swa_ctx * ctx, float * ms8) { return timing_read(ctx, ms8, 8, 8); }
 
 extern "C" int swa_ctx_synchronize(swa_ctx * ctx) {
   if (ctx == nullptr) { return SWA_E_ARG; }

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
     if (MODE == 0) {
       if (lane == 0) { a.counts[k] = row; }
     } else if (MODE == 2) {
-      if (lane == 0 && row != 0u) { atomicAdd(&a.counts[seed - a.first], row); }
+      if (lane == 0 && row != 0u && a.counts != nullptr) { atomicAdd(&a.counts[seed - a.first], row); }
     } else {
       cand_total += row;
     }
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const T * __restrict_
 // tile); the apply pass writes the offsets and drops every group into its place.
 constexpr uint32_t kListKinds = kPairClasses + 2;           // size classes | 65..pair_big | 64-seed chunks of larger groups
 
-__device__ __forceinline__ uint32_t list_kind(uint32_t g, uint32_t pair_big) {      // kListKinds: none
-  if (g < 2u || g > kGroupCap) { return kListKinds; }
+__device__ __forceinline__ uint32_t list_kind(uint32_t g, uint32_t pair_big, uint32_t group_cap = kGroupCap) {      // kListKinds: none
+  if (g < 2u || g > group_cap) { return kListKinds; }
   if (g <= kSmallGroup) { return pair_class(g); }
   return g <= pair_big ? kPairClasses : kPairClasses + 1u;
 }
@@ -915,6 +915,7 @@ __global__ __launch_bounds__(64) void k_sort_long_rows(const uint64_t * __restri
 }
 
 #include "d1_fast.inc"
+#include "d1_stream.inc"
 
 int grid_for(const swa_ctx * ctx, uint64_t items, int per_block, int max_per_cu) {
   uint64_t blocks = (items + per_block - 1) / per_block;
@@ -1040,6 +1041,7 @@ static int ensure_db_properties(swa_ctx * ctx) {
 // (re)builds the two anchor indexes for the query range [first, first + count)
 static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   ctx->anchor_ready = false;
+  ctx->stream_index = false;
   const uint32_t n = ctx->db.n;
   // Slot tables.  Safe size (anchor_slack = 1): load <= 0.5 if every anchor that gets a slot were its own group.
   // Amplicon sets are nothing like that — ten million amplicons make two million groups — and with one word per slot
@@ -1155,9 +1157,362 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   return SWA_OK;
 }
 
+// ---- the streaming build (d1_stream.inc) ------------------------------------------------------
+// SWA_D1_BUILD=table: round 2's hash-table build (k_anchor_place / k_anchor_scatter / k_scatter_edges), kept for
+// comparison and for sequences beyond 256 nt (the enumerating kernels read its structures)
+enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
+       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24 };
+
+static bool stream_enabled() {
+  const char * e = getenv("SWA_D1_BUILD");
+  return !(e != nullptr && e[0] == 't');
+}
+static int lines_width_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0); }
+
+struct PartPlan { uint32_t levels; uint32_t bits[4]; uint32_t total; };
+static PartPlan plan_levels(uint32_t total_bits) {
+  PartPlan p{};
+  p.total = std::max(1u, total_bits);
+  p.levels = (p.total + kPartMaxBits - 1) / kPartMaxBits;
+  for (uint32_t l = 0; l < p.levels; ++l) { p.bits[l] = p.total / p.levels + (l < p.total % p.levels ? 1u : 0u); }
+  return p;
+}
+
+// One multi-level partition (d1_stream.inc) over up to kMaxIdx record sets.  Level l reads what level l - 1 wrote
+// (ping / pong) and leaves, in starts[], the first record of every bucket; the last level's buckets are the result.
+struct PartJob {
+  uint32_t nidx = 1;
+  const unsigned long long * in[kMaxIdx] = {};      // level-0 input (may be buf[i][1])
+  const uint32_t * in_f[kMaxIdx] = {};
+  unsigned long long * buf[kMaxIdx][2] = {};
+  uint32_t * buf_f[kMaxIdx][2] = {};
+  const uint64_t * cstart0[kMaxIdx] = {};           // level-0 chunks
+  const uint32_t * csize0[kMaxIdx] = {};
+  uint32_t csize_cap = 0, chunks0 = 1;
+  bool single0 = true;
+  uint64_t max_records = 0, max_tiles0 = 0;         // host-side upper bounds (per set)
+  uint64_t out_cap = 0;                             // entries every buf[][] holds
+  uint32_t bias = 0, top_bit = 32;
+  PartPlan plan{};
+  uint32_t * out32[kMaxIdx] = {};                   // != nullptr: the last level writes only the low halves, here
+  // scratch, per set
+  uint32_t * cnt[kMaxIdx] = {}; uint32_t * ctile[kMaxIdx] = {}; uint64_t * starts[kMaxIdx] = {}; uint32_t * partial[kMaxIdx] = {};
+  uint32_t * total[kMaxIdx] = {};
+  uint64_t starts_stride = 0;
+  // results
+  const unsigned long long * out[kMaxIdx] = {}; const uint32_t * out_f[kMaxIdx] = {}; const uint64_t * bstart[kMaxIdx] = {};
+  uint32_t buckets = 0;
+  int last = 0;                                     // buf[i][last] holds the result, buf[i][last ^ 1] is free
+};
+
+// scratch sizes of a job (entries): flat counts, tile table, chunk starts (per half), scan partials
+static void part_scratch(const PartJob & j, uint64_t * cnt, uint64_t * ctile, uint64_t * starts_half, uint64_t * partial) {
+  uint64_t chunks = j.chunks0, c_max = 0, t_max = 0, s_max = 0;
+  bool single = j.single0;
+  for (uint32_t l = 0; l < j.plan.levels; ++l) {
+    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / kPartTile + chunks + 1);
+    c_max = std::max(c_max, (tiles << j.plan.bits[l]) + 2);
+    t_max = std::max(t_max, chunks + 2);
+    chunks = (single ? 1 : chunks) << j.plan.bits[l];
+    single = false;
+    s_max = std::max(s_max, chunks + 2);
+  }
+  *cnt = c_max; *ctile = t_max; *starts_half = s_max; *partial = c_max / kFlatChunk + 2;
+}
+
+static int run_partition(swa_ctx * ctx, PartJob & j) {
+  uint64_t chunks = j.chunks0;
+  bool single = j.single0;
+  uint32_t used_bits = 0;
+  const int cu_grid = ctx->num_cus * 8;
+  for (uint32_t l = 0; l < j.plan.levels; ++l) {
+    const uint32_t bits = j.plan.bits[l];
+    used_bits += bits;
+    const bool last_level = l + 1 == j.plan.levels;
+    PartArgs a{};
+    a.single_seg = single ? 1u : 0u; a.bits = bits; a.shift = j.top_bit - used_bits; a.bias = j.bias;
+    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / kPartTile + chunks + 1);
+    for (uint32_t i = 0; i < j.nidx; ++i) {
+      PartIdx & p = a.p[i];
+      p.in = l == 0 ? j.in[i] : j.buf[i][(l - 1) & 1u];
+      p.in_f = l == 0 ? j.in_f[i] : j.buf_f[i][(l - 1) & 1u];
+      p.out = j.buf[i][l & 1u]; p.out_f = j.buf_f[i][l & 1u];
+      p.out32 = last_level ? j.out32[i] : nullptr;
+      p.out_cap = j.out_cap;
+      p.cstart = l == 0 ? j.cstart0[i] : j.starts[i] + ((l - 1) & 1u) * j.starts_stride;
+      p.csize = l == 0 ? j.csize0[i] : nullptr;
+      p.csize_cap = j.csize_cap;
+      p.chunks = (uint32_t)chunks;
+      p.ctile = j.ctile[i]; p.cnt = j.cnt[i];
+      p.next_start = j.starts[i] + (l & 1u) * j.starts_stride;
+      p.total = j.total[i];
+    }
+    const dim3 grid_t((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)cu_grid), j.nidx);
+    hipLaunchKernelGGL(k_part_tiles, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_part_hist, grid_t, dim3(256), 0, ctx->stream, a);
+    FlatScanArgs f{};
+    f.unit_bits = bits;
+    for (uint32_t i = 0; i < j.nidx; ++i) { f.v[i] = j.cnt[i]; f.units[i] = j.ctile[i] + chunks; f.partial[i] = j.partial[i]; f.total[i] = j.total[i]; }
+    const dim3 grid_f((unsigned)std::min<uint64_t>(((tiles << bits) + 1 + kFlatChunk - 1) / kFlatChunk, (uint64_t)cu_grid), j.nidx);
+    hipLaunchKernelGGL(k_flat_sums, grid_f, dim3(256), 0, ctx->stream, f);
+    hipLaunchKernelGGL(k_flat_apply, grid_f, dim3(256), 0, ctx->stream, f);
+    if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL(k_part_scatter<2>, grid_t, dim3(256), 0, ctx->stream, a); }
+    else if (j.buf_f[0][0] != nullptr) { hipLaunchKernelGGL(k_part_scatter<1>, grid_t, dim3(256), 0, ctx->stream, a); }
+    else { hipLaunchKernelGGL(k_part_scatter<0>, grid_t, dim3(256), 0, ctx->stream, a); }
+    chunks = (single ? 1 : chunks) << bits;
+    single = false;
+    hipLaunchKernelGGL(k_part_starts, dim3((unsigned)std::min<uint64_t>((chunks + 256) / 256, (uint64_t)cu_grid), j.nidx), dim3(256), 0, ctx->stream, a);
+    SWA_HIP(ctx, hipGetLastError());
+  }
+  j.buckets = (uint32_t)chunks;
+  j.last = (int)((j.plan.levels - 1) & 1u);
+  for (uint32_t i = 0; i < j.nidx; ++i) {
+    j.out[i] = j.buf[i][j.last]; j.out_f[i] = j.buf_f[i][j.last];
+    j.bstart[i] = j.starts[i] + (uint64_t)j.last * j.starts_stride;
+  }
+  return SWA_OK;
+}
+
+__global__ void k_set_u64x2(uint64_t * p0, uint64_t a0, uint64_t b0, uint64_t * p1, uint64_t a1, uint64_t b1) {
+  p0[0] = a0; p0[1] = b0;
+  if (p1 != nullptr) { p1[0] = a1; p1[1] = b1; }
+}
+
+// the amplicon lines of the uploaded database (once per upload; needs the abundance ranks)
+static int ensure_lines(swa_ctx * ctx) {
+  const int w = lines_width_for(ctx);
+  if (w == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "amplicon lines: sequences longer than 256 nt"); }
+  if (ctx->lines_ready && ctx->lines_w == w) { return SWA_OK; }
+  const uint32_t n = ctx->db.n;
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbLines], (uint64_t)n * (w == 5 ? 64u : 128u)));
+  auto * lines = static_cast<uint4 *>(ctx->d_stream[kSbLines].ptr);
+  const auto * rank = static_cast<const uint32_t *>(ctx->d_arank.ptr);
+  swa_t0(ctx, 15);
+  if (w == 5) { hipLaunchKernelGGL(k_lines_build<5>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
+  else { hipLaunchKernelGGL(k_lines_build<8>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
+  swa_t1(ctx, 15);
+  SWA_HIP(ctx, hipGetLastError());
+  ctx->lines_ready = true;
+  ctx->lines_w = w;
+  return SWA_OK;
+}
+
+// The two anchor indexes of the whole database (or of the routed id lists) by the streaming build: members in group
+// order (d_stream[kSbMembers + which]: ids), the work lists of the pair kernels, the flags build_owned_index reads
+// ([0] identical sequences [2] partition too coarse [3] unserved seeds [4, 5] oversized groups [6] shortest sequence).
+static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_count) {
+  ctx->anchor_ready = false;
+  ctx->stream_index = false;
+  const uint32_t n = ctx->db.n;
+  const int w = lines_width_for(ctx);
+  SWA_TRY(ensure_lines(ctx));
+  const bool routed = ctx->route_ids[0] != nullptr;
+  const uint64_t records = routed ? std::max<uint64_t>(std::max(ctx->route_m[0], ctx->route_m[1]), 1) : n;
+  // buckets of at most kGroupTarget records on average: the group kernel stages kGroupCapRecords
+  uint32_t total_bits = 1;
+  while ((records >> total_bits) > kGroupTarget && total_bits < 3 * kPartMaxBits) { ++total_bits; }
+  total_bits = std::min<uint32_t>(total_bits + ctx->stream_extra_bits, 3 * kPartMaxBits);
+  PartJob j;
+  j.nidx = 2;
+  j.plan = plan_levels(total_bits);
+  j.max_records = records;
+  j.out_cap = records + 1;
+  j.max_tiles0 = records / kPartTile + 2;
+  j.chunks0 = 1; j.single0 = true; j.top_bit = 32; j.bias = 0;
+  uint64_t e_cnt, e_tile, e_start, e_partial;
+  part_scratch(j, &e_cnt, &e_tile, &e_start, &e_partial);
+  const uint64_t buckets = 1ull << total_bits;
+  e_partial = std::max<uint64_t>(e_partial, ((uint64_t)kListKinds * buckets + 1) / kFlatChunk + 2);
+  for (int i = 0; i < 2; ++i) {
+    for (int h = 0; h < 2; ++h) { SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbRec + 2 * i + h], (records + 1) * sizeof(uint64_t))); }
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbFp + i], (records + 1) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbCnt + i], e_cnt * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbTile + i], e_tile * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbStart + i], (2 * e_start + 4) * sizeof(uint64_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbPartial + i], e_partial * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbMembers + i], (records + 1) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbKind + i], ((uint64_t)kListKinds * buckets + 2) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[i], items_capacity(n) * sizeof(swa_item)));
+  }
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbScal], 64 * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbOver], ((uint64_t)n + 8) & ~3ull));
+  SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_stream[kSbOver].ptr, 0, ((uint64_t)n + 8) & ~3ull, ctx->stream));
+  auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
+  SWA_HIP(ctx, hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), ctx->stream));
+  auto * scal = static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr);      // [0..3] level-0 chunk tables, [8 + i] totals (u32)
+  const uint32_t win_a = ctx->anchor_a, win_b = ctx->anchor_b;
+  const uint32_t minlen = win_a + win_b + kMinAnchoredLen, window_mode = (win_a != 0 || win_b != 0) ? 1u : 0u;
+
+  // ---- keys: records into the PONG halves (level 0 reads them from there), fingerprints likewise
+  KeyArgs k{};
+  k.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
+  k.n = n;
+  for (int i = 0; i < 2; ++i) {
+    k.list[i] = routed ? ctx->route_ids[i] : nullptr;
+    k.list_count[i] = routed ? ctx->route_m[i] : 0;
+    k.rec[i] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i + 1].ptr);
+  }
+  k.fp = static_cast<uint32_t *>(ctx->d_stream[kSbFp + 1].ptr);
+  k.owner_rank = ctx->owner_rank; k.owner_world = ctx->owner_world;
+  k.win_a = win_a; k.win_b = win_b; k.minlen = minlen; k.window_mode = window_mode;
+  k.flags = dflags;
+  if (routed) {
+    hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(1), 0, ctx->stream, dflags,
+                       (ctx->db_shortest < minlen || (window_mode == 0u && ctx->db_run32)) ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
+  }
+  const dim3 kgrid((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u);
+  swa_t0(ctx, 8);
+  if (w == 5) { hipLaunchKernelGGL(k_keys<5>, kgrid, dim3(256), 0, ctx->stream, k); } else { hipLaunchKernelGGL(k_keys<8>, kgrid, dim3(256), 0, ctx->stream, k); }
+  hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, ctx->stream, scal, (uint64_t)0, (uint64_t)(routed ? ctx->route_m[0] : n), scal + 2, (uint64_t)0,
+                     (uint64_t)(routed ? ctx->route_m[1] : n));
+  swa_t1(ctx, 8);
+
+  // ---- partition by the top bits of the key
+  for (int i = 0; i < 2; ++i) {
+    j.buf[i][0] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i].ptr);
+    j.buf[i][1] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i + 1].ptr);
+    j.in[i] = j.buf[i][1];
+    j.cstart0[i] = scal + 2 * i;
+    j.cnt[i] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt + i].ptr);
+    j.ctile[i] = static_cast<uint32_t *>(ctx->d_stream[kSbTile + i].ptr);
+    j.starts[i] = static_cast<uint64_t *>(ctx->d_stream[kSbStart + i].ptr);
+    j.partial[i] = static_cast<uint32_t *>(ctx->d_stream[kSbPartial + i].ptr);
+    j.total[i] = reinterpret_cast<uint32_t *>(scal + 8 + i);
+  }
+  // (the fingerprints travel with the prefix index only: index 1 has no second payload)
+  j.buf_f[0][0] = static_cast<uint32_t *>(ctx->d_stream[kSbFp].ptr);
+  j.buf_f[0][1] = static_cast<uint32_t *>(ctx->d_stream[kSbFp + 1].ptr);
+  j.in_f[0] = j.buf_f[0][1];
+  j.starts_stride = e_start + 2;
+  swa_t0(ctx, 9);
+  SWA_TRY(run_partition(ctx, j));
+  swa_t1(ctx, 9);
+
+  // ---- groups
+  GroupArgs g{};
+  for (int i = 0; i < 2; ++i) {
+    GroupIdx & x = g.g[i];
+    x.rec = j.out[i];
+    x.fp = i == 0 ? j.out_f[0] : nullptr;
+    x.bstart = j.bstart[i];
+    x.buckets = j.buckets;
+    x.members = static_cast<uint32_t *>(ctx->d_stream[kSbMembers + i].ptr);
+    x.items_tmp = j.buf[i][j.last ^ 1];
+    x.kind_cnt = static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr);
+    SWA_HIP(ctx, hipMemsetAsync(x.kind_cnt + (uint64_t)kListKinds * x.buckets, 0, sizeof(uint32_t), ctx->stream));
+  }
+  g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
+  g.flags = dflags;
+  g.over = static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr);
+  g.dup_first = dup_first; g.dup_count = dup_count;
+  g.lines = k.lines; g.line_quads = w == 5 ? 4u : 8u; g.line_w = (uint32_t)w;
+  g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
+  swa_t0(ctx, 10);
+  hipLaunchKernelGGL(k_group, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus * 12), 2), dim3(256), 0, ctx->stream, g);
+
+  // ---- work lists
+  FlatScanArgs f{};
+  ListArgs la{};
+  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
+  for (int i = 0; i < 2; ++i) {
+    f.v[i] = g.g[i].kind_cnt; f.units[i] = nullptr; f.fixed[i] = (uint64_t)kListKinds * buckets + 1;
+    f.partial[i] = j.partial[i]; f.total[i] = reinterpret_cast<uint32_t *>(scal + 10 + i);
+    ListIdx & x = la.x[i];
+    x.items_tmp = g.g[i].items_tmp; x.bstart = g.g[i].bstart; x.kind_pos = g.g[i].kind_cnt; x.buckets = (uint32_t)buckets;
+    x.l.items = static_cast<swa_item *>(ctx->d_aitems[i].ptr);
+    for (uint32_t c = 0; c <= kPairClasses; ++c) { x.l.region[c] = pair_region(c, n); }
+    x.l.counters = acounters + 32 + 8 * i;
+    x.l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[i].ptr);
+    x.l.chunk_counter = acounters + i;
+    x.l.pair_big = g.pair_big;
+  }
+  const dim3 grid_k((unsigned)std::min<uint64_t>(((uint64_t)kListKinds * buckets + kFlatChunk) / kFlatChunk, (uint64_t)ctx->num_cus * 8), 2);
+  hipLaunchKernelGGL(k_flat_sums, grid_k, dim3(256), 0, ctx->stream, f);
+  hipLaunchKernelGGL(k_flat_apply, grid_k, dim3(256), 0, ctx->stream, f);
+  hipLaunchKernelGGL(k_group_lists, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, (uint64_t)ctx->num_cus * 8), 2), dim3(256), 0, ctx->stream, la);
+  swa_t1(ctx, 10);
+  SWA_HIP(ctx, hipGetLastError());
+  ctx->pair_lists = true;
+  ctx->anchor_first = 0;
+  ctx->anchor_count = n;
+  ctx->anchor_slots = 0;
+  ctx->anchor_ready = true;
+  ctx->stream_index = true;
+  return SWA_OK;
+}
+
+// CSR of the links in the per-wave segments by the streaming route: the links partitioned by the top bits of their
+// source (relative to `first`) until a bucket holds 2^r consecutive sources, then one wave per bucket (k_csr_bucket).
+// link_cap: entries of the two internal link buffers; a run with more links than that leaves garbage and is repeated
+// by the caller with bigger buffers (the total is known after the host has synchronised).
+static bool stream_csr_enabled() {
+  const char * e = getenv("SWA_D1_CSR");
+  return !(e != nullptr && e[0] == 't');
+}
+
+static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t nseg, uint64_t link_cap, uint64_t * d_offsets,
+                             uint32_t * d_neighbours, uint64_t cap) {
+  uint32_t nbits = 1;
+  while (nbits < 32 && ((uint64_t)1 << nbits) < count) { ++nbits; }
+  uint32_t r = std::min<uint32_t>(8, nbits - 1);
+  if (nbits - r > 2 * kPartMaxBits) { r = std::min<uint32_t>(kCsrMaxR, nbits - 2 * kPartMaxBits); }
+  PartJob j;
+  j.nidx = 1;
+  j.plan = plan_levels(nbits - r);
+  j.max_records = link_cap;
+  j.out_cap = link_cap;
+  const uint64_t tiles_per_seg = (ctx->seg_cap + kPartTile - 1) / kPartTile;
+  j.max_tiles0 = (uint64_t)nseg * tiles_per_seg + 2;
+  j.chunks0 = nseg; j.single0 = true; j.top_bit = nbits; j.bias = first;
+  j.csize_cap = (uint32_t)std::min<uint64_t>(ctx->seg_cap, 0xFFFFFFFFu);
+  uint64_t e_cnt, e_tile, e_start, e_partial;
+  part_scratch(j, &e_cnt, &e_tile, &e_start, &e_partial);
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbLinkA], (link_cap + 1) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbLinkB], (link_cap + 1) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbCnt], e_cnt * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbTile], e_tile * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbStart], (2 * e_start + 4) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbPartial], e_partial * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbScal], 64 * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_seg_base, uint64_t(nseg) * sizeof(uint64_t)));
+  auto * seg_starts = static_cast<uint64_t *>(ctx->d_seg_base.ptr);
+  hipLaunchKernelGGL(k_seg_starts, dim3((nseg + 255) / 256), dim3(256), 0, ctx->stream, seg_starts, nseg, ctx->seg_cap);
+  j.in[0] = static_cast<const unsigned long long *>(ctx->d_edges.ptr);
+  j.buf[0][0] = static_cast<unsigned long long *>(ctx->d_stream[kSbLinkA].ptr);
+  j.buf[0][1] = static_cast<unsigned long long *>(ctx->d_stream[kSbLinkB].ptr);
+  j.cstart0[0] = seg_starts;
+  j.csize0[0] = static_cast<const uint32_t *>(ctx->d_seg_fill.ptr);
+  j.cnt[0] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt].ptr);
+  j.ctile[0] = static_cast<uint32_t *>(ctx->d_stream[kSbTile].ptr);
+  j.starts[0] = static_cast<uint64_t *>(ctx->d_stream[kSbStart].ptr);
+  j.partial[0] = static_cast<uint32_t *>(ctx->d_stream[kSbPartial].ptr);
+  j.total[0] = reinterpret_cast<uint32_t *>(static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr) + 12);
+  j.starts_stride = e_start + 2;
+  swa_t0(ctx, 13);
+  SWA_TRY(run_partition(ctx, j));
+  swa_t1(ctx, 13);
+  CsrArgs c{};
+  c.links = j.out[0]; c.bstart = j.bstart[0]; c.buckets = j.buckets; c.r = r; c.first = first; c.count = count;
+  c.offsets = d_offsets; c.neighbours = d_neighbours; c.cap = d_neighbours != nullptr ? cap : 0;
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbHeavy], ((uint64_t)j.buckets + 2) * sizeof(uint32_t)));
+  c.heavy = static_cast<uint32_t *>(ctx->d_stream[kSbHeavy].ptr) + 1;
+  c.heavy_count = static_cast<uint32_t *>(ctx->d_stream[kSbHeavy].ptr);
+  SWA_HIP(ctx, hipMemsetAsync(c.heavy_count, 0, sizeof(uint32_t), ctx->stream));
+  swa_t0(ctx, 14);
+  const dim3 cgrid((unsigned)std::min<uint64_t>(((uint64_t)j.buckets + 3) / 4, (uint64_t)ctx->num_cus * 8));
+  if (r <= 8) { hipLaunchKernelGGL(k_csr_bucket<8>, cgrid, dim3(256), 0, ctx->stream, c); }
+  else { hipLaunchKernelGGL(k_csr_bucket<9>, cgrid, dim3(256), 0, ctx->stream, c); }
+  hipLaunchKernelGGL(k_csr_bucket_big, dim3((unsigned)ctx->num_cus * 4), dim3(256), 0, ctx->stream, c);
+  swa_t1(ctx, 14);
+  SWA_HIP(ctx, hipGetLastError());
+  return SWA_OK;
+}
+
 // anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
 // the plain kernel; edges / counts / edge counter as launch_network leaves them
-static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count) {
+static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count, bool count_links) {
   // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items [16..32) work counters
   // [32 + 8 pass + c] lists of k_scan_apply_lists
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
@@ -1180,8 +1535,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   // only the pair kernels).  SWA_D1_PAIRS_TILED=1 / 0: test switches
   const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");
   const bool aux_ready = ctx->full_index || ctx->aux_members;
-  const bool tiled_big = pairs_width != 0 && (window_mode || !aux_ready || (env_tiled != nullptr && env_tiled[0] == '1')) &&
-                         !(env_tiled != nullptr && env_tiled[0] == '0' && aux_ready && !window_mode);
+  const bool tiled_big = ctx->stream_index ||
+                         (pairs_width != 0 && (window_mode || !aux_ready || (env_tiled != nullptr && env_tiled[0] == '1')) &&
+                          !(env_tiled != nullptr && env_tiled[0] == '0' && aux_ready && !window_mode));
   for (int which = 0; which < 2 && pairs_width == 0; ++which) {
     hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
                        static_cast<const unsigned long long *>(ctx->d_acounts[which].ptr),
@@ -1192,6 +1548,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   }
   SWA_HIP(ctx, hipGetLastError());
   for (int pass = 0; pass < 2; ++pass) {
+    swa_t0(ctx, 11 + pass);
     AnchorArgs a{};
     a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen; a.abundance = ctx->db.abundance;
     a.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
@@ -1206,7 +1563,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.edges = static_cast<uint64_t *>(ctx->d_edges.ptr);
     a.seg_cap = ctx->seg_cap;
     a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
-    a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
+    a.counts = count_links ? static_cast<uint32_t *>(ctx->d_counts.ptr) : nullptr;
     a.minlen = ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen;
     a.win_word = ctx->anchor_a / 32u;
     a.window_mode = window_mode ? 1u : 0u;
@@ -1220,6 +1577,11 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.table_slots = 2 * kSmallGroup;
     const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom
     a.minfo = static_cast<const uint4 *>(ctx->d_ainfo[pass].ptr);
+    if (ctx->stream_index) {                                  // members = ids in group order + the amplicon lines
+      a.minfo = nullptr;
+      a.ids = static_cast<const uint32_t *>(ctx->d_stream[kSbMembers + pass].ptr);
+      a.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
+    }
     a.pair_items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
     for (uint32_t c = 0; c <= kPairClasses; ++c) { a.pair_region[c] = pair_region(c, ctx->db.n); }
     a.pair_counters = acounters + 32 + 8 * pass;
@@ -1244,16 +1606,23 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
       else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
     } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<false, 1>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    swa_t1(ctx, 11 + pass);
     SWA_HIP(ctx, hipGetLastError());
   }
   // seeds (or halves of seeds) the anchored passes skipped (a lean build has made sure there are none: no sequence
   // too short, no oversized group — and what holds for the whole database holds for every part of it)
-  if (ctx->full_index)
+  if (ctx->full_index && ctx->stream_index) {
+    hipLaunchKernelGGL(k_stream_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first, count,
+                       static_cast<const uint8_t *>(ctx->d_stream[kSbOver].ptr), static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2,
+                       ctx->owner_rank, ctx->owner_world, ctx->db.seqs, ctx->db.seq_off, ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen,
+                       window_mode ? 1u : 0u);
+  } else if (ctx->full_index) {
   hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
                      count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr),
                      static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
                      static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world,
                      ctx->db.seqs, ctx->db.seq_off, ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen, window_mode ? 1u : 0u);
+  }
   NetArgs f{};
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
   f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
@@ -1269,7 +1638,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   f.seg_cap = ctx->seg_cap;
   f.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
   f.stats = stats;
-  f.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
+  f.counts = count_links ? static_cast<uint32_t *>(ctx->d_counts.ptr) : nullptr;
   f.fallback = static_cast<const swa_fallback *>(ctx->d_afallback.ptr);
   f.fallback_count = acounters + 2;
   f.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
@@ -1420,70 +1789,88 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
   SWA_TRY(prepare_hashing(ctx));
   SWA_TRY(launch_abundance_rank(ctx));
-  swa_t0(ctx, 7);
-  SWA_TRY(build_anchor_index(ctx, 0, n));
-  swa_t1(ctx, 7);
-  const uint64_t asize = ctx->anchor_slots;
-  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
-  if (!ctx->pair_lists) {                                   // (with pair lists the scan over the group sizes has set these flags)
-    hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
-                       asize, dflags, 0u);
-  }
-  // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
-  swa_t0(ctx, 2);
-  if (!ctx->pair_lists) {
-    hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
-                       asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
-                       static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
-  }
-  DupArgs da{};
-  da.seqs = ctx->db.seqs; da.seq_off = ctx->db.seq_off; da.seqlen = ctx->db.seqlen;
-  da.minfo = static_cast<const uint4 *>(ctx->d_ainfo[0].ptr);
-  da.member_fingerprint = static_cast<const uint64_t *>(ctx->d_afp[1].ptr);
-  da.flag = dflags;
-  // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair is
-  // seen by exactly one rank); a single GPU honours the slice it was asked about
-  da.first = ctx->owner_world > 1 ? 0u : first;
-  da.count = ctx->owner_world > 1 ? n : count;
-  if (ctx->pair_lists) {
-    da.pair_items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);
-    for (uint32_t c = 0; c <= kPairClasses; ++c) { da.pair_region[c] = pair_region(c, n); }
-    da.pair_counters = acounters + 32;
-    hipLaunchKernelGGL(k_dup_bundles, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
-    da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + pair_region(kPairClasses, n);   // groups of 65..pair_big
-    da.item_count = acounters + 32 + kPairClasses;
-    hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
+  // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair of
+  // identical sequences is seen by exactly one rank); a single GPU honours the slice it was asked about
+  const uint32_t dup_first = ctx->owner_world > 1 ? 0u : first, dup_count = ctx->owner_world > 1 ? n : count;
+  const bool stream = stream_enabled() && pairs_width_for(ctx) != 0 && lines_width_for(ctx) != 0;
+  if (stream) {
+    // streaming build (d1_stream.inc): keys, partition, groups + work lists + identical sequences, all in one go
+    swa_t0(ctx, 7);
+    SWA_TRY(build_stream_index(ctx, dup_first, dup_count));
+    swa_t1(ctx, 7);
   } else {
-    da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n);
-    da.item_count = acounters + 3;
-    hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
+    swa_t0(ctx, 7);
+    SWA_TRY(build_anchor_index(ctx, 0, n));
+    swa_t1(ctx, 7);
+    const uint64_t asize = ctx->anchor_slots;
+    auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
+    if (!ctx->pair_lists) {                                   // (with pair lists the scan over the group sizes has set these flags)
+      hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                         static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
+                         asize, dflags, 0u);
+    }
+    // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
+    swa_t0(ctx, 2);
+    if (!ctx->pair_lists) {
+      hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
+                         static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
+                         asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
+                         static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
+    }
+    DupArgs da{};
+    da.seqs = ctx->db.seqs; da.seq_off = ctx->db.seq_off; da.seqlen = ctx->db.seqlen;
+    da.minfo = static_cast<const uint4 *>(ctx->d_ainfo[0].ptr);
+    da.member_fingerprint = static_cast<const uint64_t *>(ctx->d_afp[1].ptr);
+    da.flag = dflags;
+    // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair is
+    // seen by exactly one rank); a single GPU honours the slice it was asked about
+    da.first = ctx->owner_world > 1 ? 0u : first;
+    da.count = ctx->owner_world > 1 ? n : count;
+    if (ctx->pair_lists) {
+      da.pair_items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);
+      for (uint32_t c = 0; c <= kPairClasses; ++c) { da.pair_region[c] = pair_region(c, n); }
+      da.pair_counters = acounters + 32;
+      hipLaunchKernelGGL(k_dup_bundles, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
+      da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + pair_region(kPairClasses, n);   // groups of 65..pair_big
+      da.item_count = acounters + 32 + kPairClasses;
+      hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
+    } else {
+      da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n);
+      da.item_count = acounters + 3;
+      hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
+    }
+    da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);             // chunks of the groups beyond
+    da.item_count = acounters + 0;
+    hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
+    SWA_HIP(ctx, hipGetLastError());
+    swa_t1(ctx, 2);
   }
-  da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);             // chunks of the groups beyond
-  da.item_count = acounters + 0;
-  hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
-  SWA_HIP(ctx, hipGetLastError());
-  swa_t1(ctx, 2);
   // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence / pb = 0 [4] oversized group
   // [5] members of oversized groups [6] 0xFFFFFFFF - shortest sequence [7] groups for the enumerating kernels
-  uint32_t flags[8] = {};
+  uint32_t flags[9] = {};
   SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
   if (shortest != nullptr) { *shortest = 0xFFFFFFFFu - flags[6]; }
+  if (flags[2] != 0 && ctx->stream_index) {                 // a bucket with more distinct keys than the group kernel's table: finer
+    if (ctx->stream_extra_bits >= 8) { return swa_fail_msg(ctx, SWA_E_DEVICE, "streaming index build: partition still too coarse"); }
+    ctx->stream_extra_bits += 2;
+    SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
+    return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
+  }
   if (flags[2] != 0 && ctx->anchor_slack == 0) {            // the optimistic key tables were too small: once more, safe size
     ctx->anchor_slack = 1;
     SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
     return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
   }
   if (flags[1] != 0) { ctx->db_unordered = true; }
-  *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
+  // ([8]: a prefix group too large for the streaming build's own check of identical sequences: the table's instead)
+  *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0 || flags[8] != 0;
   // Zobrist hashes and XOR streams of the members: only the enumerating kernels read them (the pair kernels compare
   // the sequences themselves, the duplicate check their fingerprints); the full route hashes everybody anyway
   ctx->aux_members = false;
   // (the groups of the whole database bound those of any later re-index — another query range, another owner)
-  ctx->aux_needed = flags[7] != 0 || pairs_width_for(ctx) == 0;
+  ctx->aux_needed = !ctx->stream_index && (flags[7] != 0 || pairs_width_for(ctx) == 0);
   if (!*needs_table && ctx->aux_needed) {
     SWA_TRY(launch_seqhash(ctx, true));
     ctx->aux_members = true;
@@ -1503,7 +1890,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   ctx->full_index = false;
   ctx->aux_complete = false;
   ctx->anchor_a = ctx->anchor_b = 0;
-  for (int slot : {0, 1, 2, 7}) { ctx->ev_used[slot] = false; }   // phases this build does not run report 0
+  for (int slot : {0, 1, 2, 7, 8, 9, 10, 15}) { ctx->ev_used[slot] = false; }   // phases this build does not run report 0
   ctx->table_size = swa_hashtable_size(n);
   const uint64_t bloom_bytes = ctx->table_size < 8 ? 8 : ctx->table_size;   // bloompat.cc:100-113
   ctx->bloom_words = bloom_bytes >> 3;
@@ -1576,8 +1963,9 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     }
     SWA_HIP(ctx, hipGetLastError());
     swa_t1(ctx, 2);
-    // the anchored index itself is built by the first network call, for that call's query range
-    ctx->anchor_ready = false;
+    // the anchored index itself is built by the first network call, for that call's query range (the streaming
+    // index, made for the whole database above, stays)
+    if (!ctx->stream_index) { ctx->anchor_ready = false; }
     if (ctx->anchor_usable) {
       SWA_TRY(launch_abundance_rank(ctx));
       SWA_HIP(ctx, hipGetLastError());
@@ -1675,12 +2063,22 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
   constexpr uint32_t kLongRowCap = 1u << 16;
   SWA_TRY(swa_reserve(ctx, ctx->d_long_rows, (kLongRowCap + 1ull) * sizeof(uint32_t)));
   uint64_t n_edges = 0;
+  uint64_t stream_link_cap = 0;
   bool clean = false;                                        // the last attempt ran to the end without a retry condition
   for (int attempt = 0; attempt < 8 && !clean; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
     SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, uint64_t(nseg) * sizeof(uint32_t), ctx->stream));
+    // CSR by the streaming route (links sorted by source with the partition primitive) unless a flat list is wanted
+    const bool csr_stream = d_edge_list == nullptr && stream_csr_enabled() && ctx->anchor_usable && !stats;
     if (ctx->anchor_usable && !stats) {
-      if (!ctx->anchor_ready || ctx->anchor_first != first || ctx->anchor_count != count) {
+      const bool stream = stream_enabled() && pairs_width_for(ctx) != 0 && lines_width_for(ctx) != 0;
+      if (stream && !(ctx->anchor_ready && ctx->stream_index)) {
+        // (the streaming index serves any query range; it is rebuilt when the owner changed)
+        swa_t0(ctx, 7);
+        SWA_TRY(launch_abundance_rank(ctx));
+        SWA_TRY(build_stream_index(ctx, 0, 0));
+        swa_t1(ctx, 7);
+      } else if (!stream && (!ctx->anchor_ready || ctx->anchor_first != first || ctx->anchor_count != count)) {
         swa_t0(ctx, 7);
         SWA_TRY(build_anchor_index(ctx, first, count));
         swa_t1(ctx, 7);
@@ -1691,7 +2089,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
           ctx->aux_members = true;
         }
       }
-      SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count));
+      SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count, !csr_stream));
     }
     else {
       SWA_TRY(ensure_full_index(ctx));
@@ -1723,6 +2121,9 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
       hipLaunchKernelGGL(k_seg_compact, dim3(std::min<uint32_t>(nseg, (uint32_t)ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
                          static_cast<const uint64_t *>(ctx->d_edges.ptr), static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
                          nseg, ctx->seg_cap, static_cast<const unsigned long long *>(ctx->d_seg_base.ptr), d_edge_list, cap);
+    } else if (csr_stream) {
+      stream_link_cap = std::max<uint64_t>(std::max<uint64_t>(cap, stream_link_cap), 2ull * count + 1024);
+      SWA_TRY(launch_csr_stream(ctx, first, count, nseg, stream_link_cap, d_offsets, d_neighbours, cap));
     } else {
       hipLaunchKernelGGL((k_scan_tiles<uint32_t>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream,
                          static_cast<const uint32_t *>(ctx->d_counts.ptr), count, static_cast<uint64_t *>(ctx->d_scan_tmp.ptr));
@@ -1755,6 +2156,11 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     }
     if (check_unserved && unserved != 0) {                   // should not happen (build_owned_index looks for such seeds)
       SWA_TRY(ensure_full_index(ctx));
+      continue;
+    }
+    if (csr_stream && got[1] <= ctx->seg_cap && n_edges > stream_link_cap) {
+      // more links than the internal link buffers of the CSR stage hold (a first call with a small `cap`): bigger, again
+      stream_link_cap = n_edges + 1024;
       continue;
     }
     if (got[1] <= ctx->seg_cap) { clean = true; break; }
@@ -1870,6 +2276,23 @@ extern "C" int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t f
 extern "C" int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out_bytes) {
   if (ctx == nullptr || out == nullptr) { return SWA_E_ARG; }
   if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: no index"); }
+  if (what >= 10) {
+    // the streaming index as it lies in HBM (tools/check_stream.py validates it on the host): 10 + i: ids in group order of
+    // index i, u32[n] · 12 + i: its item buffer, swa_item[items_capacity(n)] · 14: the counters, u32[64] · 15: the amplicon lines
+    if (!ctx->stream_index) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: no streaming index in place"); }
+    const void * from = nullptr;
+    size_t need = 0;
+    if (what == 10 || what == 11) { from = ctx->d_stream[kSbMembers + (what - 10)].ptr; need = uint64_t(ctx->db.n) * sizeof(uint32_t); }
+    else if (what == 12 || what == 13) { from = ctx->d_aitems[what - 12].ptr; need = items_capacity(ctx->db.n) * sizeof(swa_item); }
+    else if (what == 14) { from = ctx->d_acounters.ptr; need = 64 * sizeof(uint32_t); }
+    else if (what == 15) { from = ctx->d_stream[kSbLines].ptr; need = uint64_t(ctx->db.n) * (ctx->lines_w == 5 ? 64u : 128u); }
+    else { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: unknown selector"); }
+    if (out_bytes < need) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_debug_read: buffer too small"); }
+    SWA_HIP(ctx, hipSetDevice(ctx->device));
+    SWA_HIP(ctx, hipMemcpyAsync(out, from, need, hipMemcpyDeviceToHost, ctx->stream));
+    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWA_OK;
+  }
   SWA_TRY(ensure_full_index(ctx));
   const void * src = nullptr;
   size_t bytes = 0;

@@ -74,6 +74,7 @@ struct GroupArgs {
   uint32_t * tslot;              // [n * (2 d + 1)]
   uint32_t * qslot;              // [n]
   uint32_t * overflow;
+  uint32_t owner_rank, owner_world;   // world > 1: only the window keys this rank owns make groups here (swa_dn_set_ownership)
 };
 
 __global__ __launch_bounds__(256) void k_dg_clear(unsigned long long * keys, uint32_t * c0, uint32_t * c1, uint32_t * c2, uint32_t * c3,
@@ -99,7 +100,9 @@ __global__ __launch_bounds__(256) void k_dg_targets(const GroupArgs a) {
         bool repeat = false;                                  // (low complexity: the same window at two shifts — one membership)
         for (uint32_t q = 0; q < j; ++q) { repeat = repeat || seen[q] == key; }
         seen[j] = key;
-        if (!repeat) {
+        // (ownership by bits of the mixed key that the table index — its low bits — does not use alone)
+        const bool owned = a.owner_world == 1u || (uint32_t)((((mix64(key) >> 40) & 0xFFFFFFull) * a.owner_world) >> 24) == a.owner_rank;
+        if (!repeat && owned) {
           uint64_t idx = mix64(key) & a.amask;
           bool placed = false;
           for (uint64_t probes = 0; probes <= a.amask; ++probes) {
@@ -422,14 +425,11 @@ extern "C" int swa_dn_graph_supported(swa_ctx * ctx) {
   return wlen != 0 ? 1 : 0;
 }
 
-extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint8_t * diffs,
-                            uint64_t cap, uint64_t * total) {
+// the search itself: the sorted (query << 32 | target, diff) list of this context's share of the graph, left in HBM
+int swa_dn_graph_compute(swa_ctx * ctx, int no_cluster_breaking) {
   if (ctx == nullptr) { return SWA_E_ARG; }
   if (!ctx->qgram_ready || !ctx->search_ready) {
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_graph: call swa_qgram_build and swa_search_begin first");
-  }
-  if (offsets == nullptr || total == nullptr || (cap != 0 && (neighbours == nullptr || diffs == nullptr))) {
-    return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_graph: null buffer");
   }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n = ctx->db.n;
@@ -480,6 +480,7 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
         GroupArgs g{};
         g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen; g.n = n; g.d = d; g.k = k; g.wlen = wlen;
         g.keys = keys; g.cnt_t = cnt_t; g.cnt_q = cnt_q; g.amask = asize - 1; g.tslot = tslot; g.qslot = qslot; g.overflow = dflags + 9;
+        g.owner_rank = ctx->dn_owner_rank; g.owner_world = ctx->dn_owner_world;
         const dim3 gn(grid_for(ctx, n)), ga(grid_for(ctx, asize)), b(256);
         hipLaunchKernelGGL(k_dg_clear, ga, b, 0, ctx->stream, keys, cnt_t, cnt_q, cur_t, cur_q, asize);
         hipLaunchKernelGGL(k_dg_targets, gn, b, 0, ctx->stream, g);
@@ -557,12 +558,17 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
     ctx->dn_graph_ready = true;
     ctx->dn_graph_ncb = no_cluster_breaking != 0;
   }
-  const uint64_t nedges = ctx->dn_edges;
+  return SWA_OK;
+}
+
+// a sorted link list -> offsets / neighbours / diffs on the host (buffers and capacity protocol of swa_dn_graph)
+int swa_dn_graph_emit(swa_ctx * ctx, const unsigned long long * sorted, const uint32_t * svals, uint64_t nedges, uint64_t * offsets,
+                      uint32_t * neighbours, uint8_t * diffs, uint64_t cap, uint64_t * total) {
+  const uint32_t n = ctx->db.n;
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
   *total = nedges;
   ctx->csr_ready = false;                                   // (d_offsets_tmp / d_nb_tmp now hold this graph)
   SWA_TRY(swa_reserve(ctx, ctx->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
-  const unsigned long long * sorted = ctx->dn_work != 0 ? static_cast<const unsigned long long *>(ctx->d_dn_keys.ptr) + ctx->dn_work : nullptr;
-  const uint32_t * svals = ctx->dn_work != 0 ? static_cast<const uint32_t *>(ctx->d_dn_vals.ptr) + ctx->dn_work : nullptr;
   hipLaunchKernelGGL(k_dg_offsets, dim3(grid_for(ctx, (uint64_t)n + 1)), dim3(256), 0, ctx->stream, sorted, nedges, n,
                      static_cast<uint64_t *>(ctx->d_offsets_tmp.ptr));
   SWA_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_offsets_tmp.ptr, ((uint64_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -580,6 +586,32 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
   }
   SWA_HIP(ctx, hipGetLastError());
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}
+
+extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint8_t * diffs,
+                            uint64_t cap, uint64_t * total) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (offsets == nullptr || total == nullptr || (cap != 0 && (neighbours == nullptr || diffs == nullptr))) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_graph: null buffer");
+  }
+  SWA_TRY(swa_dn_graph_compute(ctx, no_cluster_breaking));
+  const unsigned long long * sorted = ctx->dn_work != 0 ? static_cast<const unsigned long long *>(ctx->d_dn_keys.ptr) + ctx->dn_work : nullptr;
+  const uint32_t * svals = ctx->dn_work != 0 ? static_cast<const uint32_t *>(ctx->d_dn_vals.ptr) + ctx->dn_work : nullptr;
+  return swa_dn_graph_emit(ctx, sorted, svals, ctx->dn_edges, offsets, neighbours, diffs, cap, total);
+}
+
+// Multi-GPU by ownership of window groups (as swa_d1_set_ownership): with world > 1 this context makes only the groups
+// whose window key maps to `rank`.  A pair is reported through the FIRST window it shares ("not already found through
+// an earlier window" is decided on the two sequences), and that window's group lives on one rank: over all ranks every
+// pair of the graph is found exactly once.  world = 1 restores the complete graph.
+extern "C" int swa_dn_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (world == 0 || rank >= world) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_set_ownership: bad rank / world"); }
+  if (rank != ctx->dn_owner_rank || world != ctx->dn_owner_world) {
+    ctx->dn_owner_rank = rank; ctx->dn_owner_world = world;
+    ctx->dn_graph_ready = false;
+  }
   return SWA_OK;
 }
 

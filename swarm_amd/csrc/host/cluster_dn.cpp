@@ -41,18 +41,23 @@ struct swa_dn_result {
 // (swa_dn_graph: row q = the targets t with diff(q, t) <= d that the abundance rule lets q take, ascending, with
 // their diffs).  Same order-defining rules as the loop in swa_dn_cluster: seeds by lowest unswarmed id, a sub-seed's
 // hits in pool (= id) order, queue kept sorted by generation then id (src/algo.cc:205-219).
-static int cluster_over_graph(swa_ctx * ctx, const swa_hostdb * db, int no_cluster_breaking, swa_dn_result * r) {
+// (multi != nullptr: the graph comes from several GPUs, swa_multi_dn_graph)
+static int cluster_over_graph(swa_ctx * ctx, swa_multi * multi, const swa_hostdb * db, int no_cluster_breaking, swa_dn_result * r) {
   const uint32_t n = db->n;
   std::vector<uint64_t> off((size_t)n + 1);
   std::vector<uint32_t> nb;
   std::vector<uint8_t> df;
   uint64_t total = 0;
-  int rc = swa_dn_graph(ctx, no_cluster_breaking, off.data(), nullptr, nullptr, 0, &total);
+  auto graph = [&](uint32_t * nbp, uint8_t * dfp, uint64_t cap) {
+    return multi != nullptr ? swa_multi_dn_graph(multi, no_cluster_breaking, off.data(), nbp, dfp, cap, &total)
+                            : swa_dn_graph(ctx, no_cluster_breaking, off.data(), nbp, dfp, cap, &total);
+  };
+  int rc = graph(nullptr, nullptr, 0);
   if (rc == SWA_E_CAPACITY) {
     nb.resize(total); df.resize(total);
-    rc = swa_dn_graph(ctx, no_cluster_breaking, off.data(), nb.data(), df.data(), total, &total);
+    rc = graph(nb.data(), df.data(), total);
   }
-  if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  if (rc != SWA_OK) { r->error = multi != nullptr ? swa_multi_last_error(multi) : swa_last_error(ctx); return rc; }
   std::vector<uint8_t> swarmed(n, 0);
   std::vector<swa_dn_result::Member> queue;
   r->order.reserve(n);
@@ -98,6 +103,26 @@ static int cluster_over_graph(swa_ctx * ctx, const swa_hostdb * db, int no_clust
   return SWA_OK;
 }
 
+// d >= 2 on several GPUs (SWARM_AMD_DEVICES): the bulk graph shared out by ownership of window groups; a database the
+// graph route cannot serve (a sequence too short for d + 1 windows) is clustered by rank 0 alone with the fused scan.
+extern "C" int swa_dn_cluster_multi(swa_multi * multi, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
+                                    uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out) {
+  if (multi == nullptr || db == nullptr || out == nullptr || differences < 2) { return SWA_E_ARG; }
+  const char * route = std::getenv("SWARM_AMD_DN");
+  const bool want_scan = route != nullptr && std::strcmp(route, "scan") == 0;
+  if (db->n != 0 && !want_scan) {
+    int rc = swa_multi_dn_begin(multi, mismatch, gapopen, gapextend, (uint64_t)differences);
+    if (rc == SWA_OK && swa_multi_dn_graph_supported(multi) != 0) {
+      auto * r = new swa_dn_result();
+      *out = r;
+      r->differences = differences;
+      r->pen_mismatch = mismatch; r->pen_gapopen = gapopen; r->pen_gapextend = gapextend;
+      return cluster_over_graph(swa_multi_ctx(multi, 0), multi, db, no_cluster_breaking, r);
+    }
+  }
+  return swa_dn_cluster(swa_multi_ctx(multi, 0), db, differences, no_cluster_breaking, mismatch, gapopen, gapextend, out);
+}
+
 extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
                               uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, swa_dn_result ** out) {
   if (ctx == nullptr || db == nullptr || out == nullptr || differences < 2) { return SWA_E_ARG; }
@@ -118,7 +143,7 @@ extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t diff
   const char * route = std::getenv("SWARM_AMD_DN");
   const bool want_scan = route != nullptr && std::strcmp(route, "scan") == 0;
   const bool want_graph = route != nullptr && std::strcmp(route, "graph") == 0;
-  if (!want_scan && swa_dn_graph_supported(ctx) != 0) { return cluster_over_graph(ctx, db, no_cluster_breaking, r); }
+  if (!want_scan && swa_dn_graph_supported(ctx) != 0) { return cluster_over_graph(ctx, nullptr, db, no_cluster_breaking, r); }
   if (want_graph) { r->error = "SWARM_AMD_DN=graph: a sequence is too short for d + 1 windows"; return SWA_E_ARG; }
 
   std::vector<uint8_t> swarmed(n, 0);

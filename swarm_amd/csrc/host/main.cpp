@@ -8,7 +8,7 @@
 //   d = 0      swa_derep -> swa_d0_cluster
 //
 // Environment (no new flags, to stay drop-in): SWARM_AMD_DEVICE = HIP device ordinal (default 0);
-// SWARM_AMD_DEVICES = 0,1,2,... : d = 1 on several GPUs (swa_multi_*: one rank per entry, RCCL exchange).
+// SWARM_AMD_DEVICES = 0,1,2,... : d >= 1 on several GPUs (swa_multi_*: one rank per entry, RCCL exchange).
 #include <chrono>
 #include <thread>
 #include "../../../include/swarm_amd.h"
@@ -328,7 +328,7 @@ int main(int argc, char ** argv) {
       p = (*end == ',') ? end + 1 : end;
     }
   }
-  const bool use_multi = devices.size() > 1 && o.differences == 1;
+  const bool use_multi = devices.size() > 1 && o.differences >= 1;
   swa_ctx * early_ctx = nullptr;
   int early_rc = SWA_OK;
   std::thread early;
@@ -529,8 +529,10 @@ int main(int argc, char ** argv) {
     // ---- d >= 2: host greedy loop, every q-gram / alignment step on the GPU
     swa_dn_result * res = nullptr;
     if (n > 0) {
-      rc = swa_dn_cluster(ctx, db, o.differences, o.no_break ? 1 : 0, (uint64_t)o.pen_mismatch, (uint64_t)o.pen_gapopen,
-                          (uint64_t)o.pen_gapextend, &res);
+      rc = multi != nullptr ? swa_dn_cluster_multi(multi, db, o.differences, o.no_break ? 1 : 0, (uint64_t)o.pen_mismatch,
+                                                   (uint64_t)o.pen_gapopen, (uint64_t)o.pen_gapextend, &res)
+                            : swa_dn_cluster(ctx, db, o.differences, o.no_break ? 1 : 0, (uint64_t)o.pen_mismatch, (uint64_t)o.pen_gapopen,
+                                             (uint64_t)o.pen_gapextend, &res);
       if (rc != SWA_OK) { die(res != nullptr ? swa_dn_result_error(res) : "clustering failed"); }
     } else {
       rc = SWA_OK;

@@ -393,3 +393,98 @@ extern "C" int swa_multi_d1_fastidious(swa_multi * m, const uint8_t * is_light, 
   }
   return SWA_OK;
 }
+
+// ---- d >= 2 on several GPUs: the bulk graph (dn_graph.hip) divided by ownership of window groups ------------------
+// Replaces the scan fan-out of src/scan.cc:221-256 under the loop of src/algo.cc:505-602: every rank finds the pairs of
+// the window groups it owns (swa_dn_set_ownership) and aligns them; the accepted (query, target, diff) triples travel
+// to rank 0 — ncclSend / ncclRecv over RCCL, device-to-device copies when ranks share a device —, which sorts them
+// into the CSR of swa_dn_graph.  The greedy walk over it stays on the host (cluster_dn.cpp).
+extern "C" int swa_multi_dn_begin(swa_multi * m, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend, uint64_t d) {
+  if (m == nullptr) { return SWA_E_ARG; }
+  return on_all(m, [&](int r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    SWA_TRY(swa_qgram_build(c));
+    return swa_search_begin(c, mismatch, gapopen, gapextend, d);
+  });
+}
+
+extern "C" int swa_multi_dn_graph_supported(swa_multi * m) {
+  if (m == nullptr) { return 0; }
+  for (swa_ctx * c : m->ctx) { if (swa_dn_graph_supported(c) == 0) { return 0; } }
+  return 1;
+}
+
+extern "C" int swa_multi_dn_graph(swa_multi * m, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint8_t * diffs,
+                                  uint64_t cap, uint64_t * total) {
+  if (m == nullptr || offsets == nullptr || total == nullptr || (cap != 0 && (neighbours == nullptr || diffs == nullptr))) { return SWA_E_ARG; }
+  const int world = (int)m->ctx.size();
+  int rc = on_all(m, [&](int r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    SWA_TRY(swa_dn_set_ownership(c, (uint32_t)r, (uint32_t)world));
+    return swa_dn_graph_compute(c, no_cluster_breaking);
+  });
+  if (rc != SWA_OK) { return rc; }
+  swa_ctx * c0 = m->ctx[0];
+  uint64_t all = 0;
+  std::vector<uint64_t> at((size_t)world + 1, 0);
+  for (int r = 0; r < world; ++r) { at[(size_t)r] = all; all += m->ctx[(size_t)r]->dn_edges; }
+  at[(size_t)world] = all;
+  if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+  // rank 0's buffers: [all keys | sorted keys] and [all diffs | sorted diffs]
+  rc = swa_reserve(c0, m->gathered[0], (2 * all + 2) * sizeof(uint64_t));
+  if (rc == SWA_OK) { rc = swa_reserve(c0, m->links[0], (2 * all + 2) * sizeof(uint32_t)); }
+  if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c0)); }
+  auto * keys = static_cast<unsigned long long *>(m->gathered[0].ptr);
+  auto * vals = static_cast<uint32_t *>(m->links[0].ptr);
+  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupStart()); }
+  for (int r = 0; r < world; ++r) {
+    swa_ctx * c = m->ctx[(size_t)r];
+    const uint64_t cnt = c->dn_edges;
+    if (cnt == 0) { continue; }
+    const auto * k_src = static_cast<const unsigned long long *>(c->d_dn_keys.ptr) + c->dn_work;
+    const auto * v_src = static_cast<const uint32_t *>(c->d_dn_vals.ptr) + c->dn_work;
+    if (!m->comms.empty() && r != 0) {
+      NCCL_OK(m, ncclSend(k_src, cnt, ncclUint64, 0, m->comms[(size_t)r], c->stream));
+      NCCL_OK(m, ncclRecv(keys + at[(size_t)r], cnt, ncclUint64, r, m->comms[0], c0->stream));
+      NCCL_OK(m, ncclSend(v_src, cnt, ncclUint32, 0, m->comms[(size_t)r], c->stream));
+      NCCL_OK(m, ncclRecv(vals + at[(size_t)r], cnt, ncclUint32, r, m->comms[0], c0->stream));
+    } else {
+      if (hipSetDevice(c0->device) != hipSuccess ||
+          hipMemcpyAsync(keys + at[(size_t)r], k_src, cnt * sizeof(uint64_t), hipMemcpyDefault, c0->stream) != hipSuccess ||
+          hipMemcpyAsync(vals + at[(size_t)r], v_src, cnt * sizeof(uint32_t), hipMemcpyDefault, c0->stream) != hipSuccess) {
+        return fail(m, SWA_E_DEVICE, "device-to-device copy of a rank's share of the graph failed");
+      }
+    }
+  }
+  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupEnd()); }
+  for (int k = 0; k < world; ++k) {
+    if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
+      return fail(m, SWA_E_DEVICE, "synchronising the exchange of the graph failed");
+    }
+  }
+  if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+  auto stage = [&]() -> int {
+    if (all != 0) {
+      size_t bytes = 0;
+      (void)rocprim::radix_sort_pairs(nullptr, bytes, keys, keys + all + 1, vals, vals + all + 1, all, 0, 64, c0->stream);
+      SWA_TRY(swa_reserve(c0, c0->d_scan_hits, bytes + 16));
+      SWA_HIP(c0, rocprim::radix_sort_pairs(c0->d_scan_hits.ptr, bytes, keys, keys + all + 1, vals, vals + all + 1, all, 0, 64, c0->stream));
+    }
+    return swa_dn_graph_emit(c0, all != 0 ? keys + all + 1 : nullptr, all != 0 ? vals + all + 1 : nullptr, all, offsets, neighbours, diffs, cap, total);
+  };
+  rc = stage();
+  if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c0)); }
+  return SWA_OK;
+}
+
+// out3 = {q-gram comparisons, aligned pairs, kernel launches} over all ranks
+extern "C" int swa_multi_dn_graph_totals(swa_multi * m, uint64_t * out3) {
+  if (m == nullptr || out3 == nullptr) { return SWA_E_ARG; }
+  out3[0] = out3[1] = out3[2] = 0;
+  for (swa_ctx * c : m->ctx) {
+    uint64_t t[3] = {0, 0, 0};
+    (void)swa_dn_graph_totals(c, t);
+    out3[0] += t[0]; out3[1] += t[1]; out3[2] = std::max(out3[2], t[2]);
+  }
+  return SWA_OK;
+}

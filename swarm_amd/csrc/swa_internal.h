@@ -37,9 +37,9 @@ struct swa_ctx {
 
   // optional per-kernel timing (HIP events on `stream`)
   bool timing = false;
-  hipEvent_t ev[16] = {};
+  hipEvent_t ev[32] = {};
   bool ev_ready = false;
-  bool ev_used[8] = {};
+  bool ev_used[16] = {};
 
   // database (device pointers)
   swa_db_view db{};
@@ -123,6 +123,7 @@ struct swa_ctx {
   bool dn_graph_ready = false, dn_graph_ncb = false;
   uint64_t dn_pair_cap = 0, dn_comparisons = 0, dn_aligned = 0, dn_launches = 0, dn_edges = 0, dn_work = 0;
   swa_dbuf d_dn_keys, d_dn_vals;
+  uint32_t dn_owner_rank = 0, dn_owner_world = 1;   // swa_dn_set_ownership: this context finds the pairs of the window groups it owns
 
   // streaming index build / CSR assembly (d1_stream.inc)
   bool lines_ready = false;      // d_lines holds this database's amplicon lines (made once per upload), lines_w words each
@@ -132,7 +133,8 @@ struct swa_ctx {
   // [0] lines [1..4] records ping / pong per index [5, 6] fingerprints ping / pong [7] table slots of big buckets
   // [8, 9] flat counts [10, 11] tile tables [12, 13] chunk starts [14, 15] scan partials [16] scalars
   // [17, 18] members [19] oversized-group bits [20, 21] items per kind [22] link sort: records ping [23] pong
-  swa_dbuf d_stream[24];
+  // [24] buckets of the CSR stage left to whole workgroups
+  swa_dbuf d_stream[26];
 
   // the d = 1 network kept in d_offsets_tmp / d_nb_tmp (swa_d1_network_resident) and its clustering (cluster_gpu.hip)
   bool csr_ready = false;
@@ -145,6 +147,11 @@ int swa_fail_msg(swa_ctx * ctx, int code, const std::string & msg);
 int swa_reserve(swa_ctx * ctx, swa_dbuf & buf, size_t bytes);   // grow-only hipMalloc
 void swa_release(swa_dbuf & buf);
 int swa_hash_sequences(swa_ctx * ctx);                           // d1.hip: Zobrist table + d_seqhash + d_aux
+// dn_graph.hip, for multi.hip: the (partial, under ownership) graph computed and left sorted in HBM — d_dn_keys / d_dn_vals
+// from entry dn_work on, dn_edges entries —, and a sorted (query << 32 | target, diff) list written out as the CSR of swa_dn_graph
+int swa_dn_graph_compute(swa_ctx * ctx, int no_cluster_breaking);
+int swa_dn_graph_emit(swa_ctx * ctx, const unsigned long long * sorted, const uint32_t * svals, uint64_t nedges, uint64_t * offsets,
+                      uint32_t * neighbours, uint8_t * diffs, uint64_t cap, uint64_t * total);
 
 // RAII-less timing brackets: SWA_T0(ctx, slot) ... SWA_T1(ctx, slot)
 inline void swa_t0(swa_ctx * ctx, int slot) {

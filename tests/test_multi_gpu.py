@@ -80,3 +80,57 @@ def test_multi_reports_duplicates(tmp_path):
     fa.write_text(f">a_3\n{seq}\n>b_2\n{seq}\n>c_1\n{seq[:-1]}G\n")
     r = subprocess.run([str(BIN), "-d", "1", str(fa)], capture_output=True, text=True, env=dict(os.environ, SWARM_AMD_DEVICES="0,0"))
     assert r.returncode == 1 and "some fasta entries have identical sequences" in r.stderr
+
+
+# ---- d >= 2 on several ranks (swa_multi_dn_graph: the bulk graph divided by ownership of window groups) ----------
+
+G = S.GOLDEN
+FLAG = {"o": "-o", "s": "-s", "i": "-i", "w": "-w", "u": "-u"}
+
+
+@pytest.mark.parametrize("name", ["d2_small", "d3_400", "d5_ties", "d8_16bit"])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_cli_dn_with_several_ranks_matches_reference_files(tmp_path, name, devices):
+    """The golden d >= 2 cases (files written by the unmodified reference) through 2 and 3 ranks on device 0 (graph route
+    where every sequence has room for d + 1 windows; otherwise rank 0 clusters alone with the fused scan)."""
+    args = (G / f"{name}.args").read_text().split()
+    kept = [k for k in FLAG if (G / f"{name}.{k}").exists()]
+    cmd = [str(BIN)] + args
+    for k in kept:
+        cmd += [FLAG[k], str(tmp_path / k)]
+    cmd += ["-l", str(tmp_path / "log"), str(G / f"{name}.fasta")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SWARM_AMD_DEVICES=devices))
+    assert r.returncode == 0, r.stderr
+    for k in kept:
+        assert filecmp.cmp(tmp_path / k, G / f"{name}.{k}", shallow=False), k
+
+
+@pytest.mark.parametrize("ncb", [False, True])
+def test_multi_dn_graph_equals_single(tmp_path, ncb):
+    """The whole graph of a 25 k random set (d = 3, up to 3 edits per amplicon, tied abundances among them) from 2 and
+    3 ranks, entry for entry the single-GPU graph; and RCCL with one rank (the send / receive branch is then empty,
+    the communicator and the sort on rank 0 are exercised)."""
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 25000, 120, 77, 3)
+    hdb = HostDb(fa)
+    want = None
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        m = MultiContext(devices)
+        m.upload_hostdb(hdb)
+        got = m.dn_graph(3, ncb)
+        assert got is not None
+        if want is None:
+            want = got
+            assert len(got[1]) > 1000
+        else:
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+        m.close()
+    # ... and through the command line: one GPU against three ranks
+    one = subprocess.run([str(BIN), "-d", "3"] + (["-n"] if ncb else []) + ["-o", str(tmp_path / "one.o"), "-i", str(tmp_path / "one.i"), str(fa)],
+                         capture_output=True, text=True)
+    two = subprocess.run([str(BIN), "-d", "3"] + (["-n"] if ncb else []) + ["-o", str(tmp_path / "two.o"), "-i", str(tmp_path / "two.i"), str(fa)],
+                         capture_output=True, text=True, env=dict(os.environ, SWARM_AMD_DEVICES="0,0,0"))
+    assert one.returncode == 0 and two.returncode == 0, one.stderr + two.stderr
+    assert filecmp.cmp(tmp_path / "one.o", tmp_path / "two.o", shallow=False)
+    assert filecmp.cmp(tmp_path / "one.i", tmp_path / "two.i", shallow=False)

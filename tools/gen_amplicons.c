@@ -17,6 +17,11 @@
  *         gcc -O2 -shared -fPIC -DGEN_NO_MAIN ...                   (library)
  * CLI:    gen_amplicons <n> <L> <seed> <max_edits> <light_frac> <out.fasta>
  *         GEN_FLANK=<k> in the environment: all centroids share their first and last k nucleotides
+ *         GEN_CORE=<k>:  all centroids are identical except for a k-nt core in the middle (conserved everywhere but
+ *                        a hypervariable region)
+ *         GEN_ZIPF=<s>:  family sizes follow Zipf's law: the family of centroid r (r = 1, 2, ...) receives the share
+ *                        s / r of all derived amplicons (until the shares add up to 1/2); the rest as usual.  s = 0.1
+ *                        makes the largest family a tenth of the set: swarms of 10^5 members at n = 10^6
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -26,6 +31,9 @@
 
 typedef struct { uint64_t s; } rng_t;
 static uint32_t g_flank = 0;        /* GEN_FLANK environment variable (see below) */
+static uint32_t g_core = 0;         /* GEN_CORE */
+static double g_zipf = 0.0;         /* GEN_ZIPF */
+#define ZIPF_FAMILIES 64
 
 static uint64_t rng_next(rng_t * r) {            /* splitmix64 */
   uint64_t z = (r->s += 0x9E3779B97F4A7C15ULL);
@@ -41,6 +49,7 @@ typedef struct {
   uint16_t len;
   uint8_t  light;
   uint64_t abundance;
+  uint32_t family;  /* the centroid this amplicon descends from */
 } amp_t;
 
 static uint64_t seq_hash(const uint8_t * s, uint32_t len) {   /* FNV-1a over bases */
@@ -111,17 +120,39 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
   const uint64_t n_heavy = n - n_light;
   uint64_t count = 0, heavy_count = 0;
   size_t pool_used = 0;
+  /* GEN_ZIPF: member lists of the first ZIPF_FAMILIES families and the cumulative shares they are drawn with */
+  uint32_t * fam_members[ZIPF_FAMILIES];
+  uint64_t fam_count[ZIPF_FAMILIES], fam_cap[ZIPF_FAMILIES];
+  double fam_cum[ZIPF_FAMILIES];
+  uint32_t fam_used = 0;
+  if (g_zipf > 0.0) {
+    double total = 0.0;
+    for (uint32_t r = 0; r < ZIPF_FAMILIES && r < centroids; ++r) {
+      if (total + g_zipf / (double)(r + 1) > 0.5) break;
+      total += g_zipf / (double)(r + 1);
+      fam_cum[r] = total; fam_count[r] = 0; fam_cap[r] = 1024;
+      fam_members[r] = (uint32_t *)malloc(fam_cap[r] * sizeof(uint32_t));
+      if (!fam_members[r]) return 2;
+      fam_used = r + 1;
+    }
+  }
 
   while (count < n) {
     uint32_t len;
     uint64_t abundance;
     uint8_t light = 0;
+    uint32_t family_of_new = (uint32_t)count;
     if (count < centroids) {
       len = L;
       for (uint32_t i = 0; i < len; ++i) tmp[i] = (uint8_t)(rng_next(&rng) >> 62);
       /* GEN_FLANK=<k>: every centroid starts and ends with the same k nucleotides (conserved flanks / primers left
          on: the skewed case for anything that groups sequences by their ends); drawn from a generator of their own,
          so the rest of the set does not depend on the option */
+      if (g_core > 0 && g_core < len) {            /* everything but the core from a generator of its own: the same for all */
+        rng_t cr; cr.s = 0xC0DEC0DEULL;
+        const uint32_t lo = (len - g_core) / 2, hi = lo + g_core;
+        for (uint32_t i = 0; i < len; ++i) { const uint8_t b = (uint8_t)(rng_next(&cr) >> 62); if (i < lo || i >= hi) tmp[i] = b; }
+      }
       if (g_flank > 0 && 2u * g_flank < len) {
         rng_t fr; fr.s = 0x5EEDF1A2ULL;
         for (uint32_t i = 0; i < g_flank; ++i) tmp[i] = (uint8_t)(rng_next(&fr) >> 62);
@@ -133,6 +164,13 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
       abundance = (uint64_t)a;
     } else {
       const amp_t * parent = &amps[heavy_ids[rng_below(&rng, heavy_count)]];
+      if (fam_used != 0) {                         /* Zipf: a family by its share, then any of its members */
+        const double u = rng_unit(&rng);
+        for (uint32_t r = 0; r < fam_used; ++r) {
+          if (u < fam_cum[r]) { if (fam_count[r] != 0) { parent = &amps[fam_members[r][rng_below(&rng, fam_count[r])]]; } break; }
+        }
+      }
+      family_of_new = parent->family;
       len = parent->len;
       memcpy(tmp, pool + parent->off, len);
       uint32_t edits;
@@ -149,7 +187,16 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
     }
     if (!set_insert(&set, pool, amps, tmp, len, (uint32_t)count)) continue;   /* duplicate */
     amp_t * a = &amps[count];
-    a->off = pool_used; a->len = (uint16_t)len; a->light = light; a->abundance = abundance;
+    a->off = pool_used; a->len = (uint16_t)len; a->light = light; a->abundance = abundance; a->family = family_of_new;
+    if (!light && family_of_new < fam_used) {
+      const uint32_t r = family_of_new;
+      if (fam_count[r] == fam_cap[r]) {
+        fam_cap[r] *= 2;
+        fam_members[r] = (uint32_t *)realloc(fam_members[r], fam_cap[r] * sizeof(uint32_t));
+        if (!fam_members[r]) return 2;
+      }
+      fam_members[r][fam_count[r]++] = (uint32_t)count;
+    }
     memcpy(pool + pool_used, tmp, len);
     pool_used += len;
     if (!light) heavy_ids[heavy_count++] = (uint32_t)count;
@@ -178,6 +225,7 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
     fwrite(line, 1, (size_t)w + a->len + 1, fp);
   }
   fclose(fp);
+  for (uint32_t r = 0; r < fam_used; ++r) free(fam_members[r]);
   free(line); free(order); free(set.key); free(set.val); free(tmp); free(heavy_ids); free(pool); free(amps);
   return 0;
 }
@@ -190,6 +238,8 @@ int main(int argc, char ** argv) {
   }
   if (argc == 8) g_id_offset = strtoull(argv[7], NULL, 10);
   if (getenv("GEN_FLANK") != NULL) g_flank = (uint32_t)atoi(getenv("GEN_FLANK"));
+  if (getenv("GEN_CORE") != NULL) g_core = (uint32_t)atoi(getenv("GEN_CORE"));
+  if (getenv("GEN_ZIPF") != NULL) g_zipf = atof(getenv("GEN_ZIPF"));
   const int rc = gen_amplicons_fasta(strtoull(argv[1], NULL, 10), (uint32_t)atoi(argv[2]),
                                      strtoull(argv[3], NULL, 10), (uint32_t)atoi(argv[4]),
                                      atof(argv[5]), argv[6]);

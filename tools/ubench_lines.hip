@@ -19,7 +19,7 @@
 // access pattern (tools/calibrate_pmc.py).
 //
 //   hipcc -O3 --offload-arch=gfx950 -o tools/ubench_lines tools/ubench_lines.hip
-//   tools/ubench_lines [out.json]
+//   tools/ubench_lines [out.json] [quick]       (quick: stream copy, the 1 GB working set and the VALU test only: ~2 s)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -177,8 +177,10 @@ int main(int argc, char ** argv) {
   }
 
   // ---- random accesses over several working sets
+  const bool quick = argc > 2 && std::string(argv[2]) == "quick";
   const uint64_t sets[] = {32ull << 20, 128ull << 20, 1ull << 30, 8ull << 30};     // powers of two (masks)
   for (uint64_t bytes : sets) {
+    if (quick && bytes != (1ull << 30)) { continue; }
     void * tab;
     if (hipMalloc(&tab, bytes) != hipSuccess) { continue; }
     CHECK(hipMemset(tab, 0, bytes));
