@@ -477,6 +477,31 @@ def step_byte_model(n: int, links: int, index_levels: int, link_levels: int) -> 
     }
 
 
+def cpp_multi_check(fasta: Path, world: int) -> dict:
+    """swarm -d 1 with SWARM_AMD_DEVICES=0..world-1 (swa_multi_*, RCCL) against the same run on GPU 0: -o md5-equal, the
+    exchange reported as RCCL, wall times and the library's own milestones (SWARM_AMD_TIMING)."""
+    exe = ROOT / "swarm_amd" / "bin" / "swarm"
+    res = {}
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            runs = {"one_gpu": {}, "all_gpus": {"SWARM_AMD_DEVICES": ",".join(str(i) for i in range(world)), "SWARM_AMD_MULTI_REPORT": "1"}}
+            md5 = {}
+            for tag, env in runs.items():
+                t0 = time.perf_counter()
+                r = subprocess.run([str(exe), "-d", "1", "-o", f"{tmp}/{tag}.o", "-l", "/dev/null", str(fasta)], capture_output=True, text=True,
+                                   env=dict(os.environ, SWARM_AMD_TIMING="1", **env), timeout=900)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    return {"error": f"{tag}: exit {r.returncode}: {r.stderr[-400:]}"}
+                md5[tag] = md5_of(f"{tmp}/{tag}.o")
+                res[tag] = {"seconds": round(dt, 3), "milestones": [ln for ln in r.stderr.splitlines() if ln.startswith("[t") or ln.startswith("multi:")][-12:]}
+            res["output_identical"] = md5["one_gpu"] == md5["all_gpus"]
+            res["exchange_is_rccl"] = any("exchange = rccl" in ln for ln in res["all_gpus"]["milestones"])
+    except Exception as e:                                # (an extra must never cost the headline line)
+        return {"error": f"{type(e).__name__}: {e}"}
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -741,6 +766,13 @@ def main() -> None:
         if world == 1 and not sim_world and not args.no_configs1 and not args.no_cpu_baseline:
             # BASELINE.json configs[1] (1 M x 150, d=1): the same step at that size, same run
             out["config"]["configs1"] = extra_measurement(torch, dev, device_index, args, 1_000_000, 10)
+        if world > 1 and not one_gpu and not args.no_extras:
+            # What the command line ships for several GPUs is swa_multi_* (multi.hip: one rank + host thread per GPU inside
+            # ONE process, routed index build with grouped ncclSend / ncclRecv, link lists gathered with RCCL) — a different
+            # driver of the same C entry points than the torch.distributed ranks timed above.  Run it here, on the same
+            # GPUs and the same database, as a subprocess (the other ranks wait at the barrier below): its output must be
+            # byte-identical to one GPU's, and it must really have used RCCL.
+            out["config"]["cpp_multi"] = cpp_multi_check(fasta, world)
         if one_gpu:
             out["simulated"] = f"{world} ranks sharing GPU 0 over gloo: exercises the sharded step, not a result"
             out["sharded_csr_equals_whole"] = sharded_ok

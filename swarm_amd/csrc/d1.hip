@@ -405,7 +405,10 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
       uint32_t amp = 0;
       uint32_t nmatch = 0;
       if ((uint32_t)lane < cnt) {
-        const int wf = MODE != 2 ? 0 : (a.window_mode != 0u ? (int)range : (range == 2u ? 2 : 0));
+        // MODE 2: a seed's two halves are divided by the prefix-side window itself, as the pair kernels divide them — range 1
+        // keeps only neighbours that share it, range 2 only those that do not.  (By position alone the halves overlap: a
+        // deletion at position 31, or inside a run that ends there, is listed at a position >= pb AND changes the window.)
+        const int wf = MODE != 2 ? 0 : (int)range;
         hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch, wf, a.win_word);
       }
       const uint64_t hm = __ballot(hit);
@@ -1193,6 +1196,7 @@ struct PartJob {
   uint64_t max_records = 0, max_tiles0 = 0;         // host-side upper bounds (per set)
   uint64_t out_cap = 0;                             // entries every buf[][] holds
   uint32_t bias = 0, top_bit = 32;
+  uint32_t tile = 4096;                             // records per tile (2048 for the records that carry fingerprints)
   PartPlan plan{};
   uint32_t * out32[kMaxIdx] = {};                   // != nullptr: the last level writes only the low halves, here
   // scratch, per set
@@ -1210,7 +1214,7 @@ static void part_scratch(const PartJob & j, uint64_t * cnt, uint64_t * ctile, ui
   uint64_t chunks = j.chunks0, c_max = 0, t_max = 0, s_max = 0;
   bool single = j.single0;
   for (uint32_t l = 0; l < j.plan.levels; ++l) {
-    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / kPartTile + chunks + 1);
+    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / j.tile + chunks + 1);
     c_max = std::max(c_max, (tiles << j.plan.bits[l]) + 2);
     t_max = std::max(t_max, chunks + 2);
     chunks = (single ? 1 : chunks) << j.plan.bits[l];
@@ -1230,8 +1234,8 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     used_bits += bits;
     const bool last_level = l + 1 == j.plan.levels;
     PartArgs a{};
-    a.single_seg = single ? 1u : 0u; a.bits = bits; a.shift = j.top_bit - used_bits; a.bias = j.bias;
-    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / kPartTile + chunks + 1);
+    a.single_seg = single ? 1u : 0u; a.bits = bits; a.shift = j.top_bit - used_bits; a.bias = j.bias; a.tile = j.tile;
+    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / j.tile + chunks + 1);
     for (uint32_t i = 0; i < j.nidx; ++i) {
       PartIdx & p = a.p[i];
       p.in = l == 0 ? j.in[i] : j.buf[i][(l - 1) & 1u];
@@ -1256,9 +1260,9 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     const dim3 grid_f((unsigned)std::min<uint64_t>(((tiles << bits) + 1 + kFlatChunk - 1) / kFlatChunk, (uint64_t)cu_grid), j.nidx);
     hipLaunchKernelGGL(k_flat_sums, grid_f, dim3(256), 0, ctx->stream, f);
     hipLaunchKernelGGL(k_flat_apply, grid_f, dim3(256), 0, ctx->stream, f);
-    if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL(k_part_scatter<2>, grid_t, dim3(256), 0, ctx->stream, a); }
-    else if (j.buf_f[0][0] != nullptr) { hipLaunchKernelGGL(k_part_scatter<1>, grid_t, dim3(256), 0, ctx->stream, a); }
-    else { hipLaunchKernelGGL(k_part_scatter<0>, grid_t, dim3(256), 0, ctx->stream, a); }
+    if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<2, 4096>), grid_t, dim3(256), 0, ctx->stream, a); }
+    else if (j.buf_f[0][0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<1, 2048>), grid_t, dim3(256), 0, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_part_scatter<0, 4096>), grid_t, dim3(256), 0, ctx->stream, a); }
     chunks = (single ? 1 : chunks) << bits;
     single = false;
     hipLaunchKernelGGL(k_part_starts, dim3((unsigned)std::min<uint64_t>((chunks + 256) / 256, (uint64_t)cu_grid), j.nidx), dim3(256), 0, ctx->stream, a);
@@ -1317,7 +1321,8 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   j.plan = plan_levels(total_bits);
   j.max_records = records;
   j.out_cap = records + 1;
-  j.max_tiles0 = records / kPartTile + 2;
+  j.tile = 2048;
+  j.max_tiles0 = records / j.tile + 2;
   j.chunks0 = 1; j.single0 = true; j.top_bit = 32; j.bias = 0;
   uint64_t e_cnt, e_tile, e_start, e_partial;
   part_scratch(j, &e_cnt, &e_tile, &e_start, &e_partial);
@@ -1335,6 +1340,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     SWA_TRY(swa_reserve(ctx, ctx->d_aitems[i], items_capacity(n) * sizeof(swa_item)));
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbScal], 64 * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSlot], (records + 1) * sizeof(uint16_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbOver], ((uint64_t)n + 8) & ~3ull));
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
@@ -1401,6 +1407,8 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     x.members = static_cast<uint32_t *>(ctx->d_stream[kSbMembers + i].ptr);
     x.items_tmp = j.buf[i][j.last ^ 1];
     x.kind_cnt = static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr);
+    x.fp_sorted = i == 0 ? j.buf_f[0][j.last ^ 1] : nullptr;
+    x.slot_sorted = static_cast<uint16_t *>(ctx->d_stream[kSbSlot].ptr);
     SWA_HIP(ctx, hipMemsetAsync(x.kind_cnt + (uint64_t)kListKinds * x.buckets, 0, sizeof(uint32_t), ctx->stream));
   }
   g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
@@ -1432,6 +1440,12 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   hipLaunchKernelGGL(k_flat_sums, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_flat_apply, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_group_lists, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, (uint64_t)ctx->num_cus * 8), 2), dim3(256), 0, ctx->stream, la);
+  {
+    DupTiledArgs dt{};                                       // identical sequences inside the large prefix groups (chunk list)
+    dt.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr); dt.item_count = acounters + 0;
+    dt.members = g.g[0].members; dt.fp_sorted = g.g[0].fp_sorted; dt.g = g;
+    hipLaunchKernelGGL(k_dup_tiled, dim3((unsigned)ctx->num_cus * 4), dim3(256), 0, ctx->stream, dt);
+  }
   swa_t1(ctx, 10);
   SWA_HIP(ctx, hipGetLastError());
   ctx->pair_lists = true;
@@ -1463,7 +1477,8 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
   j.plan = plan_levels(nbits - r);
   j.max_records = link_cap;
   j.out_cap = link_cap;
-  const uint64_t tiles_per_seg = (ctx->seg_cap + kPartTile - 1) / kPartTile;
+  j.tile = 4096;
+  const uint64_t tiles_per_seg = (ctx->seg_cap + j.tile - 1) / j.tile;
   j.max_tiles0 = (uint64_t)nseg * tiles_per_seg + 2;
   j.chunks0 = nseg; j.single0 = true; j.top_bit = nbits; j.bias = first;
   j.csize_cap = (uint32_t)std::min<uint64_t>(ctx->seg_cap, 0xFFFFFFFFu);
@@ -1864,8 +1879,7 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
     return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
   }
   if (flags[1] != 0) { ctx->db_unordered = true; }
-  // ([8]: a prefix group too large for the streaming build's own check of identical sequences: the table's instead)
-  *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0 || flags[8] != 0;
+  *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
   // Zobrist hashes and XOR streams of the members: only the enumerating kernels read them (the pair kernels compare
   // the sequences themselves, the duplicate check their fingerprints); the full route hashes everybody anyway
   ctx->aux_members = false;

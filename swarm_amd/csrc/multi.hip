@@ -7,8 +7,8 @@
 // (swa_d1_set_ownership: rank r serves the groups whose key maps to r, with all their members), so every
 // link of the network is found by exactly one rank.  Exchange, as SURVEY 8e / the north star name it: the
 // per-rank hit counts are known on the host when the kernels return, then every rank's flat link list is
-// all-gathered into every GPU (grouped ncclBroadcast = an all-gather with unequal counts), and the CSR is
-// a radix sort + offsets on the device.  Fastidious: the heavy amplicons are split
+// gathered on rank 0 — the one consumer: grouped ncclSend / ncclRecv (round 2 all-gathered the whole network into every
+// GPU) —, and the CSR is a radix sort + offsets on that device.  Fastidious: the heavy amplicons are split
 // (swa_d1_fastidious_shard), graft_cand is combined with ncclAllReduce(min) (src/algod1.cc:244-258 keeps
 // the smallest heavy id), the two heavy-side counters add up.
 //
@@ -121,6 +121,38 @@ int all_gather_v(swa_multi * m, const std::vector<const void *> & src, const std
       }
     }
   }
+  for (int k = 0; k < world; ++k) {
+    if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
+      return fail(m, SWA_E_DEVICE, "synchronising the exchange failed");
+    }
+  }
+  return SWA_OK;
+}
+
+// every rank's buffer src[r] (count[r] elements of `bytes_per` bytes) into dst + prefix(r) on rank 0 ONLY: the consumer
+// of the gathered lists is the rank that builds the CSR, so nothing is sent to the others (an all-gather moved the
+// whole network into every GPU: 0.9 GB per rank at 8 x 10 M amplicons).  RCCL: one ncclSend per rank, the matching
+// ncclRecv on rank 0, all in one group; ranks sharing a device: device-to-device copies.
+int gather_to_root_v(swa_multi * m, const std::vector<const void *> & src, void * dst, const std::vector<uint64_t> & count, size_t bytes_per) {
+  const int world = (int)m->ctx.size();
+  swa_ctx * c0 = m->ctx[0];
+  std::vector<uint64_t> at((size_t)world + 1, 0);
+  for (int r = 0; r < world; ++r) { at[(size_t)r + 1] = at[(size_t)r] + count[(size_t)r]; }
+  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupStart()); }
+  for (int r = 0; r < world; ++r) {
+    if (count[(size_t)r] == 0) { continue; }
+    char * recv = static_cast<char *>(dst) + at[(size_t)r] * bytes_per;
+    if (!m->comms.empty() && r != 0) {
+      NCCL_OK(m, ncclSend(src[(size_t)r], count[(size_t)r] * bytes_per, ncclUint8, 0, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
+      NCCL_OK(m, ncclRecv(recv, count[(size_t)r] * bytes_per, ncclUint8, r, m->comms[0], c0->stream));
+    } else {
+      if (hipSetDevice(c0->device) != hipSuccess ||
+          hipMemcpyAsync(recv, src[(size_t)r], count[(size_t)r] * bytes_per, hipMemcpyDefault, c0->stream) != hipSuccess) {
+        return fail(m, SWA_E_DEVICE, "device-to-device copy of a rank's list failed");
+      }
+    }
+  }
+  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupEnd()); }
   for (int k = 0; k < world; ++k) {
     if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
       return fail(m, SWA_E_DEVICE, "synchronising the exchange failed");
@@ -296,22 +328,36 @@ extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint
   });
   if (has_duplicates != nullptr) { *has_duplicates = 0; for (int d : dup) { *has_duplicates |= d; } }
   if (rc != SWA_OK) { return rc; }
-  // 2. all-gather of the link lists (counts are on the host already)
+  // 2. the link lists to rank 0, which builds the CSR (counts are on the host already)
   uint64_t all = 0;
   for (uint64_t c : count) { all += c; }
   *total = all;
   std::vector<const void *> src((size_t)world);
-  std::vector<void *> dst((size_t)world);
-  for (int r = 0; r < world; ++r) {
-    swa_ctx * c = m->ctx[(size_t)r];
+  for (int r = 0; r < world; ++r) { src[(size_t)r] = m->links[(size_t)r].ptr; }
+  {
+    swa_ctx * c = m->ctx[0];
     if (hipSetDevice(c->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
     // (sorted in place below: twice the room, for the radix sort's output)
-    rc = swa_reserve(c, m->gathered[(size_t)r], (2 * all + 2) * sizeof(uint64_t));
+    rc = swa_reserve(c, m->gathered[0], (2 * all + 2) * sizeof(uint64_t));
     if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
-    src[(size_t)r] = m->links[(size_t)r].ptr;
-    dst[(size_t)r] = m->gathered[(size_t)r].ptr;
   }
-  if (all != 0) { rc = all_gather_v(m, src, dst, count, sizeof(uint64_t)); if (rc != SWA_OK) { return rc; } }
+  // (SWARM_AMD_MULTI_EXCHANGE=allgather: the literal all-gather of SURVEY 8e — every GPU ends with every list)
+  const char * env_x = getenv("SWARM_AMD_MULTI_EXCHANGE");
+  if (all != 0 && env_x != nullptr && env_x[0] == 'a') {
+    std::vector<void *> dst((size_t)world);
+    for (int r = 0; r < world; ++r) {
+      swa_ctx * c = m->ctx[(size_t)r];
+      if (hipSetDevice(c->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
+      rc = swa_reserve(c, m->gathered[(size_t)r], (2 * all + 2) * sizeof(uint64_t));
+      if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
+      dst[(size_t)r] = m->gathered[(size_t)r].ptr;
+    }
+    rc = all_gather_v(m, src, dst, count, sizeof(uint64_t));
+    if (rc != SWA_OK) { return rc; }
+  } else if (all != 0) {
+    rc = gather_to_root_v(m, src, m->gathered[0].ptr, count, sizeof(uint64_t));
+    if (rc != SWA_OK) { return rc; }
+  }
   // 3. rank 0: sort by (source, target) -> CSR -> host
   swa_ctx * c0 = m->ctx[0];
   if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
