@@ -1345,8 +1345,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stream[kSbOver].ptr, 0, ((uint64_t)n + 8) & ~3ull, ctx->stream));
-  auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
-  SWA_HIP(ctx, hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), ctx->stream));
+  auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);                // (cleared by the caller: index build, or the retry)
   auto * scal = static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr);      // [0..3] level-0 chunk tables, [8 + i] totals (u32)
   const uint32_t win_a = ctx->anchor_a, win_b = ctx->anchor_b;
   const uint32_t minlen = win_a + win_b + kMinAnchoredLen, window_mode = (win_a != 0 || win_b != 0) ? 1u : 0u;
@@ -1525,6 +1524,19 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
   return SWA_OK;
 }
 
+// workgroups of k_d1_group_pairs<*, W> that one CU holds at a time (registers and LDS: the occupancy API; 1..8)
+static int pair_blocks_per_cu(int width) {
+  static int cached[2] = {0, 0};
+  int & c = cached[width == 5 ? 0 : 1];
+  if (c == 0) {
+    int nb = 0;
+    const hipError_t e = width == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 5>, kThreads, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 8>, kThreads, 0);
+    c = (e == hipSuccess && nb >= 1) ? std::min(nb, 8) : 4;
+  }
+  return c;
+}
+
 // anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
 // the plain kernel; edges / counts / edge counter as launch_network leaves them
 static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count, bool count_links) {
@@ -1533,7 +1545,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));
+  if (count_links) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream)); }
   // item counts [0,1] big / [3,4] small, fallback count [2], work counters of both passes [16..32)
   const int pairs_width = ctx->pair_lists ? pairs_width_for(ctx) : 0;
   // (with pair lists, made at index build: [0], [1] and [32..48) are the index's)
@@ -1588,6 +1600,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr) + small_items_at(ctx->db.n);
     a.item_count = acounters + 3 + pass;
     a.sched = acounters + 16 + 8 * pass;
+    a.sched_big = acounters + 5 + pass;
     a.small_chunk = pass == 0 ? kSmallChunkPrefix : kSmallChunkSuffix;
     a.table_slots = 2 * kSmallGroup;
     const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom
@@ -1600,12 +1613,14 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.pair_items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
     for (uint32_t c = 0; c <= kPairClasses; ++c) { a.pair_region[c] = pair_region(c, ctx->db.n); }
     a.pair_counters = acounters + 32 + 8 * pass;
+    // (the pair kernel hands its work out through counters: exactly the workgroups that are resident together, no second round)
+    const int pgrid = ctx->num_cus * pair_blocks_per_cu(pairs_width);
     if (pairs_width == 5) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 5>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 5>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
     } else if (pairs_width == 8) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 8>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 8>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
     } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk
@@ -2090,6 +2105,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
         // (the streaming index serves any query range; it is rebuilt when the owner changed)
         swa_t0(ctx, 7);
         SWA_TRY(launch_abundance_rank(ctx));
+        SWA_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, 0, sizeof(uint32_t), ctx->stream));
         SWA_TRY(build_stream_index(ctx, 0, 0));
         swa_t1(ctx, 7);
       } else if (!stream && (!ctx->anchor_ready || ctx->anchor_first != first || ctx->anchor_count != count)) {
@@ -2165,6 +2181,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
       // this rank owns more anchors than its share-sized key tables hold (skewed ownership):
       // size them for the whole range, which cannot overflow, and run again
       ctx->anchor_slack = 1;
+      if (ctx->stream_index) { ctx->stream_extra_bits = std::min<uint32_t>(ctx->stream_extra_bits + 2, 8); }   // (partition too coarse: finer)
       ctx->anchor_ready = false;
       continue;
     }
