@@ -103,19 +103,24 @@ int swa_db_upload(swa_ctx * ctx, const swa_db_view * host_db);
 int swa_db_attach(swa_ctx * ctx, const swa_db_view * device_db);
 
 /* ---- B1: d = 1 network --------------------------------------------------------- */
-/* Zobrist table (bit-identical to the reference's, src/zobrist.cc:49-80), seqhash[]
-   (src/db.cc:761), amplicon hash table and Bloom filter (src/hashtable.cc,
-   src/bloompat.cc) for ALL amplicons, built on the GPU.  *has_duplicates != 0 (and
-   SWA_E_DUPLICATES returned) when two amplicons have identical sequences. */
+/* The index the network calls work on — what the reference's hash_insert loop builds (src/algod1.cc:188-208,
+   1122-1150) — and its duplicate check: *has_duplicates != 0 (and SWA_E_DUPLICATES returned) when two amplicons have
+   identical sequences.  What is built depends on the database: sequences of 65..256 nt in abundance order get the two
+   anchor indexes of the streaming build (amplicons grouped by their first / last 32 nt; members, work lists and the
+   identical-sequence check in one pass over the amplicon lines: swarm_amd/csrc/d1_stream.inc) and nothing else; the
+   database-wide structures of the reference — Zobrist table (bit-identical, src/zobrist.cc:49-80), seqhash[]
+   (src/db.cc:761), amplicon hash table + Bloom filter (src/hashtable.cc, src/bloompat.cc) — are built only for what
+   needs them: sequences under 65 nt, groups too large for the pair kernels, a database not in abundance order, the
+   debug readers. */
 int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates);
 /* Multi-GPU form: the index covers the whole database as above, but only the amplicons of
    [first, first + count) are checked for an identical twin (anywhere in the database).  A job
    that gives every rank its slice and ORs the flags detects every duplicate exactly once more
    cheaply than every rank checking everything.  Returns SWA_E_DUPLICATES like the above. */
+int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates);
 /* Where the last index build put the two anchor windows that group the amplicons: out2 = {nt from the start, nt from
    the end}; (0, 0) = the first / last 32 nt, moved inwards when those are (nearly) the same for everybody. */
 int swa_d1_anchor_windows(const swa_ctx * ctx, uint32_t * out2);
-int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates);
 /* Multi-GPU by ownership (no reference counterpart: src/algod1.cc:641-669 splits the seeds over
    threads that share one table).  With world > 1 this context serves only its share of the
    probes: the anchor groups (amplicons sharing their first / last 32 nucleotides) whose key maps
@@ -172,7 +177,9 @@ int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t
 /* Introspection used by the parity tests (bit-exact against the oracle): copies to host.
    what: 0 seqhash u64[n] · 1 Bloom bitmap u64[table_size/8] · 2 Zobrist table
    u64[4*(longest+2)] · 3 probe statistics u64[8] of the last network call
-   {variants, bloom_pass, hash_match, verified, hits, 0,0,0} */
+   {variants, bloom_pass, hash_match, verified, hits, 0,0,0} (0..3 build the database-wide structures on demand)
+   · 10 / 11 member ids in group order of the streaming prefix / suffix index u32[n] · 12 / 13 their work-item
+   buffers · 14 the counters u32[64] · 15 the amplicon lines (tools/check_index.py, tools/check_stream.py) */
 int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out_bytes);
 uint64_t swa_d1_table_size(const swa_ctx * ctx);
 

@@ -170,6 +170,7 @@ static void invalidate(swa_ctx * ctx) {
   ctx->windows_ready = false;
   ctx->lines_ready = false;
   ctx->stream_index = false;
+  ctx->member_index = false;
   ctx->stream_extra_bits = 0;
   ctx->anchor_a = ctx->anchor_b = 0;
   ctx->qgram_ready = false;

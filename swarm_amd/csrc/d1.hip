@@ -1164,7 +1164,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 // SWA_D1_BUILD=table: round 2's hash-table build (k_anchor_place / k_anchor_scatter / k_scatter_edges), kept for
 // comparison and for sequences beyond 256 nt (the enumerating kernels read its structures)
 enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
-       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24 };
+       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27 };
 
 static bool stream_enabled() {
   const char * e = getenv("SWA_D1_BUILD");
@@ -1253,16 +1253,16 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     }
     const dim3 grid_t((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)cu_grid), j.nidx);
     hipLaunchKernelGGL(k_part_tiles, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_part_hist, grid_t, dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_part_hist<512>, grid_t, dim3(256), 0, ctx->stream, a);
     FlatScanArgs f{};
     f.unit_bits = bits;
     for (uint32_t i = 0; i < j.nidx; ++i) { f.v[i] = j.cnt[i]; f.units[i] = j.ctile[i] + chunks; f.partial[i] = j.partial[i]; f.total[i] = j.total[i]; }
     const dim3 grid_f((unsigned)std::min<uint64_t>(((tiles << bits) + 1 + kFlatChunk - 1) / kFlatChunk, (uint64_t)cu_grid), j.nidx);
     hipLaunchKernelGGL(k_flat_sums, grid_f, dim3(256), 0, ctx->stream, f);
     hipLaunchKernelGGL(k_flat_apply, grid_f, dim3(256), 0, ctx->stream, f);
-    if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<2, 4096>), grid_t, dim3(256), 0, ctx->stream, a); }
-    else if (j.buf_f[0][0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<1, 2048>), grid_t, dim3(256), 0, ctx->stream, a); }
-    else { hipLaunchKernelGGL((k_part_scatter<0, 4096>), grid_t, dim3(256), 0, ctx->stream, a); }
+    if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<2, 4096, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
+    else if (j.buf_f[0][0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<1, 2048, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_part_scatter<0, 4096, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
     chunks = (single ? 1 : chunks) << bits;
     single = false;
     hipLaunchKernelGGL(k_part_starts, dim3((unsigned)std::min<uint64_t>((chunks + 256) / 256, (uint64_t)cu_grid), j.nidx), dim3(256), 0, ctx->stream, a);
@@ -1411,6 +1411,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     SWA_HIP(ctx, hipMemsetAsync(x.kind_cnt + (uint64_t)kListKinds * x.buckets, 0, sizeof(uint32_t), ctx->stream));
   }
   g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
+  if (const char * env_cap = getenv("SWA_D1_GROUP_CAP")) { g.group_cap = std::max<uint32_t>(g.pair_big, (uint32_t)atoi(env_cap)); }   // (experiments)
   g.flags = dflags;
   g.over = static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr);
   g.dup_first = dup_first; g.dup_count = dup_count;
@@ -1641,7 +1642,8 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   }
   // seeds (or halves of seeds) the anchored passes skipped (a lean build has made sure there are none: no sequence
   // too short, no oversized group — and what holds for the whole database holds for every part of it)
-  if (ctx->full_index && ctx->stream_index) {
+  const bool use_member_table = ctx->member_index && !ctx->full_index;
+  if ((ctx->full_index || ctx->member_index) && ctx->stream_index) {
     hipLaunchKernelGGL(k_stream_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first, count,
                        static_cast<const uint8_t *>(ctx->d_stream[kSbOver].ptr), static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2,
                        ctx->owner_rank, ctx->owner_world, ctx->db.seqs, ctx->db.seq_off, ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen,
@@ -1657,10 +1659,10 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
   f.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
   f.zlen = ctx->zobrist_len; f.maxwords = maxwords;
-  f.table = static_cast<const swa_slot *>(ctx->d_table.ptr);
-  f.tmask = ctx->table_size - 1;
-  f.bloom = static_cast<const uint64_t *>(ctx->d_bloom.ptr);
-  f.bmask = ctx->bloom_words - 1;
+  f.table = static_cast<const swa_slot *>(use_member_table ? ctx->d_stream[kSbMTable].ptr : ctx->d_table.ptr);
+  f.tmask = (use_member_table ? ctx->mtable_size : ctx->table_size) - 1;
+  f.bloom = static_cast<const uint64_t *>(use_member_table ? ctx->d_stream[kSbMBloom].ptr : ctx->d_bloom.ptr);
+  f.bmask = (use_member_table ? ctx->mbloom_words : ctx->bloom_words) - 1;
   f.patterns = static_cast<const uint64_t *>(ctx->d_patterns.ptr);
   f.no_cluster_breaking = ncb;
   f.first = first; f.count = count;
@@ -1679,7 +1681,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   const int fgrid = grid_for(ctx, count, kWaves, 8);
   // (a rank that built only its owned groups has no table: by construction its fallback list is
   // empty — network_run checks the count and builds the full index if that ever fails to hold)
-  if (!ctx->full_index) { /* nothing to probe against */ }
+  if (!ctx->full_index && !ctx->member_index) { /* nothing to probe against */ }
   else if (zlds) { hipLaunchKernelGGL((k_d1_probe<true, false, 2>), dim3(fgrid), dim3(kThreads), flds, ctx->stream, f); }
   else { hipLaunchKernelGGL((k_d1_probe<false, false, 2>), dim3(fgrid), dim3(kThreads), flds, ctx->stream, f); }
   swa_t1(ctx, 3);
@@ -1807,6 +1809,47 @@ static int ensure_anchor_windows(swa_ctx * ctx) {
   return SWA_OK;
 }
 
+// Hash table + Bloom filter of the members of oversized groups ONLY (the streaming build marks them: one byte per
+// amplicon), for the plain kernel that serves their halves: a neighbour that shares the window of an oversized group is
+// a member of that group, so nothing else needs to be in the table — and a Bloom filter of a few megabytes stays in L2
+// where the database-wide one (one byte per table slot: 33 MB at 10 M) is a random HBM / Infinity-Cache line per probe.
+// Identical sequences among the members are found through the same table (k_dup_check), as the reference finds them
+// while it inserts (src/algod1.cc:1131-1150).  SWA_D1_MEMBER_TABLE=0: the database-wide structures instead.
+static bool member_index_enabled() {
+  const char * e = getenv("SWA_D1_MEMBER_TABLE");
+  return !(e != nullptr && e[0] == '0');
+}
+
+static int build_member_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_count) {
+  ctx->member_index = false;
+  const uint32_t n = ctx->db.n;
+  SWA_TRY(swa_hash_sequences(ctx));                          // Zobrist hashes + the XOR streams of every amplicon (k_seqhash)
+  uint64_t slots = 1024;
+  while (slots < 2ull * ctx->over_mass) { slots <<= 1; }
+  const uint64_t words = std::max<uint64_t>(slots >> 3, 1);  // one byte of filter per slot, as the reference sizes it
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbMTable], slots * sizeof(swa_slot)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbMBloom], words * sizeof(uint64_t)));
+  auto * table = static_cast<swa_slot *>(ctx->d_stream[kSbMTable].ptr);
+  auto * bloom = static_cast<uint64_t *>(ctx->d_stream[kSbMBloom].ptr);
+  swa_t0(ctx, 1);
+  hipLaunchKernelGGL(k_table_clear, dim3(grid_for(ctx, slots, 256, 8)), dim3(256), 0, ctx->stream, table, slots, bloom, words);
+  hipLaunchKernelGGL(k_table_insert, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, static_cast<const uint64_t *>(ctx->d_seqhash.ptr), n,
+                     static_cast<const uint8_t *>(ctx->d_stream[kSbOver].ptr), table, slots - 1, reinterpret_cast<unsigned long long *>(bloom), words - 1,
+                     static_cast<const uint64_t *>(ctx->d_patterns.ptr));
+  swa_t1(ctx, 1);
+  swa_t0(ctx, 2);
+  if (dup_count != 0) {
+    hipLaunchKernelGGL(k_dup_check, dim3(grid_for(ctx, dup_count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen,
+                       static_cast<const uint64_t *>(ctx->d_seqhash.ptr), dup_first, dup_count, table, slots - 1, static_cast<uint32_t *>(ctx->d_flags.ptr));
+  }
+  swa_t1(ctx, 2);
+  SWA_HIP(ctx, hipGetLastError());
+  ctx->mtable_size = slots;
+  ctx->mbloom_words = words;
+  ctx->member_index = true;
+  return SWA_OK;
+}
+
 // Index build of a rank that serves only the anchor groups it owns (swa_d1_set_ownership,
 // world > 1), without anything proportional to the database except streaming passes: abundance
 // ranks, the anchor indexes of the owned groups (all their members), hashes and XOR streams of
@@ -1895,6 +1938,9 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   }
   if (flags[1] != 0) { ctx->db_unordered = true; }
   *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
+  // (oversized groups are the ONLY reason: a table of their members alone serves the plain kernel — build_member_index)
+  ctx->only_oversized = ctx->stream_index && flags[4] != 0 && flags[1] == 0 && flags[3] == 0;
+  ctx->over_mass = flags[5];
   // Zobrist hashes and XOR streams of the members: only the enumerating kernels read them (the pair kernels compare
   // the sequences themselves, the duplicate check their fingerprints); the full route hashes everybody anyway
   ctx->aux_members = false;
@@ -1917,6 +1963,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   ctx->csr_ready = false;                                   // (a resident network belongs to the index it was made from)
   ctx->anchor_ready = false;
   ctx->full_index = false;
+  ctx->member_index = false;
   ctx->aux_complete = false;
   ctx->anchor_a = ctx->anchor_b = 0;
   for (int slot : {0, 1, 2, 7, 8, 9, 10, 15}) { ctx->ev_used[slot] = false; }   // phases this build does not run report 0
@@ -1975,6 +2022,11 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     }
     ctx->windows_chosen = ctx->anchor_a;                     // (what the safety net settled on, for the next build)
     owned_ok = !needs_table;
+    if (!owned_ok && ctx->only_oversized && member_index_enabled()) {
+      // nothing but groups too large for the pair kernels stands in the way: a table of their members is all the plain kernel needs
+      SWA_TRY(build_member_index(ctx, ctx->owner_world > 1 ? 0u : first, ctx->owner_world > 1 ? n : count));
+      owned_ok = true;
+    }
     ctx->aux_complete = owned_ok && ctx->owner_world == 1 && (ctx->aux_members || !ctx->aux_needed);
     SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2134,7 +2186,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     SWA_HIP(ctx, hipMemcpyAsync(&anchor_overflow, static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
     uint32_t unserved = 0;                                   // fallback seeds listed while there is no table to serve them
-    const bool check_unserved = ctx->anchor_usable && !stats && !ctx->full_index;
+    const bool check_unserved = ctx->anchor_usable && !stats && !ctx->full_index && !ctx->member_index;
     if (check_unserved) {
       SWA_HIP(ctx, hipMemcpyAsync(&unserved, static_cast<uint32_t *>(ctx->d_acounters.ptr) + 2, sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, ctx->stream));

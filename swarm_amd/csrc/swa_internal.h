@@ -133,8 +133,12 @@ struct swa_ctx {
   // [0] lines [1..4] records ping / pong per index [5, 6] fingerprints ping / pong [7] table slots of big buckets
   // [8, 9] flat counts [10, 11] tile tables [12, 13] chunk starts [14, 15] scan partials [16] scalars
   // [17, 18] members [19] oversized-group bits [20, 21] items per kind [22] link sort: records ping [23] pong
-  // [24] buckets of the CSR stage left to whole workgroups
-  swa_dbuf d_stream[26];
+  // [24] buckets of the CSR stage left to whole workgroups [26] member table [27] member Bloom
+  swa_dbuf d_stream[28];
+  // member index: hash table + Bloom of the members of oversized groups only (what the plain kernel probes for them)
+  bool member_index = false, only_oversized = false;
+  uint32_t over_mass = 0;
+  uint64_t mtable_size = 0, mbloom_words = 0;
 
   // the d = 1 network kept in d_offsets_tmp / d_nb_tmp (swa_d1_network_resident) and its clustering (cluster_gpu.hip)
   bool csr_ready = false;

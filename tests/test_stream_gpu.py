@@ -59,3 +59,14 @@ def test_heavy_tailed_sets_equal_the_oracle(tmp_path, monkeypatch, name, env, li
     if name == "core":
         assert ctx.d1_anchor_windows() != (0, 0)
     ctx.close()
+
+
+def test_table_route_index_keys_against_the_host():
+    """tools/repro/anchor_race: the table route's index kernels in four launch orders, every key of both tables checked
+    against keys computed on the host, 25 rounds each (the round-1 anomaly's reproducer, in the suite since round 3)."""
+    exe = S.ROOT / "tools" / "repro" / "anchor_race"
+    if not exe.exists():
+        pytest.skip("tools/repro/anchor_race not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([str(exe), "300000", "25"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "0 / 25 rounds with wrong anchor keys" in r.stdout
