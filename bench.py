@@ -17,6 +17,7 @@ rank r serves the anchor groups whose key maps to r (routed index build), the li
 At N = 1 the same run also measures, after the timed region (none of it enters `value`; --no-extras skips it):
   config.configs1 / configs2 / configs3   BASELINE configs[1..3]
   config.skewed / config.heavy_tail        the headline step on conserved flanks / on Zipf-sized families
+  config.d1_x400                           the d=1 step on 1 M amplicons of 400 bp
   config.whole_run                         FASTA -> -o through the drop-in command line, 1 M (md5 vs the reference) and 10 M
   config.host_seam_ms                      swa_db_upload + index + swa_d1_network from / to host buffers (PCIe inclusive)
   roofline.traffic / roofline.kernels      HBM bytes and VALU instructions per kernel from nested rocprofv3 --pmc passes,
@@ -798,6 +799,8 @@ def main() -> None:
                                            "sample": f"unmodified reference swarm 3.1.6 -d 1 -t 16, whole run on the {n_total} x {args.length} bp set of the headline"}
             for name, fn in (("skewed", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 40)),
                              ("heavy_tail", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 0, 0.1)),
+                             # 400-bp amplicons: the pair route with 13-word records (128-byte lines), 1 M x 400, d = 1
+                             ("d1_x400", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 400}), 1_000_000, 5)),
                              ("host_seam_ms", lambda: host_seam(args, n_total)),
                              ("whole_run", lambda: whole_run(args, n_total, ref_md5, sample_n)),
                              ("configs2", lambda: config2_fastidious(args, args.per_gpu)),

@@ -991,7 +991,7 @@ static int pairs_width_for(const swa_ctx * ctx) {
   const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
   const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;       // (only chosen when the pair kernels apply)
   if (env_enum != nullptr && env_enum[0] == '1' && !window_mode) { return 0; }
-  return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0);
+  return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0));
 }
 // groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
 // them to the enumerating / tiled kernel (test switch)
@@ -1162,7 +1162,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 
 // ---- the streaming build (d1_stream.inc) ------------------------------------------------------
 // SWA_D1_BUILD=table: round 2's hash-table build (k_anchor_place / k_anchor_scatter / k_scatter_edges), kept for
-// comparison and for sequences beyond 256 nt (the enumerating kernels read its structures)
+// comparison and for sequences beyond 416 nt (the enumerating kernels read its structures)
 enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
        kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27 };
 
@@ -1170,7 +1170,7 @@ static bool stream_enabled() {
   const char * e = getenv("SWA_D1_BUILD");
   return !(e != nullptr && e[0] == 't');
 }
-static int lines_width_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : 0); }
+static int lines_width_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0)); }
 
 struct PartPlan { uint32_t levels; uint32_t bits[4]; uint32_t total; };
 static PartPlan plan_levels(uint32_t total_bits) {
@@ -1285,7 +1285,7 @@ __global__ void k_set_u64x2(uint64_t * p0, uint64_t a0, uint64_t b0, uint64_t * 
 // the amplicon lines of the uploaded database (once per upload; needs the abundance ranks)
 static int ensure_lines(swa_ctx * ctx) {
   const int w = lines_width_for(ctx);
-  if (w == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "amplicon lines: sequences longer than 256 nt"); }
+  if (w == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "amplicon lines: sequences longer than 416 nt"); }
   if (ctx->lines_ready && ctx->lines_w == w) { return SWA_OK; }
   const uint32_t n = ctx->db.n;
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbLines], (uint64_t)n * (w == 5 ? 64u : 128u)));
@@ -1293,6 +1293,7 @@ static int ensure_lines(swa_ctx * ctx) {
   const auto * rank = static_cast<const uint32_t *>(ctx->d_arank.ptr);
   swa_t0(ctx, 15);
   if (w == 5) { hipLaunchKernelGGL(k_lines_build<5>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
+  else if (w == 13) { hipLaunchKernelGGL(k_lines_build<13>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
   else { hipLaunchKernelGGL(k_lines_build<8>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
   swa_t1(ctx, 15);
   SWA_HIP(ctx, hipGetLastError());
@@ -1369,7 +1370,9 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   }
   const dim3 kgrid((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u);
   swa_t0(ctx, 8);
-  if (w == 5) { hipLaunchKernelGGL(k_keys<5>, kgrid, dim3(256), 0, ctx->stream, k); } else { hipLaunchKernelGGL(k_keys<8>, kgrid, dim3(256), 0, ctx->stream, k); }
+  if (w == 5) { hipLaunchKernelGGL(k_keys<5>, kgrid, dim3(256), 0, ctx->stream, k); }
+  else if (w == 13) { hipLaunchKernelGGL(k_keys<13>, kgrid, dim3(256), 0, ctx->stream, k); }
+  else { hipLaunchKernelGGL(k_keys<8>, kgrid, dim3(256), 0, ctx->stream, k); }
   hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, ctx->stream, scal, (uint64_t)0, (uint64_t)(routed ? ctx->route_m[0] : n), scal + 2, (uint64_t)0,
                      (uint64_t)(routed ? ctx->route_m[1] : n));
   swa_t1(ctx, 8);
@@ -1415,7 +1418,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.flags = dflags;
   g.over = static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr);
   g.dup_first = dup_first; g.dup_count = dup_count;
-  g.lines = k.lines; g.line_quads = w == 5 ? 4u : 8u; g.line_w = (uint32_t)w;
+  g.lines = k.lines; g.line_quads = w == 5 ? 4u : 8u; g.line_w = (uint32_t)w;   // (64-byte lines for W = 5, 128-byte lines for W = 8, 13)
   g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
   swa_t0(ctx, 10);
   hipLaunchKernelGGL(k_group, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus * 12), 2), dim3(256), 0, ctx->stream, g);
@@ -1527,12 +1530,13 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
 
 // workgroups of k_d1_group_pairs<*, W> that one CU holds at a time (registers and LDS: the occupancy API; 1..8)
 static int pair_blocks_per_cu(int width) {
-  static int cached[2] = {0, 0};
-  int & c = cached[width == 5 ? 0 : 1];
+  static int cached[3] = {0, 0, 0};
+  int & c = cached[width == 5 ? 0 : (width == 8 ? 1 : 2)];
   if (c == 0) {
     int nb = 0;
     const hipError_t e = width == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 5>, kThreads, 0)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 8>, kThreads, 0);
+                       : width == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 8>, kThreads, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 13>, kThreads, 0);
     c = (e == hipSuccess && nb >= 1) ? std::min(nb, 8) : 4;
   }
   return c;
@@ -1622,6 +1626,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     } else if (pairs_width == 8) {
       if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 8>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
       else { hipLaunchKernelGGL((k_d1_group_pairs<1, 8>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
+    } else if (pairs_width == 13) {
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 13>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 13>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
     } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk
@@ -1632,6 +1639,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     if (tiled_big && pairs_width == 5) {
       if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
       else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+    } else if (tiled_big && pairs_width == 13) {
+      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 13>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
+      else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 13>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
     } else if (tiled_big) {
       if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
       else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
@@ -1767,11 +1777,11 @@ static int ensure_full_index(swa_ctx * ctx) {
 
 // Anchor windows for this database, from a sample (k_anchor_sample): the smallest offset whose estimated share of
 // amplicons in oversized groups and of too-short seeds is below 1 / 64 each; (0, 0) when nothing is skewed, which is
-// the normal case.  Window mode needs the pair kernels (sequences up to 256 nt); SWA_D1_WINDOWS=0 switches it off.
+// the normal case.  Window mode needs the pair kernels (sequences up to 416 nt); SWA_D1_WINDOWS=0 switches it off.
 static int choose_anchor_windows(swa_ctx * ctx) {
   ctx->anchor_a = ctx->anchor_b = 0;
   const char * env_win = getenv("SWA_D1_WINDOWS");
-  if (ctx->db.longest > 256u || (env_win != nullptr && env_win[0] == '0')) { return SWA_OK; }
+  if (ctx->db.longest > 416u || (env_win != nullptr && env_win[0] == '0')) { return SWA_OK; }
   const uint32_t n = ctx->db.n;
   const uint32_t stride = std::max<uint32_t>(1u, n / 65536u);
   const uint32_t samples = (n + stride - 1) / stride;
@@ -1998,13 +2008,13 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     // Conserved flanks: when a noticeable part of the database sits in groups too large for LDS (everybody shares
     // the first or last 32 nt), the anchor windows move inwards, 32 nt at a time, as far as the shortest sequence
     // allows (every seed needs win_a + win_b + 65 nt), and the setting with the fewest stranded members wins.  Window
-    // mode needs the pair kernels (sequences up to 256 nt); SWA_D1_WINDOWS=0 switches the search off.
+    // mode needs the pair kernels (sequences up to 416 nt); SWA_D1_WINDOWS=0 switches the search off.
     const char * env_win = getenv("SWA_D1_WINDOWS");
     // (safety net behind the sample: the real build still found too many stranded members — try the next offsets.
     // Single GPU only: under ownership `mass` counts the oversized groups THIS rank owns, the ranks would settle on
     // different windows and divide the pairs differently; there the sampled choice — the same on every rank — stands
     // and oversized groups take the plain kernel)
-    if (!routed && ctx->owner_world == 1 && needs_table && mass > n / 64u && ctx->db.longest <= 256u && !(env_win != nullptr && env_win[0] == '0')) {
+    if (!routed && ctx->owner_world == 1 && needs_table && mass > n / 64u && ctx->db.longest <= 416u && !(env_win != nullptr && env_win[0] == '0')) {
       uint32_t best = sampled, best_mass = mass;
       for (uint32_t w = sampled + 32u; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
         ctx->anchor_a = ctx->anchor_b = w;
