@@ -699,12 +699,15 @@ def main() -> None:
             abytes = algorithmic_bytes(hdb.seqlen, 0) / (sim_world or world) + 4.0 * hits_seen[0]
         else:
             abytes = algorithmic_bytes(hdb.seqlen[first:first + count], hits_seen[0])
-        # levels of the two partitions (the library's arithmetic: buckets of <= 700 key records; 2^8 sources per link bucket)
+        # levels of the two partitions (the library's arithmetic: buckets of <= 10 240 key records, up to 10 bits a level — or, with
+        # SWA_D1_GROUPS=small, <= 700 and 9; 2^8 sources per link bucket, 9 bits a level)
+        small_groups = os.environ.get("SWA_D1_GROUPS", "")[:1] == "s"
         bits = 1
-        while (count >> bits) > 700:
+        while (count >> bits) > (700 if small_groups else 10240):
             bits += 1
+        per_level = 9 if small_groups else 10
         nbits = max(1, int(np.ceil(np.log2(max(2, q_count)))))
-        model = step_byte_model(count, hits_seen[0], (bits + 8) // 9, (max(1, nbits - min(8, nbits - 1)) + 8) // 9)
+        model = step_byte_model(count, hits_seen[0], (bits + per_level - 1) // per_level, (max(1, nbits - min(8, nbits - 1)) + 8) // 9)
         kernels = {}
         for g, ms in group_ms.items():
             if ms > 0.0:
@@ -836,7 +839,9 @@ def main() -> None:
                 # VALU issue for the pair kernels (and their line fetches against the random-line rate)
                 if ceil is not None:
                     copy = ceil.get("stream_copy", {}).get("rate")
-                    valu = ceil.get("valu_3op", {}).get("rate")
+                    # (two instruction mixes are measured: the pair test's own v_ffbl / v_min and plain full-rate integer ones; the
+                    # ceiling is the higher rate)
+                    valu = max((ceil.get(k, {}).get("rate") or 0.0) for k in ("valu_3op", "valu_simple")) or None
                     lines = ceil.get("gather64", {}).get("rate")
                     for g, rec in out["roofline"]["kernels"].items():
                         if g.startswith("pairs"):

@@ -1164,7 +1164,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 // SWA_D1_BUILD=table: round 2's hash-table build (k_anchor_place / k_anchor_scatter / k_scatter_edges), kept for
 // comparison and for sequences beyond 416 nt (the enumerating kernels read its structures)
 enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
-       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27 };
+       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27, kSbSched = 28 };
 
 static bool stream_enabled() {
   const char * e = getenv("SWA_D1_BUILD");
@@ -1173,10 +1173,10 @@ static bool stream_enabled() {
 static int lines_width_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0)); }
 
 struct PartPlan { uint32_t levels; uint32_t bits[4]; uint32_t total; };
-static PartPlan plan_levels(uint32_t total_bits) {
+static PartPlan plan_levels(uint32_t total_bits, uint32_t max_bits = kPartMaxBits) {
   PartPlan p{};
   p.total = std::max(1u, total_bits);
-  p.levels = (p.total + kPartMaxBits - 1) / kPartMaxBits;
+  p.levels = (p.total + max_bits - 1) / max_bits;
   for (uint32_t l = 0; l < p.levels; ++l) { p.bits[l] = p.total / p.levels + (l < p.total % p.levels ? 1u : 0u); }
   return p;
 }
@@ -1253,7 +1253,9 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     }
     const dim3 grid_t((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)cu_grid), j.nidx);
     hipLaunchKernelGGL(k_part_tiles, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_part_hist<512>, grid_t, dim3(256), 0, ctx->stream, a);
+    const bool bins1024 = bits > kPartMaxBits;                 // (the key records of the one-level form: 10 bits)
+    if (bins1024) { hipLaunchKernelGGL(k_part_hist<1024>, grid_t, dim3(256), 0, ctx->stream, a); }
+    else { hipLaunchKernelGGL(k_part_hist<512>, grid_t, dim3(256), 0, ctx->stream, a); }
     FlatScanArgs f{};
     f.unit_bits = bits;
     for (uint32_t i = 0; i < j.nidx; ++i) { f.v[i] = j.cnt[i]; f.units[i] = j.ctile[i] + chunks; f.partial[i] = j.partial[i]; f.total[i] = j.total[i]; }
@@ -1261,6 +1263,8 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     hipLaunchKernelGGL(k_flat_sums, grid_f, dim3(256), 0, ctx->stream, f);
     hipLaunchKernelGGL(k_flat_apply, grid_f, dim3(256), 0, ctx->stream, f);
     if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<2, 4096, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
+    else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 4096) { hipLaunchKernelGGL((k_part_scatter<1, 4096, 1024>), grid_t, dim3(256), 0, ctx->stream, a); }
+    else if (j.buf_f[0][0] != nullptr && bins1024) { hipLaunchKernelGGL((k_part_scatter<1, 2048, 1024>), grid_t, dim3(256), 0, ctx->stream, a); }
     else if (j.buf_f[0][0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<1, 2048, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_part_scatter<0, 4096, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
     chunks = (single ? 1 : chunks) << bits;
@@ -1313,16 +1317,22 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   SWA_TRY(ensure_lines(ctx));
   const bool routed = ctx->route_ids[0] != nullptr;
   const uint64_t records = routed ? std::max<uint64_t>(std::max(ctx->route_m[0], ctx->route_m[1]), 1) : n;
-  // buckets of at most kGroupTarget records on average: the group kernel stages kGroupCapRecords
+  // Large buckets (k_group1: ~10 000 records, ONE partition level of up to 10 bits at 10 M amplicons) or small ones (k_group:
+  // ~600 records, two levels); SWA_D1_GROUPS=small selects the latter (comparison switch).
+  const char * env_groups = getenv("SWA_D1_GROUPS");
+  const bool large_buckets = !(env_groups != nullptr && env_groups[0] == 's');
+  const uint32_t target = large_buckets ? kG1Target : kGroupTarget, level_bits = large_buckets ? 10u : kPartMaxBits;
   uint32_t total_bits = 1;
-  while ((records >> total_bits) > kGroupTarget && total_bits < 3 * kPartMaxBits) { ++total_bits; }
+  while ((records >> total_bits) > target && total_bits < 3 * kPartMaxBits) { ++total_bits; }
   total_bits = std::min<uint32_t>(total_bits + ctx->stream_extra_bits, 3 * kPartMaxBits);
   PartJob j;
   j.nidx = 2;
-  j.plan = plan_levels(total_bits);
+  j.plan = plan_levels(total_bits, level_bits);
   j.max_records = records;
   j.out_cap = records + 1;
-  j.tile = 2048;
+  // (tiles of 2048 records for 512 bins; one level of 1024 bins: 4096, or the flat count array — bins x tiles — and the 16-byte runs
+  // a tile leaves per bin cost more than the saved level: 0.56 -> 0.43 ms at 10 M amplicons)
+  j.tile = (total_bits > kPartMaxBits && j.plan.levels == 1) ? 4096 : 2048;
   j.max_tiles0 = records / j.tile + 2;
   j.chunks0 = 1; j.single0 = true; j.top_bit = 32; j.bias = 0;
   uint64_t e_cnt, e_tile, e_start, e_partial;
@@ -1421,7 +1431,16 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.lines = k.lines; g.line_quads = w == 5 ? 4u : 8u; g.line_w = (uint32_t)w;   // (64-byte lines for W = 5, 128-byte lines for W = 8, 13)
   g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
   swa_t0(ctx, 10);
-  hipLaunchKernelGGL(k_group, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus * 12), 2), dim3(256), 0, ctx->stream, g);
+  if (large_buckets) {
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {                                        // (112 KB of dynamic LDS: above the 64 KB a kernel gets unasked)
+      SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_group1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kG1LdsBytes));
+      lds_opt_in = true;
+    }
+    hipLaunchKernelGGL(k_group1, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus), 2), dim3(kG1Threads), kG1LdsBytes, ctx->stream, g);
+  } else {
+    hipLaunchKernelGGL(k_group, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus * 12), 2), dim3(256), 0, ctx->stream, g);
+  }
 
   // ---- work lists
   FlatScanArgs f{};
@@ -1443,7 +1462,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   hipLaunchKernelGGL(k_flat_sums, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_flat_apply, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_group_lists, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, (uint64_t)ctx->num_cus * 8), 2), dim3(256), 0, ctx->stream, la);
-  {
+  if (!large_buckets) {
     DupTiledArgs dt{};                                       // identical sequences inside the large prefix groups (chunk list)
     dt.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr); dt.item_count = acounters + 0;
     dt.members = g.g[0].members; dt.fp_sorted = g.g[0].fp_sorted; dt.g = g;
@@ -1555,6 +1574,16 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   const int pairs_width = ctx->pair_lists ? pairs_width_for(ctx) : 0;
   // (with pair lists, made at index build: [0], [1] and [32..48) are the index's)
   SWA_HIP(ctx, hipMemsetAsync(acounters + (pairs_width != 0 ? 2 : 0), 0, (pairs_width != 0 ? 30 : 32) * sizeof(uint32_t), ctx->stream));
+  // work counters of k_d1_group_pairs (both passes): 2^shard_bits of them, sched_stride entries apart
+  uint32_t pair_batch = 4, shard_bits = 6, sched_stride = 64;
+  if (const char * e = getenv("SWA_D1_PAIR_BATCH")) { pair_batch = (uint32_t)std::max(1, atoi(e)); }                           // (experiments)
+  if (const char * e = getenv("SWA_D1_PAIR_SHARD_BITS")) { shard_bits = (uint32_t)std::min(10, std::max(0, atoi(e))); }
+  if (const char * e = getenv("SWA_D1_SCHED_STRIDE")) { sched_stride = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
+  if (pairs_width != 0) {
+    const uint64_t bytes = (2ull << shard_bits) * sched_stride * sizeof(uint32_t);
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSched], bytes));
+    SWA_HIP(ctx, hipMemsetAsync(ctx->d_stream[kSbSched].ptr, 0, bytes, ctx->stream));
+  }
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
   auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
@@ -1606,6 +1635,8 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.item_count = acounters + 3 + pass;
     a.sched = acounters + 16 + 8 * pass;
     a.sched_big = acounters + 5 + pass;
+    a.batch = pair_batch; a.shard_bits = shard_bits; a.sched_stride = sched_stride;
+    a.sched_wide = static_cast<uint32_t *>(ctx->d_stream[kSbSched].ptr) + ((uint64_t)pass << shard_bits) * sched_stride;
     a.small_chunk = pass == 0 ? kSmallChunkPrefix : kSmallChunkSuffix;
     a.table_slots = 2 * kSmallGroup;
     const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom

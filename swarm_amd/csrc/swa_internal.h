@@ -134,7 +134,7 @@ struct swa_ctx {
   // [8, 9] flat counts [10, 11] tile tables [12, 13] chunk starts [14, 15] scan partials [16] scalars
   // [17, 18] members [19] oversized-group bits [20, 21] items per kind [22] link sort: records ping [23] pong
   // [24] buckets of the CSR stage left to whole workgroups [26] member table [27] member Bloom
-  swa_dbuf d_stream[28];
+  swa_dbuf d_stream[30];
   // member index: hash table + Bloom of the members of oversized groups only (what the plain kernel probes for them)
   bool member_index = false, only_oversized = false;
   uint32_t over_mass = 0;

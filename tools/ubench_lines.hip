@@ -127,6 +127,25 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t * sink, uint32_t rounds, 
   if (acc == 0x12345u) { sink[0] = acc; }
 }
 
+// the same with full-rate integer instructions only (v_xor, v_add, v_and): the issue rate itself
+__global__ __launch_bounds__(256) void k_valu_simple(uint32_t * sink, uint32_t rounds, uint32_t seed) {
+  uint32_t a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = seed * (threadIdx.x + 1u) + (uint32_t)i; }
+  for (uint32_t r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t f;
+      asm volatile("v_and_b32 %0, %1, %2" : "=v"(f) : "v"(a[i] ^ r), "v"(0x7FFFFFFFu));
+      asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(f));
+    }
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { acc ^= a[i]; }
+  if (acc == 0x12345u) { sink[0] = acc; }
+}
+
 struct Timer {
   hipEvent_t a, b;
   Timer() { CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b)); }
@@ -225,6 +244,8 @@ int main(int argc, char ** argv) {
     const double ms = tm.best_ms([&](int r) { hipLaunchKernelGGL(k_valu, dim3(blocks), dim3(256), 0, nullptr, sink, rounds, (uint32_t)r + 1u); });
     const double wave_insts = (double)blocks * 4.0 * rounds * 8.0 * 3.0;       // v_xor + v_ffbl + v_min per chain step
     emit("valu_3op", 0, ms, wave_insts, "wave-instructions/s (v_xor + v_ffbl + v_min, eight independent chains)", 0, 0);
+    const double ms2 = tm.best_ms([&](int r) { hipLaunchKernelGGL(k_valu_simple, dim3(blocks), dim3(256), 0, nullptr, sink, rounds, (uint32_t)r + 1u); });
+    emit("valu_simple", 0, ms2, wave_insts, "wave-instructions/s (v_xor + v_and + v_add, eight independent chains)", 0, 0);
   }
   json += "]}";
   if (argc > 1) {
