@@ -2594,6 +2594,14 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
   auto * item_counter = dflags + 8;                          // [8] item counter, [9] key table overflow
   uint64_t npairs = 0;
+  // pairs on the amplicon lines, sequences in registers (up to 416 nt; SWA_FAST_PAIRS=words: the round-2 kernel, which
+  // walks the packed sequences — comparison switch)
+  const char * env_fp = getenv("SWA_FAST_PAIRS");
+  const int pair_w = (env_fp != nullptr && env_fp[0] == 'w') ? 0 : lines_width_for(ctx);
+  if (pair_w != 0 && !(ctx->lines_ready && ctx->lines_w == pair_w)) {
+    SWA_TRY(launch_abundance_rank(ctx));
+    SWA_TRY(ensure_lines(ctx));
+  }
   swa_t0(ctx, 5);
   for (int attempt = 0; attempt < 6; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_fpairs, ctx->fast_pair_cap * sizeof(uint64_t)));
@@ -2627,7 +2635,21 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
       p.items = items; p.item_count = item_counter; p.item_cap = item_cap;
       p.pairs = static_cast<unsigned long long *>(ctx->d_fpairs.ptr); p.pair_counter = fc + 5; p.pair_cap = ctx->fast_pair_cap;
       const dim3 gp(ctx->num_cus * 8);
-      if (type == 0) { hipLaunchKernelGGL(k_fast_pairs<0>, gp, dim3(kThreads), 0, ctx->stream, p); }
+      p.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
+      if (pair_w == 5) {
+        if (type == 0) { hipLaunchKernelGGL((k_fast_pairs_lines<0, 5>), gp, dim3(kThreads), 0, ctx->stream, p); }
+        else if (type == 1) { hipLaunchKernelGGL((k_fast_pairs_lines<1, 5>), gp, dim3(kThreads), 0, ctx->stream, p); }
+        else { hipLaunchKernelGGL((k_fast_pairs_lines<2, 5>), gp, dim3(kThreads), 0, ctx->stream, p); }
+      } else if (pair_w == 8) {
+        if (type == 0) { hipLaunchKernelGGL((k_fast_pairs_lines<0, 8>), gp, dim3(kThreads), 0, ctx->stream, p); }
+        else if (type == 1) { hipLaunchKernelGGL((k_fast_pairs_lines<1, 8>), gp, dim3(kThreads), 0, ctx->stream, p); }
+        else { hipLaunchKernelGGL((k_fast_pairs_lines<2, 8>), gp, dim3(kThreads), 0, ctx->stream, p); }
+      } else if (pair_w == 13) {
+        if (type == 0) { hipLaunchKernelGGL((k_fast_pairs_lines<0, 13>), gp, dim3(kThreads), 0, ctx->stream, p); }
+        else if (type == 1) { hipLaunchKernelGGL((k_fast_pairs_lines<1, 13>), gp, dim3(kThreads), 0, ctx->stream, p); }
+        else { hipLaunchKernelGGL((k_fast_pairs_lines<2, 13>), gp, dim3(kThreads), 0, ctx->stream, p); }
+      }
+      else if (type == 0) { hipLaunchKernelGGL(k_fast_pairs<0>, gp, dim3(kThreads), 0, ctx->stream, p); }
       else if (type == 1) { hipLaunchKernelGGL(k_fast_pairs<1>, gp, dim3(kThreads), 0, ctx->stream, p); }
       else { hipLaunchKernelGGL(k_fast_pairs<2>, gp, dim3(kThreads), 0, ctx->stream, p); }
       SWA_HIP(ctx, hipGetLastError());

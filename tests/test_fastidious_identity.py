@@ -165,3 +165,80 @@ def test_common_microvariants_come_from_the_difference_interval():
         assert got == want, (h, x, want, got, lo, hi)
         checked += 1
     assert checked > 10000
+
+
+def test_far_apart_edits_need_only_the_two_neighbourhoods():
+    """k_fast_count_sites, second form: with P <= E and the neighbourhoods of the two edits apart, only the canonical
+    positions [runstart(P - 1) - 1, P + 1] and [runstart(E - 1) - 1, E + 1] of h are expanded (a common microvariant undoes
+    one of the two edits); otherwise the whole interval as above.  Random, low-complexity and periodic sequences."""
+    rng = np.random.default_rng(17)
+
+    def edit(s, alpha):
+        p = int(rng.integers(0, len(s) + 1))
+        k = int(rng.integers(0, 3))
+        b = str(rng.choice(list(alpha)))
+        if k == 0 and p < len(s):
+            return s[:p] + b + s[p + 1:]
+        if k == 1 and p < len(s):
+            return s[:p] + s[p + 1:]
+        return s[:p] + b + s[p:]
+
+    def runstart(h, q):
+        q = max(q, 0)
+        while q > 0 and h[q - 1] == h[q]:
+            q -= 1
+        return q
+
+    def make(t):
+        L = int(rng.integers(20, 90))
+        m = t % 5
+        if m == 0:
+            return "".join(rng.choice(list("ACGT"), L))
+        if m == 1:
+            return "".join(rng.choice(list("AC"), L))
+        if m == 2:
+            return "".join(rng.choice(list("AAAAAAC"), L))
+        if m == 3:                                      # a repeat with a few point changes
+            unit = "".join(rng.choice(list("ACGT"), int(rng.integers(1, 5))))
+            s = list((unit * L)[:L])
+            for _ in range(int(rng.integers(0, 3))):
+                s[int(rng.integers(0, L))] = str(rng.choice(list("ACGT")))
+            return "".join(s)
+        a = "".join(rng.choice(list("ACGT"), L // 2))  # a repeat between two random flanks
+        unit = "".join(rng.choice(list("AC"), int(rng.integers(1, 4))))
+        return a[:L // 4] + (unit * L)[:L // 2] + a[L // 4:]
+
+    checked = split = 0
+    for t in range(9000):
+        h = make(t)
+        x = h
+        alpha = "ACGT" if t % 2 else "AC"
+        for _ in range(2):
+            x = edit(x, alpha)
+        if x == h:
+            continue
+        lh, lx = len(h), len(x)
+        dl = lx - lh
+        P = 0
+        while P < min(lh, lx) and h[P] == x[P]:
+            P += 1
+        E = -1
+        for i in range(lh - 1, -1, -1):
+            if i + dl < 0 or h[i] != x[i + dl]:
+                E = i
+                break
+        P, E = min(P, lh - 1), min(max(E, 0), lh - 1)
+        first, last = min(P, E), max(P, E)
+        lo, hi = max(runstart(h, first - 1) - 1, 0), min(last + 1, lh)
+        lo_b, hi_a = max(runstart(h, last - 1) - 1, 0), min(first + 1, lh)
+        two = P <= E and lo_b > hi_a
+        vx = v1(x)
+        want = len(v1(h) & vx)
+        if two:
+            got = sum(1 for p, v in _canonical_slots(h) if (lo <= p <= hi_a or lo_b <= p <= hi) and v in vx)
+            split += 1
+        else:
+            got = sum(1 for p, v in _canonical_slots(h) if lo <= p <= hi and v in vx)
+        assert got == want, (h, x, want, got, (lo, hi_a), (lo_b, hi))
+        checked += 1
+    assert checked > 8000 and split > 2000
