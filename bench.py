@@ -294,7 +294,7 @@ def config3_dn(args, n: int, length: int, d: int) -> dict:
     band = 2 * ((d * max(mm, go + ge)) // ge + 1) + 1
     res = {"workload": f"{hdb.n} synthetic amplicons x {length} bp, d={d}", "route": scan["route"],
            "clustering_seconds": round(dt, 3), "fasta_read_seconds": round(t_read, 3), "value": hdb.n / dt,
-           "unit": "amplicons/s (clustering phase: search on the GPU + download + host greedy walk)",
+           "unit": "amplicons/s (clustering phase: graph of pairs within d and the greedy walk on the GPU, swarm tables on the host)",
            "swarms": cl.summary()["swarms"], "kernel_launches": scan["launch_sequences"],
            "qgram_comparisons": scan["qgram_comparisons"], "aligned_pairs": scan["aligned_pairs"],
            "qgram_comparisons_per_s": scan["qgram_comparisons"] / dt, "aligned_pairs_per_s": scan["aligned_pairs"] / dt,

@@ -289,6 +289,12 @@ int swa_scan_totals(swa_ctx * ctx, uint64_t * out3);
 int swa_dn_graph_supported(swa_ctx * ctx);
 int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * offsets, uint32_t * neighbours, uint8_t * diffs,
                  uint64_t cap, uint64_t * total);
+/* The same graph left in HBM as the resident network: swa_d1_cluster_device then runs the greedy agglomeration of
+   src/algo.cc:384-602 on it where it lies (seeds by lowest id, members by generation then id: src/algo.cc:205-219 — the
+   same function of the directed graph as for d = 1), and swa_dn_parent_diffs returns, per amplicon, the differences to
+   its parent in that clustering (0 for seeds; n bytes): radius(v) = radius(parent) + that (src/algo.cc:560-574). */
+int swa_dn_graph_resident(swa_ctx * ctx, int no_cluster_breaking, uint64_t * total);
+int swa_dn_parent_diffs(swa_ctx * ctx, uint8_t * pdiff);
 /* out3 = {q-gram comparisons, aligned pairs, kernel launches} of the last swa_dn_graph */
 int swa_dn_graph_totals(swa_ctx * ctx, uint64_t * out3);
 

@@ -506,7 +506,7 @@ class Context:
 _DN_EXPORTS = ["swa_dn_cluster", "swa_dn_result_free", "swa_dn_result_error", "swa_dn_result_summary",
                "swa_dn_write_swarms", "swa_dn_write_stats", "swa_dn_write_structure", "swa_dn_write_seeds",
                "swa_dn_write_uclust", "swa_d1_write_uclust", "swa_scan_begin", "swa_scan_step", "swa_scan_batch", "swa_scan_fetch", "swa_scan_totals",
-               "swa_dn_graph_supported", "swa_dn_graph", "swa_dn_graph_totals",
+               "swa_dn_graph_supported", "swa_dn_graph", "swa_dn_graph_totals", "swa_dn_graph_resident", "swa_dn_parent_diffs",
                "swa_multi_create", "swa_multi_destroy", "swa_multi_size", "swa_multi_uses_rccl", "swa_multi_ctx", "swa_multi_last_error",
                "swa_multi_db_upload", "swa_multi_d1_network", "swa_multi_d1_fastidious", "swa_dn_set_ownership", "swa_multi_dn_begin",
                "swa_multi_dn_graph_supported", "swa_multi_dn_graph", "swa_multi_dn_graph_totals", "swa_dn_cluster_multi",

@@ -113,6 +113,7 @@ extern "C" int swa_d1_network_resident(swa_ctx * ctx, int no_cluster_breaking, u
     break;
   }
   ctx->csr_ready = true;
+  ctx->csr_has_diffs = false;
   ctx->csr_total = *total;
   return SWA_OK;
 }

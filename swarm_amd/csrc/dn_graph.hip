@@ -380,6 +380,25 @@ __global__ __launch_bounds__(256) void k_dg_split(const unsigned long long * __r
   }
 }
 
+// diff of the link parent[v] -> v (rows ascending: binary search), 0 for a seed
+__global__ __launch_bounds__(256) void k_dg_parent_diffs(const uint64_t * __restrict__ offsets, const uint32_t * __restrict__ nb,
+                                                         const uint8_t * __restrict__ df, const uint32_t * __restrict__ parent, uint32_t n,
+                                                         uint8_t * __restrict__ out) {
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const uint32_t p = parent[v];
+    uint8_t d = 0;
+    if (p != SWA_NO_AMPLICON) {
+      uint64_t lo = offsets[p], hi = offsets[p + 1];
+      while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (nb[mid] < v) { lo = mid + 1; } else { hi = mid; }
+      }
+      d = (lo < offsets[p + 1] && nb[lo] == v) ? df[lo] : (uint8_t)0xFF;
+    }
+    out[v] = d;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_dg_shortest(const uint32_t * __restrict__ seqlen, uint32_t n, uint32_t * out) {
   uint32_t mn = 0xFFFFFFFFu;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { mn = min(mn, seqlen[i]); }
@@ -599,6 +618,56 @@ extern "C" int swa_dn_graph(swa_ctx * ctx, int no_cluster_breaking, uint64_t * o
   const unsigned long long * sorted = ctx->dn_work != 0 ? static_cast<const unsigned long long *>(ctx->d_dn_keys.ptr) + ctx->dn_work : nullptr;
   const uint32_t * svals = ctx->dn_work != 0 ? static_cast<const uint32_t *>(ctx->d_dn_vals.ptr) + ctx->dn_work : nullptr;
   return swa_dn_graph_emit(ctx, sorted, svals, ctx->dn_edges, offsets, neighbours, diffs, cap, total);
+}
+
+// The graph left in HBM as the resident network (offsets | neighbours | diffs in the buffers swa_d1_network_resident uses):
+// swa_d1_cluster_device then evaluates the agglomeration of src/algo.cc:384-602 on it where it lies — the same pure
+// function of the directed graph as for d = 1 (seeds by lowest id, generations by distance, members by generation then
+// id: find_correct_position_in_list, src/algo.cc:205-219) — and swa_dn_parent_diffs adds what the radius needs.
+extern "C" int swa_dn_graph_resident(swa_ctx * ctx, int no_cluster_breaking, uint64_t * total) {
+  if (ctx == nullptr || total == nullptr) { return SWA_E_ARG; }
+  SWA_TRY(swa_dn_graph_compute(ctx, no_cluster_breaking));
+  const uint32_t n = ctx->db.n;
+  const uint64_t nedges = ctx->dn_edges;
+  const unsigned long long * sorted = ctx->dn_work != 0 ? static_cast<const unsigned long long *>(ctx->d_dn_keys.ptr) + ctx->dn_work : nullptr;
+  const uint32_t * svals = ctx->dn_work != 0 ? static_cast<const uint32_t *>(ctx->d_dn_vals.ptr) + ctx->dn_work : nullptr;
+  ctx->csr_ready = false;
+  SWA_TRY(swa_reserve(ctx, ctx->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_nb_tmp, (nedges + 1) * (sizeof(uint32_t) + 1)));
+  hipLaunchKernelGGL(k_dg_offsets, dim3(grid_for(ctx, (uint64_t)n + 1)), dim3(256), 0, ctx->stream, sorted, nedges, n,
+                     static_cast<uint64_t *>(ctx->d_offsets_tmp.ptr));
+  if (nedges != 0) {
+    auto * nb32 = static_cast<uint32_t *>(ctx->d_nb_tmp.ptr);
+    hipLaunchKernelGGL(k_dg_split, dim3(grid_for(ctx, nedges)), dim3(256), 0, ctx->stream, sorted, svals, nedges, nb32,
+                       reinterpret_cast<uint8_t *>(nb32 + nedges));
+  }
+  SWA_HIP(ctx, hipGetLastError());
+  ctx->csr_ready = true;
+  ctx->csr_total = nedges;
+  ctx->csr_has_diffs = true;
+  *total = nedges;
+  return SWA_OK;
+}
+
+// pdiff[v] = differences between v and its parent in the clustering swa_d1_cluster_device has just made of the graph
+// (0 for seeds); n bytes on the host.  radius(v) = radius(parent) + pdiff[v] (src/algo.cc:560-574).
+extern "C" int swa_dn_parent_diffs(swa_ctx * ctx, uint8_t * pdiff) {
+  if (ctx == nullptr || pdiff == nullptr) { return SWA_E_ARG; }
+  if (!ctx->csr_ready || !ctx->csr_has_diffs || ctx->d_cluster.ptr == nullptr) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_dn_parent_diffs: call swa_dn_graph_resident and swa_d1_cluster_device first");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  const auto * nb32 = static_cast<const uint32_t *>(ctx->d_nb_tmp.ptr);
+  const auto * parent = static_cast<const uint32_t *>(ctx->d_cluster.ptr) + 2ull * n;        // (layout of swa_d1_cluster_device: label | gen | parent)
+  SWA_TRY(swa_reserve(ctx, ctx->d_scan_diffs, (uint64_t)n + 16));
+  auto * out = static_cast<uint8_t *>(ctx->d_scan_diffs.ptr);
+  hipLaunchKernelGGL(k_dg_parent_diffs, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, static_cast<const uint64_t *>(ctx->d_offsets_tmp.ptr),
+                     nb32, reinterpret_cast<const uint8_t *>(nb32 + ctx->csr_total), parent, n, out);
+  SWA_HIP(ctx, hipGetLastError());
+  SWA_HIP(ctx, hipMemcpyAsync(pdiff, out, n, hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
 }
 
 // Multi-GPU by ownership of window groups (as swa_d1_set_ownership): with world > 1 this context makes only the groups

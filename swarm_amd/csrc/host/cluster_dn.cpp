@@ -103,6 +103,63 @@ static int cluster_over_graph(swa_ctx * ctx, swa_multi * multi, const swa_hostdb
   return SWA_OK;
 }
 
+// The same with the walk itself on the GPU: the graph stays in HBM (swa_dn_graph_resident), swa_d1_cluster_device labels
+// swarms, generations and parents on it (the greedy loop above is a pure function of the directed graph: a swarm = what
+// its seed reaches, a member's generation = its distance from the seed, its parent = the smallest id of the previous
+// generation that points at it — cluster_gpu.hip), and only five arrays of n entries come back instead of the graph.
+// Radii and the -i lines (acceptance order: sub-seeds in queue order, each one's hits by id) follow from the parents.
+static int cluster_on_device(swa_ctx * ctx, const swa_hostdb * db, int no_cluster_breaking, swa_dn_result * r) {
+  const uint32_t n = db->n;
+  uint64_t total = 0;
+  int rc = swa_dn_graph_resident(ctx, no_cluster_breaking, &total);
+  if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  std::vector<uint32_t> swarmid(n), generation(n), parent(n), order(n), begins((size_t)n + 1);
+  std::vector<uint8_t> pdiff(n);
+  uint32_t nswarms = 0;
+  rc = swa_d1_cluster_device(ctx, swarmid.data(), generation.data(), parent.data(), order.data(), begins.data(), n, &nswarms);
+  if (rc == SWA_OK) { rc = swa_dn_parent_diffs(ctx, pdiff.data()); }
+  if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  std::vector<uint32_t> radius(n, 0), pos_of(n, 0), fill;
+  r->order.resize(n);
+  r->swarms.resize(nswarms);
+  r->links.resize((size_t)n - nswarms);
+  uint32_t link_at = 0;
+  for (uint32_t s = 0; s < nswarms; ++s) {
+    swa_dn_result::Swarm & sw = r->swarms[s];
+    sw.begin = begins[s]; sw.end = begins[s + 1];
+    sw.link_begin = link_at;
+    const uint32_t size = sw.end - sw.begin;
+    for (uint32_t at = sw.begin; at < sw.end; ++at) {       // (generation, id) order: a parent comes before its children
+      const uint32_t v = order[at];
+      const uint32_t g = generation[v];
+      if (g != 0 && pdiff[v] == 0xFF) { r->error = "d >= 2 clustering on the GPU: a parent without a link to its child"; return SWA_E_DEVICE; }
+      const uint32_t rad = g == 0 ? 0u : radius[parent[v]] + pdiff[v];
+      radius[v] = rad;
+      pos_of[v] = at;
+      r->order[at] = {v, g, rad};
+      sw.mass += db->abundance[v];
+      if (db->abundance[v] == 1) { ++sw.singletons; }
+      sw.maxgen = std::max(sw.maxgen, g);
+      sw.maxradius = std::max(sw.maxradius, rad);
+    }
+    if (size > 1) {
+      // the links by the parent's place in the queue (counting sort, stable: a parent's children stay in id order)
+      fill.assign((size_t)size + 1, 0);
+      for (uint32_t at = sw.begin + 1; at < sw.end; ++at) { ++fill[pos_of[parent[order[at]]] - sw.begin + 1]; }
+      for (uint32_t k = 0; k < size; ++k) { fill[k + 1] += fill[k]; }
+      for (uint32_t at = sw.begin + 1; at < sw.end; ++at) {
+        const uint32_t v = order[at], p = parent[v];
+        r->links[link_at + fill[pos_of[p] - sw.begin]++] = {p, v, pdiff[v], s + 1, generation[v]};
+      }
+      link_at += size - 1;
+    }
+    sw.link_end = link_at;
+    r->largest = std::max<uint64_t>(r->largest, size);
+    r->maxgenerations = std::max<uint64_t>(r->maxgenerations, sw.maxgen);
+  }
+  return SWA_OK;
+}
+
 // d >= 2 on several GPUs (SWARM_AMD_DEVICES): the bulk graph shared out by ownership of window groups; a database the
 // graph route cannot serve (a sequence too short for d + 1 windows) is clustered by rank 0 alone with the fused scan.
 extern "C" int swa_dn_cluster_multi(swa_multi * multi, const swa_hostdb * db, int64_t differences, int no_cluster_breaking,
@@ -143,7 +200,12 @@ extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t diff
   const char * route = std::getenv("SWARM_AMD_DN");
   const bool want_scan = route != nullptr && std::strcmp(route, "scan") == 0;
   const bool want_graph = route != nullptr && std::strcmp(route, "graph") == 0;
-  if (!want_scan && swa_dn_graph_supported(ctx) != 0) { return cluster_over_graph(ctx, nullptr, db, no_cluster_breaking, r); }
+  if (!want_scan && swa_dn_graph_supported(ctx) != 0) {
+    // (SWARM_AMD_DN_WALK=host: the graph downloaded and walked on the host — comparison switch)
+    const char * walk = std::getenv("SWARM_AMD_DN_WALK");
+    if (walk != nullptr && std::strcmp(walk, "host") == 0) { return cluster_over_graph(ctx, nullptr, db, no_cluster_breaking, r); }
+    return cluster_on_device(ctx, db, no_cluster_breaking, r);
+  }
   if (want_graph) { r->error = "SWARM_AMD_DN=graph: a sequence is too short for d + 1 windows"; return SWA_E_ARG; }
 
   std::vector<uint8_t> swarmed(n, 0);
