@@ -1286,6 +1286,25 @@ __global__ void k_set_u64x2(uint64_t * p0, uint64_t a0, uint64_t b0, uint64_t * 
   if (p1 != nullptr) { p1[0] = a1; p1[1] = b1; }
 }
 
+// several small buffers zeroed by ONE launch (a step clears about ten; each hipMemsetAsync is a launch of 4-5 us)
+struct ClearList { uint32_t * p[8]; uint64_t words[8]; uint32_t n; };
+__global__ __launch_bounds__(256) void k_clear_many(const ClearList c) {
+  for (uint32_t k = 0; k < c.n; ++k) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c.words[k]; i += (uint64_t)gridDim.x * blockDim.x) { c.p[k][i] = 0u; }
+  }
+}
+static void clear_add(ClearList & c, void * p, uint64_t bytes) {          // (bytes: a multiple of 4)
+  c.p[c.n] = static_cast<uint32_t *>(p); c.words[c.n] = bytes / 4; ++c.n;
+}
+static int clear_launch(swa_ctx * ctx, const ClearList & c) {
+  uint64_t most = 0;
+  for (uint32_t k = 0; k < c.n; ++k) { most = std::max(most, c.words[k]); }
+  if (c.n == 0 || most == 0) { return SWA_OK; }
+  hipLaunchKernelGGL(k_clear_many, dim3(grid_for(ctx, most, 256, 8)), dim3(256), 0, ctx->stream, c);
+  SWA_HIP(ctx, hipGetLastError());
+  return SWA_OK;
+}
+
 // the amplicon lines of the uploaded database (once per upload; needs the abundance ranks)
 static int ensure_lines(swa_ctx * ctx) {
   const int w = lines_width_for(ctx);
@@ -1354,8 +1373,14 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSlot], (records + 1) * sizeof(uint16_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbOver], ((uint64_t)n + 8) & ~3ull));
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_stream[kSbOver].ptr, 0, ((uint64_t)n + 8) & ~3ull, ctx->stream));
+  {
+    ClearList c{};
+    clear_add(c, ctx->d_acounters.ptr, 64 * sizeof(uint32_t));
+    clear_add(c, ctx->d_stream[kSbOver].ptr, ((uint64_t)n + 8) & ~3ull);
+    // (the entry behind the last bucket's counts of each index: the scan of the counts reads one past the end)
+    for (int i = 0; i < 2; ++i) { clear_add(c, static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr) + (uint64_t)kListKinds * buckets, sizeof(uint32_t)); }
+    SWA_TRY(clear_launch(ctx, c));
+  }
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);                // (cleared by the caller: index build, or the retry)
   auto * scal = static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr);      // [0..3] level-0 chunk tables, [8 + i] totals (u32)
   const uint32_t win_a = ctx->anchor_a, win_b = ctx->anchor_b;
@@ -1421,7 +1446,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     x.kind_cnt = static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr);
     x.fp_sorted = i == 0 ? j.buf_f[0][j.last ^ 1] : nullptr;
     x.slot_sorted = static_cast<uint16_t *>(ctx->d_stream[kSbSlot].ptr);
-    SWA_HIP(ctx, hipMemsetAsync(x.kind_cnt + (uint64_t)kListKinds * x.buckets, 0, sizeof(uint32_t), ctx->stream));
   }
   g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
   if (const char * env_cap = getenv("SWA_D1_GROUP_CAP")) { g.group_cap = std::max<uint32_t>(g.pair_big, (uint32_t)atoi(env_cap)); }   // (experiments)
@@ -1568,12 +1592,13 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   // [32 + 8 pass + c] lists of k_scan_apply_lists
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
-  if (count_links) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream)); }
+  ClearList clears{};
+  clear_add(clears, ctx->d_stats.ptr, 16 * sizeof(uint64_t));
+  if (count_links) { clear_add(clears, ctx->d_counts.ptr, uint64_t(count) * sizeof(uint32_t)); }
   // item counts [0,1] big / [3,4] small, fallback count [2], work counters of both passes [16..32)
   const int pairs_width = ctx->pair_lists ? pairs_width_for(ctx) : 0;
   // (with pair lists, made at index build: [0], [1] and [32..48) are the index's)
-  SWA_HIP(ctx, hipMemsetAsync(acounters + (pairs_width != 0 ? 2 : 0), 0, (pairs_width != 0 ? 30 : 32) * sizeof(uint32_t), ctx->stream));
+  clear_add(clears, acounters + (pairs_width != 0 ? 2 : 0), (pairs_width != 0 ? 30 : 32) * sizeof(uint32_t));
   // work counters of k_d1_group_pairs (both passes): 2^shard_bits of them, sched_stride entries apart
   uint32_t pair_batch = 4, shard_bits = 6, sched_stride = 64;
   if (const char * e = getenv("SWA_D1_PAIR_BATCH")) { pair_batch = (uint32_t)std::max(1, atoi(e)); }                           // (experiments)
@@ -1582,8 +1607,9 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   if (pairs_width != 0) {
     const uint64_t bytes = (2ull << shard_bits) * sched_stride * sizeof(uint32_t);
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSched], bytes));
-    SWA_HIP(ctx, hipMemsetAsync(ctx->d_stream[kSbSched].ptr, 0, bytes, ctx->stream));
+    clear_add(clears, ctx->d_stream[kSbSched].ptr, bytes);
   }
+  SWA_TRY(clear_launch(ctx, clears));
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
   auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);

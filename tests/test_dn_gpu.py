@@ -1,7 +1,8 @@
-"""d >= 2 end to end on the GPU: FASTA -> HostDb -> the search (B3 + B4) -> host greedy loop -> writers,
+"""d >= 2 end to end on the GPU: FASTA -> HostDb -> the search (B3 + B4) -> greedy agglomeration -> writers,
 byte-compared with the reference's own output files.  Two routes for the search, both exercised:
 "graph" = every pair within d differences at once (dn_graph.hip; taken when every sequence has room for
-d + 1 windows), "scan" = one fused scan step per swarm generation (scan.hip)."""
+d + 1 windows; the greedy walk then runs on the GPU as well — or, "graph_host_walk", on the downloaded graph),
+"scan" = one fused scan step per swarm generation (scan.hip) driving the host's loop."""
 import filecmp
 
 import numpy as np
@@ -14,12 +15,15 @@ pytestmark = pytest.mark.gpu
 G = S.GOLDEN
 
 
-@pytest.fixture(params=["auto", "scan"])
+@pytest.fixture(params=["auto", "scan", "graph_host_walk"])
 def route(request, monkeypatch):
+    monkeypatch.delenv("SWARM_AMD_DN_WALK", raising=False)
     if request.param == "scan":
         monkeypatch.setenv("SWARM_AMD_DN", "scan")
     else:
         monkeypatch.delenv("SWARM_AMD_DN", raising=False)
+        if request.param == "graph_host_walk":
+            monkeypatch.setenv("SWARM_AMD_DN_WALK", "host")
     return request.param
 
 
