@@ -1164,7 +1164,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 // SWA_D1_BUILD=table: round 2's hash-table build (k_anchor_place / k_anchor_scatter / k_scatter_edges), kept for
 // comparison and for sequences beyond 416 nt (the enumerating kernels read its structures)
 enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
-       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27, kSbSched = 28 };
+       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27, kSbSched = 28, kSbSweep = 29 };
 
 static bool stream_enabled() {
   const char * e = getenv("SWA_D1_BUILD");
@@ -1224,6 +1224,35 @@ static void part_scratch(const PartJob & j, uint64_t * cnt, uint64_t * ctile, ui
   *cnt = c_max; *ctile = t_max; *starts_half = s_max; *partial = c_max / kFlatChunk + 2;
 }
 
+// several small buffers zeroed by ONE launch (a step clears about ten; each hipMemsetAsync is a launch of 4-5 us)
+struct ClearList { uint32_t * p[8]; uint64_t words[8]; uint32_t n; };
+__global__ __launch_bounds__(256) void k_clear_many(const ClearList c) {
+  for (uint32_t k = 0; k < c.n; ++k) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c.words[k]; i += (uint64_t)gridDim.x * blockDim.x) { c.p[k][i] = 0u; }
+  }
+}
+static void clear_add(ClearList & c, void * p, uint64_t bytes) {          // (bytes: a multiple of 4)
+  c.p[c.n] = static_cast<uint32_t *>(p); c.words[c.n] = bytes / 4; ++c.n;
+}
+static int clear_launch(swa_ctx * ctx, const ClearList & c) {
+  uint64_t most = 0;
+  for (uint32_t k = 0; k < c.n; ++k) { most = std::max(most, c.words[k]); }
+  if (c.n == 0 || most == 0) { return SWA_OK; }
+  hipLaunchKernelGGL(k_clear_many, dim3(grid_for(ctx, most, 256, 8)), dim3(256), 0, ctx->stream, c);
+  SWA_HIP(ctx, hipGetLastError());
+  return SWA_OK;
+}
+
+// SWA_D1_SWEEP=1: first levels in one pass (k_sweep_*).  Off by default — measured on the 10 M set: key partition 0.41 ms
+// against 0.44, link partition 0.50 against 0.39, and at 1 M both clearly slower (0.07 / 0.22 ms against 0.04 / 0.12): a
+// level is bound by the NUMBER of contiguous runs it writes (tiles x bins, ~26 G runs/s — the random-write rate of
+// tools/ubench_lines), which chaining the tiles does not change, and every tile pays the look-back's round trips.
+static bool sweep_enabled(const swa_ctx * ctx) {
+  if (ctx->sweep_off) { return false; }
+  const char * e = getenv("SWA_D1_SWEEP");
+  return e != nullptr && e[0] == '1';
+}
+
 static int run_partition(swa_ctx * ctx, PartJob & j) {
   uint64_t chunks = j.chunks0;
   bool single = j.single0;
@@ -1253,6 +1282,52 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     }
     const dim3 grid_t((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)cu_grid), j.nidx);
     hipLaunchKernelGGL(k_part_tiles, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a);
+    // a first level in one pass over the records (k_sweep_*: chained tiles, decoupled look-back) instead of histogram + scan + scatter
+    if (l == 0 && single && sweep_enabled(ctx) && j.max_records < (1ull << 30) && !(last_level && j.out32[0] != nullptr)) {
+      SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSweep], (2 * 1024 + 64) * sizeof(uint32_t)));
+      auto * sw = static_cast<uint32_t *>(ctx->d_stream[kSbSweep].ptr);
+      SweepArgs w{};
+      w.shift = a.shift; w.bits = a.bits; w.bias = a.bias;
+      w.err = static_cast<uint32_t *>(ctx->d_flags.ptr) + 12;
+      ClearList c{};
+      clear_add(c, sw, (2 * 1024 + 64) * sizeof(uint32_t));
+      for (uint32_t i = 0; i < j.nidx; ++i) {
+        w.p[i] = a.p[i];
+        w.ghist[i] = sw + 1024 * i; w.ticket[i] = sw + 2048 + i; w.status[i] = j.cnt[i];
+        clear_add(c, j.cnt[i], ((tiles << bits) + 1) * sizeof(uint32_t));
+      }
+      SWA_TRY(clear_launch(ctx, c));
+      const bool with_f = j.buf_f[0][0] != nullptr;
+      const bool wide = bits > kPartMaxBits;
+      int per_cu = 2;
+      const dim3 grid_h((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * 4), j.nidx);
+      if (with_f && wide && j.tile == 4096) {
+        hipLaunchKernelGGL((k_sweep_ghist<4096, 1024>), grid_h, dim3(256), 0, ctx->stream, w);
+        hipLaunchKernelGGL(k_sweep_bases<1024>, dim3(1, j.nidx), dim3(256), 0, ctx->stream, w);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_scatter<1, 4096, 1024>, 256, 0);
+        const dim3 grid_s((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * std::max(per_cu, 1) / j.nidx), j.nidx);
+        hipLaunchKernelGGL((k_sweep_scatter<1, 4096, 1024>), grid_s, dim3(256), 0, ctx->stream, w);
+      } else if (with_f && !wide && j.tile == 2048) {
+        hipLaunchKernelGGL((k_sweep_ghist<2048, 512>), grid_h, dim3(256), 0, ctx->stream, w);
+        hipLaunchKernelGGL(k_sweep_bases<512>, dim3(1, j.nidx), dim3(256), 0, ctx->stream, w);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_scatter<1, 2048, 512>, 256, 0);
+        const dim3 grid_s((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * std::max(per_cu, 1) / j.nidx), j.nidx);
+        hipLaunchKernelGGL((k_sweep_scatter<1, 2048, 512>), grid_s, dim3(256), 0, ctx->stream, w);
+      } else if (!with_f && !wide && j.tile == 4096) {
+        hipLaunchKernelGGL((k_sweep_ghist<4096, 512>), grid_h, dim3(256), 0, ctx->stream, w);
+        hipLaunchKernelGGL(k_sweep_bases<512>, dim3(1, j.nidx), dim3(256), 0, ctx->stream, w);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_scatter<0, 4096, 512>, 256, 0);
+        const dim3 grid_s((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * std::max(per_cu, 1) / j.nidx), j.nidx);
+        hipLaunchKernelGGL((k_sweep_scatter<0, 4096, 512>), grid_s, dim3(256), 0, ctx->stream, w);
+      } else {
+        return swa_fail_msg(ctx, SWA_E_ARG, "partition: no one-pass kernel for this tile / bin combination");
+      }
+      SWA_HIP(ctx, hipGetLastError());
+      ctx->sweep_used = true;
+      chunks = 1ull << bits;
+      single = false;
+      continue;
+    }
     const bool bins1024 = bits > kPartMaxBits;                 // (the key records of the one-level form: 10 bits)
     if (bins1024) { hipLaunchKernelGGL(k_part_hist<1024>, grid_t, dim3(256), 0, ctx->stream, a); }
     else { hipLaunchKernelGGL(k_part_hist<512>, grid_t, dim3(256), 0, ctx->stream, a); }
@@ -1284,25 +1359,6 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
 __global__ void k_set_u64x2(uint64_t * p0, uint64_t a0, uint64_t b0, uint64_t * p1, uint64_t a1, uint64_t b1) {
   p0[0] = a0; p0[1] = b0;
   if (p1 != nullptr) { p1[0] = a1; p1[1] = b1; }
-}
-
-// several small buffers zeroed by ONE launch (a step clears about ten; each hipMemsetAsync is a launch of 4-5 us)
-struct ClearList { uint32_t * p[8]; uint64_t words[8]; uint32_t n; };
-__global__ __launch_bounds__(256) void k_clear_many(const ClearList c) {
-  for (uint32_t k = 0; k < c.n; ++k) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c.words[k]; i += (uint64_t)gridDim.x * blockDim.x) { c.p[k][i] = 0u; }
-  }
-}
-static void clear_add(ClearList & c, void * p, uint64_t bytes) {          // (bytes: a multiple of 4)
-  c.p[c.n] = static_cast<uint32_t *>(p); c.words[c.n] = bytes / 4; ++c.n;
-}
-static int clear_launch(swa_ctx * ctx, const ClearList & c) {
-  uint64_t most = 0;
-  for (uint32_t k = 0; k < c.n; ++k) { most = std::max(most, c.words[k]); }
-  if (c.n == 0 || most == 0) { return SWA_OK; }
-  hipLaunchKernelGGL(k_clear_many, dim3(grid_for(ctx, most, 256, 8)), dim3(256), 0, ctx->stream, c);
-  SWA_HIP(ctx, hipGetLastError());
-  return SWA_OK;
 }
 
 // the amplicon lines of the uploaded database (once per upload; needs the abundance ranks)
@@ -1987,9 +2043,14 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   }
   // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence / pb = 0 [4] oversized group
   // [5] members of oversized groups [6] 0xFFFFFFFF - shortest sequence [7] groups for the enumerating kernels
-  uint32_t flags[9] = {};
+  uint32_t flags[13] = {};                                   // ([12]: a one-pass partition level gave up waiting)
   SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (flags[12] != 0) {
+    ctx->sweep_off = true;
+    SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
+    return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
+  }
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
   if (shortest != nullptr) { *shortest = 0xFFFFFFFFu - flags[6]; }
   if (flags[2] != 0 && ctx->stream_index) {                 // a bucket with more distinct keys than the group kernel's table: finer
@@ -2252,6 +2313,8 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
                                 ctx->stream));
     SWA_HIP(ctx, hipMemcpyAsync(&anchor_overflow, static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t sweep_gave_up = 0;
+    SWA_HIP(ctx, hipMemcpyAsync(&sweep_gave_up, static_cast<uint32_t *>(ctx->d_flags.ptr) + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t unserved = 0;                                   // fallback seeds listed while there is no table to serve them
     const bool check_unserved = ctx->anchor_usable && !stats && !ctx->full_index && !ctx->member_index;
     if (check_unserved) {
@@ -2296,6 +2359,12 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     swa_t1(ctx, 4);
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     n_edges = got[0];
+    if (sweep_gave_up != 0) {                                 // (a look-back that never ended: the three-step levels from now on)
+      ctx->sweep_off = true;
+      ctx->anchor_ready = false;
+      SWA_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(ctx->d_flags.ptr) + 12, 0, sizeof(uint32_t), ctx->stream));
+      continue;
+    }
     if (ctx->anchor_usable && !stats && anchor_overflow != 0) {
       // this rank owns more anchors than its share-sized key tables hold (skewed ownership):
       // size them for the whole range, which cannot overflow, and run again

@@ -21,6 +21,19 @@ def test_network_by_stage_equals_the_oracle(order):
     assert "lines: wrong words 0, wrong length 0, wrong rank 0" in r.stdout
 
 
+def test_one_pass_first_levels_equal_the_oracle():
+    """SWA_D1_SWEEP=1: the first partition levels by chained tiles (decoupled look-back, k_sweep_*) — an opt-in,
+    measured slower than the three-step levels (d1.hip: sweep_enabled); same network, same indexes."""
+    import os
+    env = dict(os.environ, SWA_D1_SWEEP="1")
+    r = subprocess.run([sys.executable, str(S.ROOT / "tools" / "check_stream.py"), "200000", "stream"], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "DIFFERENT" not in r.stdout
+    r = subprocess.run([sys.executable, str(S.ROOT / "tools" / "check_index.py"), "200000"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
 def test_indexes_in_hbm_are_consistent():
     r = subprocess.run([sys.executable, str(S.ROOT / "tools" / "check_index.py"), "200000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
