@@ -378,7 +378,7 @@ KERNEL_GROUPS = [          # (substring of the kernel name, group, FETCH_SIZE co
     ("k_keys", "keys", 2.0), ("k_lines_build", "lines", 2.0),
     ("k_part_", "partition", 2.0), ("k_flat_", "partition", 2.0), ("k_seg_starts", "partition", 2.0),      # (both partitions: the counters
     # cannot tell the key records' launches from the links')
-    ("k_group_lists", "groups", 2.0), ("k_group", "groups", 2.0),
+    ("k_group_lists", "groups", 2.0), ("k_group", "groups", 2.0), ("k_clear_many", "clears", 2.0),
     ("k_d1_group_pairs<0", "pairs0", 1.0), ("k_d1_group_pairs<1", "pairs1", 1.0), ("k_d1_pairs_tiled<0", "pairs0", 1.0),
     ("k_d1_pairs_tiled<1", "pairs1", 1.0), ("k_csr_bucket", "csr_rows", 2.0), ("k_seg_reduce", "csr_rows", 2.0),
     # round 2's kernels (SWA_D1_BUILD=table / SWA_D1_CSR=table)

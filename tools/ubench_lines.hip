@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void k_atom_add32(uint32_t * tab, uint64_t wor
   for (int k = 0; k < kPerThread; ++k) { atomicAdd(&tab[mix(t * kPerThread + k + ((uint64_t)salt << 40)) & words_mask], 1u); }
 }
 
-// VALU issue: eight independent chains of the two instructions the pair test is made of
+// VALU issue: eight independent chains of three instructions per step, all written out (nothing for the compiler to fold):
+//   KIND 0  v_xor + v_ffbl + v_min   (the pair test's own instructions)
+//   KIND 1  v_xor + v_and + v_add    (plain full-rate integer instructions: the issue rate itself)
+//   KIND 2  v_xor + v_ffbl + v_ffbh  (is the bit scan a full-rate instruction?)
+template <int KIND>
 __global__ __launch_bounds__(256) void k_valu(uint32_t * sink, uint32_t rounds, uint32_t seed) {
   uint32_t a[8];
 #pragma unroll
@@ -116,28 +120,18 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t * sink, uint32_t rounds, 
   for (uint32_t r = 0; r < rounds; ++r) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      uint32_t f;
-      asm volatile("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(a[i] ^ r));
-      asm volatile("v_min_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(f | 32u));
-    }
-  }
-  uint32_t acc = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { acc ^= a[i]; }
-  if (acc == 0x12345u) { sink[0] = acc; }
-}
-
-// the same with full-rate integer instructions only (v_xor, v_add, v_and): the issue rate itself
-__global__ __launch_bounds__(256) void k_valu_simple(uint32_t * sink, uint32_t rounds, uint32_t seed) {
-  uint32_t a[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { a[i] = seed * (threadIdx.x + 1u) + (uint32_t)i; }
-  for (uint32_t r = 0; r < rounds; ++r) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint32_t f;
-      asm volatile("v_and_b32 %0, %1, %2" : "=v"(f) : "v"(a[i] ^ r), "v"(0x7FFFFFFFu));
-      asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(f));
+      uint32_t x, f;
+      asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(a[i]), "v"(r));
+      if (KIND == 0) {
+        asm volatile("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x));
+        asm volatile("v_min_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(f));
+      } else if (KIND == 1) {
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(f) : "v"(x), "v"(0x7FFFFFFFu));
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(f));
+      } else {
+        asm volatile("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x));
+        asm volatile("v_ffbh_u32 %0, %1" : "=v"(a[i]) : "v"(f));
+      }
     }
   }
   uint32_t acc = 0;
@@ -241,11 +235,13 @@ int main(int argc, char ** argv) {
   {
     const uint32_t rounds = 4096;
     const int blocks = cus * 8;
-    const double ms = tm.best_ms([&](int r) { hipLaunchKernelGGL(k_valu, dim3(blocks), dim3(256), 0, nullptr, sink, rounds, (uint32_t)r + 1u); });
-    const double wave_insts = (double)blocks * 4.0 * rounds * 8.0 * 3.0;       // v_xor + v_ffbl + v_min per chain step
+    const double wave_insts = (double)blocks * 4.0 * rounds * 8.0 * 3.0;       // three instructions per chain step
+    const double ms = tm.best_ms([&](int r) { hipLaunchKernelGGL(k_valu<0>, dim3(blocks), dim3(256), 0, nullptr, sink, rounds, (uint32_t)r + 1u); });
     emit("valu_3op", 0, ms, wave_insts, "wave-instructions/s (v_xor + v_ffbl + v_min, eight independent chains)", 0, 0);
-    const double ms2 = tm.best_ms([&](int r) { hipLaunchKernelGGL(k_valu_simple, dim3(blocks), dim3(256), 0, nullptr, sink, rounds, (uint32_t)r + 1u); });
+    const double ms2 = tm.best_ms([&](int r) { hipLaunchKernelGGL(k_valu<1>, dim3(blocks), dim3(256), 0, nullptr, sink, rounds, (uint32_t)r + 1u); });
     emit("valu_simple", 0, ms2, wave_insts, "wave-instructions/s (v_xor + v_and + v_add, eight independent chains)", 0, 0);
+    const double ms3 = tm.best_ms([&](int r) { hipLaunchKernelGGL(k_valu<2>, dim3(blocks), dim3(256), 0, nullptr, sink, rounds, (uint32_t)r + 1u); });
+    emit("valu_bitscan", 0, ms3, wave_insts, "wave-instructions/s (v_xor + v_ffbl + v_ffbh, eight independent chains)", 0, 0);
   }
   json += "]}";
   if (argc > 1) {
