@@ -1267,9 +1267,9 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     // runs of 16 consecutive tiles per XCD (xcd_tile; measured at 10 M amplicons: key partition 0.44 -> 0.33 ms, link partition
     // 0.39 -> 0.36, the same for runs of 8 .. 64) — unless there are fewer tiles than workgroups in flight, where the runs
     // would leave XCDs without work
+    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / j.tile + chunks + 1);
     a.run_bits = tiles >= (uint64_t)cu_grid ? 4u : 0u;
     if (const char * e = getenv("SWA_D1_XCD_RUN_BITS")) { a.run_bits = (uint32_t)std::min(8, std::max(0, atoi(e))); }   // (experiment)
-    const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / j.tile + chunks + 1);
     for (uint32_t i = 0; i < j.nidx; ++i) {
       PartIdx & p = a.p[i];
       p.in = l == 0 ? j.in[i] : j.buf[i][(l - 1) & 1u];
