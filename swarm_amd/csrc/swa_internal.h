@@ -197,6 +197,11 @@ __device__ __forceinline__ uint64_t swa_shfl_u64(uint64_t v, int src) {
   const int hi = __shfl((int)(uint32_t)(v >> 32), src, 64);
   return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
+__device__ __forceinline__ uint64_t swa_shfl_xor_u64(uint64_t v, int mask) {
+  const int lo = __shfl_xor((int)(uint32_t)v, mask, 64);
+  const int hi = __shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
 __device__ __forceinline__ uint64_t swa_shfl_up_u64(uint64_t v, unsigned d) {
   const int lo = __shfl_up((int)(uint32_t)v, d, 64);
   const int hi = __shfl_up((int)(uint32_t)(v >> 32), d, 64);
