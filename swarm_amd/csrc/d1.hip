@@ -1659,7 +1659,8 @@ static int pair_blocks_per_cu(int width) {
 // anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
 // the plain kernel; edges / counts / edge counter as launch_network leaves them
 static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count, bool count_links) {
-  // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items [16..32) work counters
+  // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items [5, 6] / [7, 8] work counters of the
+  // 65..256 groups / of the tiled kernel, per pass [16..32) work counters of the enumerating kernels
   // [32 + 8 pass + c] lists of k_scan_apply_lists
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
@@ -1732,6 +1733,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.item_count = acounters + 3 + pass;
     a.sched = acounters + 16 + 8 * pass;
     a.sched_big = acounters + 5 + pass;
+    a.sched_tiled = acounters + 7 + pass;
     a.batch = pair_batch; a.shard_bits = shard_bits; a.sched_stride = sched_stride;
     a.sched_wide = static_cast<uint32_t *>(ctx->d_stream[kSbSched].ptr) + ((uint64_t)pass << shard_bits) * sched_stride;
     a.small_chunk = pass == 0 ? kSmallChunkPrefix : kSmallChunkSuffix;
