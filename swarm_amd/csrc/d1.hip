@@ -1206,6 +1206,7 @@ struct PartJob {
   uint64_t out_cap = 0;                             // entries every buf[][] holds
   uint32_t bias = 0, top_bit = 32;
   uint32_t tile = 4096;                             // records per tile (2048 for the records that carry fingerprints)
+  bool hist0_done = false;                          // the flat counts of level 0 are there already (k_keys<W, true>)
   PartPlan plan{};
   uint32_t * out32[kMaxIdx] = {};                   // != nullptr: the last level writes only the low halves, here
   // scratch, per set
@@ -1344,7 +1345,8 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
       continue;
     }
     const bool bins1024 = bits > kPartMaxBits;                 // (the key records of the one-level form: 10 bits)
-    if (bins1024) { hipLaunchKernelGGL(k_part_hist<1024>, grid_t, dim3(256), 0, ctx->stream, a); }
+    if (l == 0 && j.hist0_done) { /* (k_keys has left the counts) */ }
+    else if (bins1024) { hipLaunchKernelGGL(k_part_hist<1024>, grid_t, dim3(256), 0, ctx->stream, a); }
     else { hipLaunchKernelGGL(k_part_hist<512>, grid_t, dim3(256), 0, ctx->stream, a); }
     FlatScanArgs f{};
     f.unit_bits = bits;
@@ -1474,11 +1476,27 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(1), 0, ctx->stream, dflags,
                        (ctx->db_shortest < minlen || (window_mode == 0u && ctx->db_run32)) ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
   }
-  const dim3 kgrid((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u);
+  // the first partition level's histogram is taken on the way (one read pass over the records less: 0.07 ms at 10 M);
+  // not for routed id lists (their length is the device's to know), SWA_D1_KEYS_HIST=0: comparison switch
+  const char * env_kh = getenv("SWA_D1_KEYS_HIST");
+  const bool keys_hist = !routed && !(env_kh != nullptr && env_kh[0] == '0') && (sweep_enabled(ctx) ? false : true);
   swa_t0(ctx, 8);
-  if (w == 5) { hipLaunchKernelGGL(k_keys<5>, kgrid, dim3(256), 0, ctx->stream, k); }
-  else if (w == 13) { hipLaunchKernelGGL(k_keys<13>, kgrid, dim3(256), 0, ctx->stream, k); }
-  else { hipLaunchKernelGGL(k_keys<8>, kgrid, dim3(256), 0, ctx->stream, k); }
+  if (keys_hist) {
+    const uint32_t ntiles = (uint32_t)((records + j.tile - 1) / j.tile);
+    for (int i = 0; i < 2; ++i) { k.hist_cnt[i] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt + i].ptr); }
+    k.hist_bits = j.plan.bits[0]; k.hist_tile = j.tile; k.hist_ntiles = ntiles;
+    k.hist_run_bits = j.max_tiles0 >= (uint64_t)ctx->num_cus * 8 ? 4u : 0u;
+    const dim3 hgrid((unsigned)((std::min<uint64_t>(ntiles, (uint64_t)ctx->num_cus * 8) + 7) & ~7ull), 1u);
+    if (w == 5) { hipLaunchKernelGGL((k_keys<5, true>), hgrid, dim3(256), 0, ctx->stream, k); }
+    else if (w == 13) { hipLaunchKernelGGL((k_keys<13, true>), hgrid, dim3(256), 0, ctx->stream, k); }
+    else { hipLaunchKernelGGL((k_keys<8, true>), hgrid, dim3(256), 0, ctx->stream, k); }
+    j.hist0_done = true;
+  } else {
+    const dim3 kgrid((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u);
+    if (w == 5) { hipLaunchKernelGGL((k_keys<5, false>), kgrid, dim3(256), 0, ctx->stream, k); }
+    else if (w == 13) { hipLaunchKernelGGL((k_keys<13, false>), kgrid, dim3(256), 0, ctx->stream, k); }
+    else { hipLaunchKernelGGL((k_keys<8, false>), kgrid, dim3(256), 0, ctx->stream, k); }
+  }
   hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, ctx->stream, scal, (uint64_t)0, (uint64_t)(routed ? ctx->route_m[0] : n), scal + 2, (uint64_t)0,
                      (uint64_t)(routed ? ctx->route_m[1] : n));
   swa_t1(ctx, 8);
