@@ -203,7 +203,9 @@ def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, f
             "unit": "amplicons/s", "steps": steps, "ms_per_step": 1000.0 * elapsed / steps, "network_kernels_ms": k,
             "neighbour_links": int(total),
             "kernel_group_ms": {"keys": st[0], "partition_keys": st[1], "groups": st[2], "pairs0": st[3], "pairs1": st[4], "partition_links": st[5], "csr_rows": st[6],
-                                "plain_kernel_and_table": t8[0] + t8[1]},
+                                # (members of groups beyond the pair kernels' limit: their hash table + Bloom filter at index build,
+                                # and the enumerating plain kernel inside the network call — what is left of it beside the pair passes)
+                                "plain_kernel_and_table": t8[0] + t8[1], "plain_kernel_in_network": max(0.0, k - st[3] - st[4])},
             # (SURVEY 8(d) bytes — the reference's probing loop — over the step's wall time: an equivalent rate, see roofline)
             "reference_equivalent_GBs": abytes / (elapsed / steps) / 1e9}
 

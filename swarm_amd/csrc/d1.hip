@@ -1425,6 +1425,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   // (tiles of 2048 records for 512 bins; one level of 1024 bins: 4096, or the flat count array — bins x tiles — and the 16-byte runs
   // a tile leaves per bin cost more than the saved level: 0.56 -> 0.43 ms at 10 M amplicons)
   j.tile = (total_bits > kPartMaxBits && j.plan.levels == 1) ? 4096 : 2048;
+  if (const char * e = getenv("SWA_D1_KEY_TILE")) { if (atoi(e) == 2048 || (atoi(e) == 4096 && total_bits > kPartMaxBits && j.plan.levels == 1)) { j.tile = (uint32_t)atoi(e); } }   // (experiment)
   j.max_tiles0 = records / j.tile + 2;
   j.chunks0 = 1; j.single0 = true; j.top_bit = 32; j.bias = 0;
   uint64_t e_cnt, e_tile, e_start, e_partial;
