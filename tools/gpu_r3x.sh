@@ -1,7 +1,7 @@
 #!/bin/bash
 # final evidence run of round 3: the whole GPU suite, the full bench line, kernel traces of the 10 M and 1 M steps
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r3final
+O=$R/gpurun_out/r3final2
 mkdir -p $O
 cd $R
 ( time timeout 1500 python -m pytest tests -q -m gpu ) > $O/gpu_suite.log 2>&1; tail -3 $O/gpu_suite.log
