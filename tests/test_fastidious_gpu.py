@@ -114,6 +114,23 @@ def test_pair_route_equals_bloom_route(tmp_path, monkeypatch):
     assert (res[0][0] != 0xFFFFFFFF).sum() > 1000
 
 
+def test_pair_kernel_on_lines_equals_the_one_on_packed_words(tmp_path, monkeypatch):
+    """k_fast_pairs_lines (both sequences in registers, pairs of 64 groups dealt to the lanes: round 3) against round 2's
+    k_fast_pairs (SWA_FAST_PAIRS=words), on a set with low-complexity families: identical graft candidates and counters."""
+    from swarm_amd import Context
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 40000, 140, 77, 1, 0.3)
+    res = []
+    for route in ("lines", "words"):
+        monkeypatch.setenv("SWA_FAST_PAIRS", route)
+        ctx = Context(0)
+        hdb, cl, flags, stats, graft, counters = _pipeline(ctx, fa, 3, 16)
+        res.append((graft, [int(x) for x in counters[:5]]))
+        ctx.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert (res[0][0] != 0xFFFFFFFF).sum() > 1000
+
+
 @pytest.mark.parametrize("nshards", [2, 3])
 def test_fastidious_shards_combine_to_whole(gpu_ctx, tmp_path, nshards):
     """heavy amplicons split over GPUs; minimum of graft_cand, sum of the heavy
