@@ -134,3 +134,43 @@ def test_multi_dn_graph_equals_single(tmp_path, ncb):
     assert one.returncode == 0 and two.returncode == 0, one.stderr + two.stderr
     assert filecmp.cmp(tmp_path / "one.o", tmp_path / "two.o", shallow=False)
     assert filecmp.cmp(tmp_path / "one.i", tmp_path / "two.i", shallow=False)
+
+
+def _fasta_of(db, path):
+    """a database built in memory (tests/test_d1_gpu.py's hard sets) as a FASTA file for the production reader"""
+    out = []
+    for i in range(db.n):
+        w = db.words(i)
+        s = "".join("ACGT"[int((w[p >> 5] >> np.uint64((p & 31) * 2)) & np.uint64(3))] for p in range(int(db.seqlen[i])))
+        out.append(f">h{i}_{int(db.abundance[i])}\n{s}\n")
+    path.write_text("".join(out))
+
+
+@pytest.mark.parametrize("which", ["flanks", "giant_groups", "length_mix"])
+@pytest.mark.parametrize("build", ["routed", "streamed"])
+def test_multi_on_sets_that_leave_the_friendly_route(tmp_path, monkeypatch, which, build):
+    """Separate contexts per rank (MultiContext: per-context state cannot leak between ranks as it can when one context
+    plays them in turn) on the sets whose index build takes decisions: conserved flanks (the anchor windows move — the same
+    way on every rank, or the ranks would divide the pairs differently: ADVICE r02), groups beyond the pair kernels' limit,
+    sequences around the anchoring thresholds.  Three ranks on device 0 against one GPU, entry for entry."""
+    import test_d1_gpu as T
+    fa = tmp_path / "in.fa"
+    if which == "flanks":
+        T._conserved_flank_set(fa, 20000, 77)
+    else:
+        _fasta_of(T._giant_group_db() if which == "giant_groups" else T._length_mix_db(), fa)
+    hdb = HostDb(fa)
+    ctx = Context(0)
+    ctx.upload_hostdb(hdb)
+    assert ctx.d1_index_build() is False
+    off, nb = ctx.d1_network()
+    ctx.close()
+    assert len(nb) > 1000
+    monkeypatch.setenv("SWARM_AMD_MULTI_BUILD", build)
+    m = MultiContext([0, 0, 0])
+    m.upload_hostdb(hdb)
+    for ncb in (False, True, False):
+        moff, mnb = m.d1_network(ncb)
+        if not ncb:
+            assert np.array_equal(moff, off) and np.array_equal(mnb, nb)
+    m.close()
