@@ -429,7 +429,9 @@ def measured_pmc(args) -> dict | None:
                         group, corr = kernel_group(row["Kernel_Name"])
                         if group is None or group == "lines":          # (the lines are made once per upload, not per step)
                             continue
-                        g = groups.setdefault(group, {"fetch_bytes": 0.0, "write_bytes": 0.0, "valu_wave_instructions": 0.0})
+                        g = groups.setdefault(group, {"fetch_bytes": 0.0, "write_bytes": 0.0, "valu_wave_instructions": 0.0, "launches": 0.0})
+                        if counter == "SQ_INSTS_VALU":                  # (one row per dispatch in a single-counter pass)
+                            g["launches"] += 1.0 / (steps + warm)
                         v = float(row["Counter_Value"]) / (steps + warm)
                         if counter == "FETCH_SIZE":
                             g["fetch_bytes"] += v * 1024.0 * corr
@@ -442,7 +444,10 @@ def measured_pmc(args) -> dict | None:
                 return None
     for g in groups.values():
         g["hbm_bytes"] = g["fetch_bytes"] + g["write_bytes"]
+    step_groups = ("keys", "partition", "groups", "pairs0", "pairs1", "csr_rows", "clears")
     return {"per_kernel_group": groups, "hbm_bytes_per_step": sum(g["hbm_bytes"] for g in groups.values()),
+            # (launches per step — the library's own kernels; the runtime's fills and copies are not counted)
+            "kernel_launches_per_step": round(sum(g.get("launches", 0.0) for k, g in groups.items() if k in step_groups), 1),
             "how": f"nested rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) over bench.py --steps {steps} --warmup {warm}, per step; "
                    "FETCH_SIZE x 2 for the streaming kernels, x 1 for the pair kernels (random 64-byte lines), as calibrated by tools/ubench_lines"}
 
@@ -471,7 +476,9 @@ def step_byte_model(n: int, links: int, index_levels: int, link_levels: int) -> 
     n, e = float(n), float(links)
     return {
         "keys": 64 * n + 20 * n,                                   # lines in; two record arrays + fingerprints out
-        "partition_keys": index_levels * (16 * n + 2 * 20 * n),    # per level: histogram pass + scatter in / out (two record sets + fingerprints)
+        # per level: scatter in / out (two record sets + fingerprints) + a histogram pass over the records — which the first level
+        # does not have: k_keys takes its histogram on the way
+        "partition_keys": index_levels * (2 * 20 * n) + (index_levels - (0 if os.environ.get("SWA_D1_KEYS_HIST", "")[:1] == "0" else 1)) * 16 * n,
         "partition_links": link_levels * (8 * e + 2 * 8 * e),
         "groups": 20 * n + 8 * n,                                  # records + fingerprints in, members out (work items: a few %)
         "pairs0": 68 * n + 4 * e,                                  # id + line per member; half the links out
