@@ -307,3 +307,24 @@ def test_hostdb_errors_in_the_reference_order(tmp_path, text, d):
     with pytest.raises(SwaError) as e:
         HostDb(fa, check_duplicate_sequences=d > 1)
     assert want[0].strip() in str(e.value), (want[0], str(e.value))
+
+
+def test_xcd_tile_mapping_visits_every_tile_once():
+    """swarm_amd/csrc/d1_stream.inc: xcd_tile(v) — which tile the workgroup of turn v takes, so that runs of 2^run_bits
+    consecutive tiles stay on XCD v mod 8.  The partition kernels walk v over [0, tiles rounded up to 8 << run_bits) and
+    skip tiles beyond the end: that must reach every tile exactly once, and a run must stay on one XCD.  (The formula
+    restated; the kernels themselves are checked end to end by tests/test_stream_gpu.py.)"""
+    def xcd_tile(v, run_bits):
+        xcd, w = v & 7, v >> 3
+        return ((((w >> run_bits) << 3) + xcd) << run_bits) + (w & ((1 << run_bits) - 1))
+
+    for run_bits in range(0, 7):
+        span = 8 << run_bits
+        for ntiles in (1, 7, 8, 127, 128, 129, 2443, 8194):
+            vmax = (ntiles + span - 1) // span * span
+            seen = [xcd_tile(v, run_bits) for v in range(vmax)]
+            assert sorted(seen) == list(range(vmax))                     # a permutation of the padded range
+            assert {t for t in seen if t < ntiles} == set(range(ntiles))
+            for v in range(vmax):                                        # the tiles of one run share their XCD
+                t = seen[v]
+                assert (t >> run_bits) % 8 == v % 8
