@@ -242,3 +242,120 @@ def test_far_apart_edits_need_only_the_two_neighbourhoods():
         assert got == want, (h, x, want, got, (lo, hi_a), (lo_b, hi))
         checked += 1
     assert checked > 8000 and split > 2000
+
+
+# ---- the two-edit test of k_fast_pairs_lines, bit for bit (swarm_amd/csrc/d1_fast.inc: diagonal_mask, first_difference,
+# reg_lce, within_two_edits_reg), restated on Python integers as 64-bit words ----------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _pack(s: str, W: int):
+    w = [0] * W
+    for p, c in enumerate(s):
+        w[p >> 5] |= "ACGT".index(c) << ((p & 31) * 2)
+    return w
+
+
+def _diagonal_mask(A, B, k, W):
+    s = 2 * abs(k)
+    D = []
+    for w in range(W):
+        b = B[w]
+        if k > 0:
+            b = ((B[w] >> s) | ((B[w + 1] if w + 1 < W else 0) << (64 - s))) & _M64
+        elif k < 0:
+            b = ((B[w] << s) | ((B[w - 1] if w > 0 else 0) >> (64 - s))) & _M64
+        D.append(A[w] ^ b)
+    return D
+
+
+def _first_difference(D, frm, W):
+    pos = 32 * W
+    for w in range(W - 1, -1, -1):
+        rel = frm - 32 * w
+        mask = _M64 if rel <= 0 else (0 if rel >= 32 else (_M64 << (2 * rel)) & _M64)
+        t = D[w] & mask
+        if t:
+            pos = 32 * w + (((t & -t).bit_length() - 1) >> 1)
+    return pos
+
+
+def _reg_lce(D, i, k, m, n, W):
+    return min(_first_difference(D, i, W) - i, min(m - i, n - i - k))
+
+
+def _within_two_edits_reg(a: str, b: str, W: int) -> bool:
+    A, B, m, n = _pack(a, W), _pack(b, W), len(a), len(b)
+    dk = n - m
+    if dk > 2 or dk < -2:
+        return False
+    D0, Dp, Dm = _diagonal_mask(A, B, 0, W), _diagonal_mask(A, B, 1, W), _diagonal_mask(A, B, -1, W)
+    l0 = _reg_lce(D0, 0, 0, m, n, W)
+    if dk == 0 and l0 >= m:
+        return True
+    l1 = [-1] * 5
+    l1[2] = l0 + 1 + _reg_lce(D0, l0 + 1, 0, m, n, W) if (l0 + 1 <= m and l0 + 1 <= n) else -1
+    l1[3] = l0 + _reg_lce(Dp, l0, 1, m, n, W) if l0 + 1 <= n else -1
+    l1[1] = l0 + 1 + _reg_lce(Dm, l0 + 1, -1, m, n, W) if l0 + 1 <= m else -1
+    if -1 <= dk <= 1 and l1[dk + 2] >= m:
+        return True
+    same = {0: l1[2], 1: l1[3], -1: l1[1]}.get(dk, -1)
+    below = {1: l1[2], 0: l1[1], 2: l1[3]}.get(dk, -1)
+    above = {-1: l1[2], 0: l1[3], -2: l1[1]}.get(dk, -1)
+    best = -1
+    if same >= 0 and same + 1 <= m and same + 1 + dk <= n:
+        best = same + 1
+    if below >= 0 and below + dk <= n and below > best:
+        best = below
+    if above >= 0 and above + 1 <= m and above + 1 > best:
+        best = above + 1
+    if best < 0:
+        return False
+    D = {0: D0, 1: Dp, -1: Dm}.get(dk) or _diagonal_mask(A, B, dk, W)
+    return best + _reg_lce(D, best, dk, m, n, W) >= m
+
+
+def _edit_distance_at_most_2(a: str, b: str) -> bool:
+    if abs(len(a) - len(b)) > 2:
+        return False
+    prev = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        cur = [i] + [0] * len(b)
+        for j in range(1, len(b) + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (a[i - 1] != b[j - 1]))
+        prev = cur
+    return prev[-1] <= 2
+
+
+def test_two_edit_test_on_register_words_is_exact():
+    """Sequences zero padded to W words ('A' is 00: a tail of A's looks like padding), lengths across a word boundary,
+    0..4 random edits, low-complexity alphabets: the difference-mask form of Landau-Vishkin decides "edit distance <= 2"
+    exactly as the dynamic programme does."""
+    rng = np.random.default_rng(29)
+
+    def edit(s, alpha):
+        p = int(rng.integers(0, len(s) + 1))
+        k = int(rng.integers(0, 3))
+        c = str(rng.choice(list(alpha)))
+        if k == 0 and p < len(s):
+            return s[:p] + c + s[p + 1:]
+        if k == 1 and p < len(s) and len(s) > 1:
+            return s[:p] + s[p + 1:]
+        return s[:p] + c + s[p:]
+
+    yes = no = 0
+    for t in range(6000):
+        alpha = ["ACGT", "AC", "A", "AAAC"][t % 4]
+        L = int(rng.integers(1, 100))
+        a = "".join(rng.choice(list(alpha), L))
+        b = a
+        for _ in range(int(rng.integers(0, 5))):
+            b = edit(b, alpha)
+        if not b or len(b) > 150:
+            continue
+        want = _edit_distance_at_most_2(a, b)
+        assert _within_two_edits_reg(a, b, 5) == want, (a, b, want)
+        assert _within_two_edits_reg(b, a, 5) == want, (b, a, want)
+        yes += want
+        no += not want
+    assert yes > 1500 and no > 500
