@@ -1546,10 +1546,11 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
   swa_t0(ctx, 10);
   if (large_buckets) {
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {                                        // (112 KB of dynamic LDS: above the 64 KB a kernel gets unasked)
+    if (!ctx->g1_lds_opt_in) {
+      // (128 KB of dynamic LDS: above the 64 KB a kernel gets unasked.  The attribute belongs to the function ON A DEVICE:
+      // once per context, not once per process — swa_multi_* runs a context per GPU in one process)
       SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_group1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kG1LdsBytes));
-      lds_opt_in = true;
+      ctx->g1_lds_opt_in = true;
     }
     hipLaunchKernelGGL(k_group1, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus), 2), dim3(kG1Threads), kG1LdsBytes, ctx->stream, g);
   } else {
