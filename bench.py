@@ -708,13 +708,12 @@ def main() -> None:
             abytes = algorithmic_bytes(hdb.seqlen, 0) / (sim_world or world) + 4.0 * hits_seen[0]
         else:
             abytes = algorithmic_bytes(hdb.seqlen[first:first + count], hits_seen[0])
-        # levels of the two partitions (the library's arithmetic: buckets of <= 10 240 key records, up to 10 bits a level — or, with
-        # SWA_D1_GROUPS=small, <= 700 and 9; 2^8 sources per link bucket, 9 bits a level)
-        small_groups = os.environ.get("SWA_D1_GROUPS", "")[:1] == "s"
+        # levels of the two partitions (the library's arithmetic: buckets of <= 10 240 key records, up to 10 bits a level;
+        # 2^8 sources per link bucket, 9 bits a level)
         bits = 1
-        while (count >> bits) > (700 if small_groups else 10240):
+        while (count >> bits) > 10240:
             bits += 1
-        per_level = 9 if small_groups else 10
+        per_level = 10
         nbits = max(1, int(np.ceil(np.log2(max(2, q_count)))))
         model = step_byte_model(count, hits_seen[0], (bits + per_level - 1) // per_level, (max(1, nbits - min(8, nbits - 1)) + 8) // 9)
         kernels = {}

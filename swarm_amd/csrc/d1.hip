@@ -1173,7 +1173,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 // SWA_D1_BUILD=table: round 2's hash-table build (k_anchor_place / k_anchor_scatter / k_scatter_edges), kept for
 // comparison and for sequences beyond 416 nt (the enumerating kernels read its structures)
 enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
-       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27, kSbSched = 28, kSbSweep = 29 };
+       kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27, kSbSched = 28 };
 
 static bool stream_enabled() {
   const char * e = getenv("SWA_D1_BUILD");
@@ -1253,16 +1253,6 @@ static int clear_launch(swa_ctx * ctx, const ClearList & c) {
   return SWA_OK;
 }
 
-// SWA_D1_SWEEP=1: first levels in one pass (k_sweep_*).  Off by default — measured on the 10 M set: key partition 0.41 ms
-// against 0.44, link partition 0.50 against 0.39, and at 1 M both clearly slower (0.07 / 0.22 ms against 0.04 / 0.12): a
-// level is bound by the NUMBER of contiguous runs it writes (tiles x bins, ~26 G runs/s — the random-write rate of
-// tools/ubench_lines), which chaining the tiles does not change, and every tile pays the look-back's round trips.
-static bool sweep_enabled(const swa_ctx * ctx) {
-  if (ctx->sweep_off) { return false; }
-  const char * e = getenv("SWA_D1_SWEEP");
-  return e != nullptr && e[0] == '1';
-}
-
 static int run_partition(swa_ctx * ctx, PartJob & j) {
   uint64_t chunks = j.chunks0;
   bool single = j.single0;
@@ -1298,52 +1288,6 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     // (a multiple of 8 workgroups: turn v of the tile loops then stays on XCD v mod 8 — xcd_tile)
     const dim3 grid_t((unsigned)((std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)cu_grid) + 7) & ~7ull), j.nidx);
     hipLaunchKernelGGL(k_part_tiles, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a);
-    // a first level in one pass over the records (k_sweep_*: chained tiles, decoupled look-back) instead of histogram + scan + scatter
-    if (l == 0 && single && sweep_enabled(ctx) && j.max_records < (1ull << 30) && !(last_level && j.out32[0] != nullptr)) {
-      SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSweep], (2 * 1024 + 64) * sizeof(uint32_t)));
-      auto * sw = static_cast<uint32_t *>(ctx->d_stream[kSbSweep].ptr);
-      SweepArgs w{};
-      w.shift = a.shift; w.bits = a.bits; w.bias = a.bias;
-      w.err = static_cast<uint32_t *>(ctx->d_flags.ptr) + 12;
-      ClearList c{};
-      clear_add(c, sw, (2 * 1024 + 64) * sizeof(uint32_t));
-      for (uint32_t i = 0; i < j.nidx; ++i) {
-        w.p[i] = a.p[i];
-        w.ghist[i] = sw + 1024 * i; w.ticket[i] = sw + 2048 + i; w.status[i] = j.cnt[i];
-        clear_add(c, j.cnt[i], ((tiles << bits) + 1) * sizeof(uint32_t));
-      }
-      SWA_TRY(clear_launch(ctx, c));
-      const bool with_f = j.buf_f[0][0] != nullptr;
-      const bool wide = bits > kPartMaxBits;
-      int per_cu = 2;
-      const dim3 grid_h((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * 4), j.nidx);
-      if (with_f && wide && j.tile == 4096) {
-        hipLaunchKernelGGL((k_sweep_ghist<4096, 1024>), grid_h, dim3(256), 0, ctx->stream, w);
-        hipLaunchKernelGGL(k_sweep_bases<1024>, dim3(1, j.nidx), dim3(256), 0, ctx->stream, w);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_scatter<1, 4096, 1024>, 256, 0);
-        const dim3 grid_s((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * std::max(per_cu, 1) / j.nidx), j.nidx);
-        hipLaunchKernelGGL((k_sweep_scatter<1, 4096, 1024>), grid_s, dim3(256), 0, ctx->stream, w);
-      } else if (with_f && !wide && j.tile == 2048) {
-        hipLaunchKernelGGL((k_sweep_ghist<2048, 512>), grid_h, dim3(256), 0, ctx->stream, w);
-        hipLaunchKernelGGL(k_sweep_bases<512>, dim3(1, j.nidx), dim3(256), 0, ctx->stream, w);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_scatter<1, 2048, 512>, 256, 0);
-        const dim3 grid_s((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * std::max(per_cu, 1) / j.nidx), j.nidx);
-        hipLaunchKernelGGL((k_sweep_scatter<1, 2048, 512>), grid_s, dim3(256), 0, ctx->stream, w);
-      } else if (!with_f && !wide && j.tile == 4096) {
-        hipLaunchKernelGGL((k_sweep_ghist<4096, 512>), grid_h, dim3(256), 0, ctx->stream, w);
-        hipLaunchKernelGGL(k_sweep_bases<512>, dim3(1, j.nidx), dim3(256), 0, ctx->stream, w);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_scatter<0, 4096, 512>, 256, 0);
-        const dim3 grid_s((unsigned)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)ctx->num_cus * std::max(per_cu, 1) / j.nidx), j.nidx);
-        hipLaunchKernelGGL((k_sweep_scatter<0, 4096, 512>), grid_s, dim3(256), 0, ctx->stream, w);
-      } else {
-        return swa_fail_msg(ctx, SWA_E_ARG, "partition: no one-pass kernel for this tile / bin combination");
-      }
-      SWA_HIP(ctx, hipGetLastError());
-      ctx->sweep_used = true;
-      chunks = 1ull << bits;
-      single = false;
-      continue;
-    }
     const bool bins1024 = bits > kPartMaxBits;                 // (the key records of the one-level form: 10 bits)
     if (l == 0 && j.hist0_done) { /* (k_keys has left the counts) */ }
     else if (bins1024) { hipLaunchKernelGGL(k_part_hist<1024>, grid_t, dim3(256), 0, ctx->stream, a); }
@@ -1409,11 +1353,8 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   SWA_TRY(ensure_lines(ctx));
   const bool routed = ctx->route_ids[0] != nullptr;
   const uint64_t records = routed ? std::max<uint64_t>(std::max(ctx->route_m[0], ctx->route_m[1]), 1) : n;
-  // Large buckets (k_group1: ~10 000 records, ONE partition level of up to 10 bits at 10 M amplicons) or small ones (k_group:
-  // ~600 records, two levels); SWA_D1_GROUPS=small selects the latter (comparison switch).
-  const char * env_groups = getenv("SWA_D1_GROUPS");
-  const bool large_buckets = !(env_groups != nullptr && env_groups[0] == 's');
-  const uint32_t target = large_buckets ? kG1Target : kGroupTarget, level_bits = large_buckets ? 10u : kPartMaxBits;
+  // buckets of ~10 000 records for k_group1: ONE partition level of up to 10 bits at 10 M amplicons
+  const uint32_t target = kG1Target, level_bits = 10u;
   uint32_t total_bits = 1;
   while ((records >> total_bits) > target && total_bits < 3 * kPartMaxBits) { ++total_bits; }
   total_bits = std::min<uint32_t>(total_bits + ctx->stream_extra_bits, 3 * kPartMaxBits);
@@ -1444,7 +1385,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     SWA_TRY(swa_reserve(ctx, ctx->d_aitems[i], items_capacity(n) * sizeof(swa_item)));
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbScal], 64 * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSlot], (records + 1) * sizeof(uint16_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbOver], ((uint64_t)n + 8) & ~3ull));
   SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
   {
@@ -1480,7 +1420,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   // the first partition level's histogram is taken on the way (one read pass over the records less: 0.07 ms at 10 M);
   // not for routed id lists (their length is the device's to know), SWA_D1_KEYS_HIST=0: comparison switch
   const char * env_kh = getenv("SWA_D1_KEYS_HIST");
-  const bool keys_hist = !routed && !(env_kh != nullptr && env_kh[0] == '0') && (sweep_enabled(ctx) ? false : true);
+  const bool keys_hist = !routed && !(env_kh != nullptr && env_kh[0] == '0');
   swa_t0(ctx, 8);
   if (keys_hist) {
     const uint32_t ntiles = (uint32_t)((records + j.tile - 1) / j.tile);
@@ -1534,8 +1474,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     x.members = static_cast<uint32_t *>(ctx->d_stream[kSbMembers + i].ptr);
     x.items_tmp = j.buf[i][j.last ^ 1];
     x.kind_cnt = static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr);
-    x.fp_sorted = i == 0 ? j.buf_f[0][j.last ^ 1] : nullptr;
-    x.slot_sorted = static_cast<uint16_t *>(ctx->d_stream[kSbSlot].ptr);
   }
   g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
   if (const char * env_cap = getenv("SWA_D1_GROUP_CAP")) { g.group_cap = std::max<uint32_t>(g.pair_big, (uint32_t)atoi(env_cap)); }   // (experiments)
@@ -1545,7 +1483,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.lines = k.lines; g.line_quads = w == 5 ? 4u : 8u; g.line_w = (uint32_t)w;   // (64-byte lines for W = 5, 128-byte lines for W = 8, 13)
   g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
   swa_t0(ctx, 10);
-  if (large_buckets) {
+  {
     if (!ctx->g1_lds_opt_in) {
       // (128 KB of dynamic LDS: above the 64 KB a kernel gets unasked.  The attribute belongs to the function ON A DEVICE:
       // once per context, not once per process — swa_multi_* runs a context per GPU in one process)
@@ -1553,8 +1491,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
       ctx->g1_lds_opt_in = true;
     }
     hipLaunchKernelGGL(k_group1, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus), 2), dim3(kG1Threads), kG1LdsBytes, ctx->stream, g);
-  } else {
-    hipLaunchKernelGGL(k_group, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus * 12), 2), dim3(256), 0, ctx->stream, g);
   }
 
   // ---- work lists
@@ -1577,12 +1513,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   hipLaunchKernelGGL(k_flat_sums, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_flat_apply, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_group_lists, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, (uint64_t)ctx->num_cus * 8), 2), dim3(256), 0, ctx->stream, la);
-  if (!large_buckets) {
-    DupTiledArgs dt{};                                       // identical sequences inside the large prefix groups (chunk list)
-    dt.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr); dt.item_count = acounters + 0;
-    dt.members = g.g[0].members; dt.fp_sorted = g.g[0].fp_sorted; dt.g = g;
-    hipLaunchKernelGGL(k_dup_tiled, dim3((unsigned)ctx->num_cus * 4), dim3(256), 0, ctx->stream, dt);
-  }
   swa_t1(ctx, 10);
   SWA_HIP(ctx, hipGetLastError());
   ctx->pair_lists = true;
@@ -1696,6 +1626,8 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   if (const char * e = getenv("SWA_D1_PAIR_BATCH")) { pair_batch = (uint32_t)std::max(1, atoi(e)); }                           // (experiments)
   if (const char * e = getenv("SWA_D1_PAIR_SHARD_BITS")) { shard_bits = (uint32_t)std::min(10, std::max(0, atoi(e))); }
   if (const char * e = getenv("SWA_D1_SCHED_STRIDE")) { sched_stride = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
+  // (a workgroup serves the bundles of shard blockIdx.x mod 2^shard_bits: every shard needs a workgroup — ADVICE r03)
+  while (shard_bits > 0 && (1u << shard_bits) > (uint32_t)(ctx->num_cus * (pairs_width != 0 ? pair_blocks_per_cu(pairs_width) : 1))) { --shard_bits; }
   if (pairs_width != 0) {
     const uint64_t bytes = (2ull << shard_bits) * sched_stride * sizeof(uint32_t);
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSched], bytes));
@@ -2080,14 +2012,9 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   }
   // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence / pb = 0 [4] oversized group
   // [5] members of oversized groups [6] 0xFFFFFFFF - shortest sequence [7] groups for the enumerating kernels
-  uint32_t flags[13] = {};                                   // ([12]: a one-pass partition level gave up waiting)
+  uint32_t flags[8] = {};
   SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (flags[12] != 0) {
-    ctx->sweep_off = true;
-    SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
-    return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
-  }
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
   if (shortest != nullptr) { *shortest = 0xFFFFFFFFu - flags[6]; }
   if (flags[2] != 0 && ctx->stream_index) {                 // a bucket with more distinct keys than the group kernel's table: finer
@@ -2325,6 +2252,16 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
         SWA_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, 0, sizeof(uint32_t), ctx->stream));
         SWA_TRY(build_stream_index(ctx, 0, 0));
         swa_t1(ctx, 7);
+        // The index of another owner (swa_d1_set_ownership after the build): the member table and its Bloom filter hold the
+        // previous owner's oversized groups, so they are dropped, and whatever this owner's groups leave to the plain kernel
+        // ([3] seeds the anchored passes cannot serve, [4] oversized groups) gets the database-wide table
+        if (!ctx->full_index) {
+          uint32_t fl[6] = {};
+          SWA_HIP(ctx, hipMemcpyAsync(fl, ctx->d_flags.ptr, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
+          SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          ctx->member_index = false;
+          if (fl[3] != 0 || fl[4] != 0) { SWA_TRY(ensure_full_index(ctx)); }
+        }
       } else if (!stream && (!ctx->anchor_ready || ctx->anchor_first != first || ctx->anchor_count != count)) {
         swa_t0(ctx, 7);
         SWA_TRY(build_anchor_index(ctx, first, count));
@@ -2350,8 +2287,6 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
                                 ctx->stream));
     SWA_HIP(ctx, hipMemcpyAsync(&anchor_overflow, static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
-    uint32_t sweep_gave_up = 0;
-    SWA_HIP(ctx, hipMemcpyAsync(&sweep_gave_up, static_cast<uint32_t *>(ctx->d_flags.ptr) + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t unserved = 0;                                   // fallback seeds listed while there is no table to serve them
     const bool check_unserved = ctx->anchor_usable && !stats && !ctx->full_index && !ctx->member_index;
     if (check_unserved) {
@@ -2396,12 +2331,6 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     swa_t1(ctx, 4);
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     n_edges = got[0];
-    if (sweep_gave_up != 0) {                                 // (a look-back that never ended: the three-step levels from now on)
-      ctx->sweep_off = true;
-      ctx->anchor_ready = false;
-      SWA_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(ctx->d_flags.ptr) + 12, 0, sizeof(uint32_t), ctx->stream));
-      continue;
-    }
     if (ctx->anchor_usable && !stats && anchor_overflow != 0) {
       // this rank owns more anchors than its share-sized key tables hold (skewed ownership):
       // size them for the whole range, which cannot overflow, and run again
@@ -2504,6 +2433,7 @@ extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world
     ctx->csr_ready = false;
     ctx->anchor_ready = false;                               // the next network call indexes this rank's groups
     ctx->anchor_slack = 0;
+    ctx->member_index = false;                               // (the table of the previous owner's oversized groups is not this one's)
   }
   return SWA_OK;
 }

@@ -169,7 +169,14 @@ extern "C" int swa_dn_cluster_multi(swa_multi * multi, const swa_hostdb * db, in
   const bool want_scan = route != nullptr && std::strcmp(route, "scan") == 0;
   if (db->n != 0 && !want_scan) {
     int rc = swa_multi_dn_begin(multi, mismatch, gapopen, gapextend, (uint64_t)differences);
-    if (rc == SWA_OK && swa_multi_dn_graph_supported(multi) != 0) {
+    if (rc != SWA_OK) {                                       // (no silent single-rank run behind a failed start: ADVICE r03)
+      auto * r = new swa_dn_result();
+      *out = r;
+      r->differences = differences;
+      r->error = swa_multi_last_error(multi);
+      return rc;
+    }
+    if (swa_multi_dn_graph_supported(multi) != 0) {
       auto * r = new swa_dn_result();
       *out = r;
       r->differences = differences;
@@ -203,7 +210,9 @@ extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t diff
   if (!want_scan && swa_dn_graph_supported(ctx) != 0) {
     // (SWARM_AMD_DN_WALK=host: the graph downloaded and walked on the host — comparison switch)
     const char * walk = std::getenv("SWARM_AMD_DN_WALK");
-    if (walk != nullptr && std::strcmp(walk, "host") == 0) { return cluster_over_graph(ctx, nullptr, db, no_cluster_breaking, r); }
+    // (differences of 255 are what the device walk's parent-difference bytes use for "no link": d >= 255 walks on the host)
+    if ((walk != nullptr && std::strcmp(walk, "host") == 0) || differences >= 255) { return cluster_over_graph(ctx, nullptr, db, no_cluster_breaking, r); }
+    (void)swa_dn_set_ownership(ctx, 0, 1);                    // (a context that served one rank's share before: the whole graph)
     return cluster_on_device(ctx, db, no_cluster_breaking, r);
   }
   if (want_graph) { r->error = "SWARM_AMD_DN=graph: a sequence is too short for d + 1 windows"; return SWA_E_ARG; }

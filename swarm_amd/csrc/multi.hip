@@ -467,8 +467,14 @@ extern "C" int swa_multi_dn_graph(swa_multi * m, int no_cluster_breaking, uint64
   int rc = on_all(m, [&](int r) {
     swa_ctx * c = m->ctx[(size_t)r];
     SWA_TRY(swa_dn_set_ownership(c, (uint32_t)r, (uint32_t)world));
-    return swa_dn_graph_compute(c, no_cluster_breaking);
+    SWA_TRY(swa_dn_graph_compute(c, no_cluster_breaking));
+    // (the share's final sort is still queued on this rank's stream, and the streams of the contexts do not order against
+    // each other: the copies below run on rank 0's stream when the ranks share a device — ADVICE r03)
+    SWA_HIP(c, hipStreamSynchronize(c->stream));
+    return (int)SWA_OK;
   });
+  // the shares are computed: a later single-context call on any of these contexts sees the whole database again
+  for (swa_ctx * c : m->ctx) { (void)swa_dn_set_ownership(c, 0, 1); }
   if (rc != SWA_OK) { return rc; }
   swa_ctx * c0 = m->ctx[0];
   uint64_t all = 0;
