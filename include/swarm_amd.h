@@ -50,7 +50,8 @@ enum {
   SWA_E_ARG = 2,         /* invalid argument or call order */
   SWA_E_NOMEM = 3,       /* hipMalloc / host allocation failed */
   SWA_E_CAPACITY = 4,    /* caller's result buffer too small; *total tells the need */
-  SWA_E_DUPLICATES = 5   /* identical sequences present (reference: fatal, src/algod1.cc:1141-1150) */
+  SWA_E_DUPLICATES = 5,  /* identical sequences present (reference: fatal, src/algod1.cc:1141-1150) */
+  SWA_E_INTERNAL = 6     /* the d = 1 guard: index / network counts that must balance do not (never a short network instead) */
 };
 
 #define SWA_NO_AMPLICON 0xFFFFFFFFu   /* the reference's no_swarm (src/algod1.cc:80) */
@@ -121,6 +122,10 @@ int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int 
 /* Where the last index build put the two anchor windows that group the amplicons: out2 = {nt from the start, nt from
    the end}; (0, 0) = the first / last 32 nt, moved inwards when those are (nearly) the same for everybody. */
 int swa_d1_anchor_windows(const swa_ctx * ctx, uint32_t * out2);
+/* ... and how wide it made them, in nucleotides: 32, 64 or 128 — the widest that leaves the shortest sequence of the
+   database two windows and a nucleotide.  Two sequences of at least 2 w + 1 nt one edit apart share their first w or
+   their last w nucleotides for any w; the reference has no such notion (it enumerates: src/variants.cc:184-249). */
+uint32_t swa_d1_anchor_width(const swa_ctx * ctx);
 /* Multi-GPU by ownership (no reference counterpart: src/algod1.cc:641-669 splits the seeds over
    threads that share one table).  With world > 1 this context serves only its share of the
    probes: the anchor groups (amplicons sharing their first / last 32 nucleotides) whose key maps

@@ -21,7 +21,7 @@ PKG = Path(__file__).resolve().parent
 # SWARM_AMD_LIB=<path>: another build of the library (triage: tools/gpu_selfcheck.py; `make asan`)
 LIB_PATH = Path(os.environ.get("SWARM_AMD_LIB") or PKG / "lib" / "libswarm_amd.so")
 
-SWA_OK, SWA_E_DEVICE, SWA_E_ARG, SWA_E_NOMEM, SWA_E_CAPACITY, SWA_E_DUPLICATES = range(6)
+SWA_OK, SWA_E_DEVICE, SWA_E_ARG, SWA_E_NOMEM, SWA_E_CAPACITY, SWA_E_DUPLICATES, SWA_E_INTERNAL = range(7)
 NO_AMPLICON = 0xFFFFFFFF
 
 u64p = C.POINTER(C.c_uint64)
@@ -41,7 +41,7 @@ class DbView(C.Structure):
 
 
 EXPORTS = [
-    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_d1_anchor_windows",
+    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_d1_anchor_windows", "swa_d1_anchor_width",
     "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_resident",
     "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
@@ -411,6 +411,12 @@ class Context:
         self.lib.swa_d1_anchor_windows.argtypes = [C.c_void_p, C.c_void_p]
         self._check(self.lib.swa_d1_anchor_windows(self.h, _ptr(out)))
         return int(out[0]), int(out[1])
+
+    def d1_anchor_width(self) -> int:
+        """Width of the anchor windows the last index build chose, in nucleotides (32, 64 or 128)."""
+        self.lib.swa_d1_anchor_width.argtypes = [C.c_void_p]
+        self.lib.swa_d1_anchor_width.restype = C.c_uint32
+        return int(self.lib.swa_d1_anchor_width(self.h))
 
     def d1_network_resident(self, no_cluster_breaking: bool = False) -> int:
         """The network of the whole database computed into the context's own HBM buffers and kept there."""

@@ -102,7 +102,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_aoffsets[0], &ctx->d_aoffsets[1], &ctx->d_aslot[0],
                        &ctx->d_aslot[1], &ctx->d_aitems[0], &ctx->d_aitems[1], &ctx->d_ainfo[0], &ctx->d_ainfo[1], &ctx->d_apos[0], &ctx->d_apos[1], &ctx->d_afp[0], &ctx->d_afp[1],
                        &ctx->d_frole, &ctx->d_fkeys, &ctx->d_fcnt, &ctx->d_foff, &ctx->d_fslot, &ctx->d_fmembers, &ctx->d_fitems,
-                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster}) {
+                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster, &ctx->d_guard}) {
     swa_release(*b);
   }
   for (auto & b : ctx->d_stream) { swa_release(b); }
@@ -173,6 +173,9 @@ static void invalidate(swa_ctx * ctx) {
   ctx->member_index = false;
   ctx->stream_extra_bits = 0;
   ctx->anchor_a = ctx->anchor_b = 0;
+  ctx->anchor_w = ctx->windows_w = 32;
+  ctx->guard_index = false;
+  ctx->guard_keys_done = ctx->guard_keys_pending = false;
   ctx->qgram_ready = false;
   ctx->scan_ready = false;
   ctx->dn_graph_ready = false;

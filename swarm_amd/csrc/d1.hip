@@ -77,6 +77,7 @@ struct NetArgs {
   // range 1 = neighbours with the same prefix-side window (word win_word), range 2 = the others; all positions are
   // enumerated and the hits filtered
   uint32_t window_mode, win_word;
+  uint32_t anchor_w;            // width of the anchor windows in nt (32 / 64 / 128): the window is words [win_word, win_word + anchor_w / 32)
 };
 
 #define SWA_ANCHOR_TYPES_ONLY
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
                                                  const uint64_t * __restrict__ zobrist, uint32_t zlen,
                                                  uint32_t n, uint64_t * __restrict__ seqhash,
                                                  swa_aux * __restrict__ aux, const uint4 * __restrict__ list,
-                                                 const uint64_t * __restrict__ list_count) {
+                                                 const uint64_t * __restrict__ list_count, uint32_t anchor_w) {
   extern __shared__ uint64_t lds[];
   const uint64_t * zob = zobrist;
   if (ZLDS) {
@@ -109,24 +110,22 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
     uint64_t h = 0, dall = 0, iall = 0;
     uint64_t word = 0;
     swa_aux ax{};
-    // pb: first position of the run that contains position 31 (see swa_aux)
-    uint32_t pb = kAnchor;
-    if (len >= kAnchor) {
-      const uint64_t w0 = s[0];
-      const uint64_t differs = w0 ^ ((w0 >> 62) * 0x5555555555555555ull);          // 2-bit groups != the nucleotide at 31
-      pb = differs == 0ull ? 0u : (uint32_t)(64 - __builtin_clzll(differs) + 1) >> 1;   // one past the last differing position
-    }
-    ax.pb = pb;
+    // pb: first position of the run that contains position anchor_w - 1 (see swa_aux; 31 for the 32-nt windows of rounds
+    // 1-3), and the three streams below it: kept as of the start of the current run until that position is reached
+    uint32_t run_start = 0, prev = 4u;
+    uint64_t rh = 0, rd = 0, ri = 0;
+    ax.pb = anchor_w;
     for (uint32_t p = 0; p < len; ++p) {
       if ((p & 31u) == 0u) { word = s[p >> 5]; }
-      if (p == pb) { ax.a32 = h; ax.d32 = dall; ax.i32 = iall; }          // the three streams below position pb
       const uint32_t c = (uint32_t)(word & 3u);
+      if (c != prev) { run_start = p; rh = h; rd = dall; ri = iall; prev = c; }
+      if (p + 1u == anchor_w) { ax.pb = run_start; ax.a32 = rh; ax.d32 = rd; ax.i32 = ri; }
       h ^= zob[4u * p + c];
       if (p >= 1u) { dall ^= zob[4u * (p - 1u) + c]; }
       iall ^= zob[4u * (p + 1u) + c];
       word >>= 2;
     }
-    if (len <= kAnchor) { ax.a32 = h; ax.d32 = dall; ax.i32 = iall; }
+    if (len < anchor_w) { ax.a32 = h; ax.d32 = dall; ax.i32 = iall; }
     ax.h = h; ax.dall = dall; ax.iall = iall;
     seqhash[a] = h;
     aux[a] = ax;
@@ -297,7 +296,7 @@ template <bool SECOND>
 __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64_t * sw, uint32_t slen,
                                                  uint32_t snw, uint32_t seed, uint64_t seed_abundance,
                                                  uint64_t h, uint32_t code, uint32_t & out_amp,
-                                                 uint32_t & n_match, int window_filter = 0, uint32_t win_word = 0) {
+                                                 uint32_t & n_match, int window_filter = 0, uint32_t win_word = 0, uint32_t nwin = 1) {
   const uint32_t type = code & 3u;
   const uint32_t base = (code >> 2) & 3u;
   const uint32_t pos = code >> 4;
@@ -317,7 +316,9 @@ __device__ __forceinline__ bool probe_and_verify(const NetArgs & a, const uint64
       if (allowed && alen == vlen) {
         const uint64_t * y = a.seqs + a.seq_off[amp];
         // window_filter 1: only neighbours that share the seed's prefix-side window, 2: only those that do not
-        bool same = window_filter == 0 || (window_filter == 1 ? y[win_word] == sw[win_word] : y[win_word] != sw[win_word]);
+        bool shared = true;                                    // the seed's prefix-side window, in the neighbour
+        for (uint32_t w = 0; w < nwin; ++w) { shared = shared && y[win_word + w] == sw[win_word + w]; }
+        bool same = window_filter == 0 || (window_filter == 1 ? shared : !shared);
         for (uint32_t w = 0; w < vnw; ++w) {
           same = same && (swa_variant_word(sw, snw, type, pos, base, w) == y[w]);
         }
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
         // keeps only neighbours that share it, range 2 only those that do not.  (By position alone the halves overlap: a
         // deletion at position 31, or inside a run that ends there, is listed at a position >= pb AND changes the window.)
         const int wf = MODE != 2 ? 0 : (int)range;
-        hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch, wf, a.win_word);
+        hit = probe_and_verify<MODE == 1>(a, sw, len, nw, seed, seed_ab, qh[lane], qc[lane], amp, nmatch, wf, a.win_word, MODE == 2 ? a.anchor_w / 32u : 1u);
       }
       const uint64_t hm = __ballot(hit);
       if (STATS) {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void k_d1_probe(const NetArgs a) {
       const swa_aux ax = a.aux[seed];
       const bool by_position = a.window_mode == 0u;           // (window mode: every position, the hits are filtered)
       const uint32_t pb = by_position && range == 1u ? ax.pb : 0u;   // range 1 = what the prefix pass would have done (swa_aux::pb)
-      const uint32_t pe = by_position && range == 2u ? kAnchor : len + 1u;
+      const uint32_t pe = by_position && range == 2u ? a.anchor_w : len + 1u;
       const uint32_t erange = by_position ? range : 0u;       // (`range` itself still selects the filter in drain())
       enumerate_range(sw, len, zob, lane, pb, pe < len + 1u ? pe : len + 1u, ax.h, erange == 1u ? ax.a32 : 0ull,
                       erange == 1u ? (ax.dall ^ ax.d32) : ax.dall, erange == 1u ? (ax.iall ^ ax.i32) : ax.iall,
@@ -796,31 +797,37 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply_lists(const unsigned 
   }
 }
 
-// total and largest fill of the per-wave edge segments -> out[0], out[1]
+// total and largest fill of the per-wave edge segments -> out[0], out[1]; the members the pair kernels staged (the
+// guard; seg_fill + nseg, + 2 nseg: pass 0, pass 1) -> out[2], out[3]
 // (one workgroup of 1024 threads, eight loads in flight per thread: the 8192 fills of an MI355X in one round — with 256
 // threads and a load per turn this single workgroup took 11 us of every step)
 __global__ __launch_bounds__(1024) void k_seg_reduce(const uint32_t * __restrict__ seg_fill, uint32_t nseg,
                                                      unsigned long long * out) {
-  __shared__ unsigned long long ssum[16];
-  __shared__ unsigned long long smax[16];
-  unsigned long long sum = 0, mx = 0;
+  __shared__ unsigned long long ssum[16], smax[16], sst0[16], sst1[16];
+  unsigned long long sum = 0, mx = 0, st0 = 0, st1 = 0;
   for (uint32_t base = 0; base < nseg; base += 8192u) {
-    uint32_t v[8];
+    uint32_t v[8], s0[8], s1[8];
 #pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) { const uint32_t i = base + k * 1024u + threadIdx.x; v[k] = i < nseg ? seg_fill[i] : 0u; }
+    for (uint32_t k = 0; k < 8u; ++k) {
+      const uint32_t i = base + k * 1024u + threadIdx.x;
+      v[k] = i < nseg ? seg_fill[i] : 0u;
+      s0[k] = i < nseg ? seg_fill[(uint64_t)nseg + i] : 0u;
+      s1[k] = i < nseg ? seg_fill[2ull * nseg + i] : 0u;
+    }
 #pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) { sum += v[k]; mx = mx > v[k] ? mx : v[k]; }
+    for (uint32_t k = 0; k < 8u; ++k) { sum += v[k]; mx = mx > v[k] ? mx : v[k]; st0 += s0[k]; st1 += s1[k]; }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long s2 = swa_shfl_xor_u64(sum, o), m2 = swa_shfl_xor_u64(mx, o);
     sum += s2; mx = mx > m2 ? mx : m2;
+    st0 += swa_shfl_xor_u64(st0, o); st1 += swa_shfl_xor_u64(st1, o);
   }
-  if ((threadIdx.x & 63u) == 0u) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; }
+  if ((threadIdx.x & 63u) == 0u) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; sst0[threadIdx.x >> 6] = st0; sst1[threadIdx.x >> 6] = st1; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long s = 0, m = 0;
-    for (int w = 0; w < 16; ++w) { s += ssum[w]; m = m > smax[w] ? m : smax[w]; }
-    out[0] = s; out[1] = m;
+    unsigned long long s = 0, m = 0, a0 = 0, a1 = 0;
+    for (int w = 0; w < 16; ++w) { s += ssum[w]; m = m > smax[w] ? m : smax[w]; a0 += sst0[w]; a1 += sst1[w]; }
+    out[0] = s; out[1] = m; out[2] = a0; out[3] = a1;
   }
 }
 
@@ -973,6 +980,9 @@ static bool owned_index_enabled() {
   return !(e != nullptr && e[0] == '1');
 }
 
+// shortest seed the anchored passes serve: two windows and a nucleotide (65 with the 32-nt windows of rounds 1-3)
+static uint32_t anchor_minlen(const swa_ctx * ctx) { return ctx->anchor_a + ctx->anchor_b + 2u * ctx->anchor_w + 1u; }
+
 // whether the anchored passes may be used at all for this database (decided at index build)
 static bool anchor_applicable(const swa_ctx * ctx) {
   // (the anchored kernel prefetches a seed's words into kPrefetchWords registers per lane)
@@ -994,6 +1004,12 @@ static uint64_t items_capacity(uint32_t n) { return std::max<uint64_t>(uint64_t(
 constexpr uint32_t kSmallChunkPrefix = 16;  // prefix pass: seeds per small item (a seed walks its whole sequence)
 constexpr uint32_t kSmallChunkSuffix = 64;  // suffix pass: 32 positions per seed, the table build dominates: no split
 
+static bool stream_enabled() {
+  const char * e = getenv("SWA_D1_BUILD");
+  return !(e != nullptr && e[0] == 't');
+}
+static int lines_width_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0)); }
+
 // small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_group_pairs), else by
 // enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
 static int pairs_width_for(const swa_ctx * ctx) {
@@ -1002,6 +1018,18 @@ static int pairs_width_for(const swa_ctx * ctx) {
   if (env_enum != nullptr && env_enum[0] == '1' && !window_mode) { return 0; }
   return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0));
 }
+// the streaming build + pair kernels serve this database (else: round 2's table build, sequences beyond 416 nt)
+static bool stream_route(const swa_ctx * ctx) { return stream_enabled() && pairs_width_for(ctx) != 0 && lines_width_for(ctx) != 0; }
+// widest anchor windows the kernels in place take, in words of 32 nt (anchor_nwin_for): 4 with the streaming build (128-nt
+// windows need 257-nt sequences: the 13-word kernels), 1 with the table build, whose enumerating kernels divide a seed at
+// position 32.  SWA_D1_ANCHOR_W=32 / 64 / 128 caps it (comparison switch).
+static uint32_t anchor_max_nwin(const swa_ctx * ctx) {
+  if (!stream_route(ctx)) { return 1u; }
+  uint32_t cap = 4u;
+  if (const char * e = getenv("SWA_D1_ANCHOR_W")) { cap = std::min(4u, std::max(1u, (uint32_t)atoi(e) / 32u)); }
+  return cap;
+}
+
 // groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
 // them to the enumerating / tiled kernel (test switch)
 static uint32_t pair_big_limit() {
@@ -1096,7 +1124,7 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
   b.fingerprint = static_cast<uint64_t *>(ctx->d_afp[0].ptr);
   b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.flags = dflags;
   b.win_a = ctx->anchor_a; b.win_b = ctx->anchor_b;
-  b.minlen = ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen;
+  b.minlen = anchor_minlen(ctx);
   b.window_mode = (ctx->anchor_a != 0 || ctx->anchor_b != 0) ? 1u : 0u;
   for (int which = 0; which < 2; ++which) {
     b.slots[which] = static_cast<unsigned long long *>(ctx->d_acounts[which].ptr);
@@ -1174,12 +1202,6 @@ static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
 // comparison and for sequences beyond 416 nt (the enumerating kernels read its structures)
 enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
        kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27, kSbSched = 28 };
-
-static bool stream_enabled() {
-  const char * e = getenv("SWA_D1_BUILD");
-  return !(e != nullptr && e[0] == 't');
-}
-static int lines_width_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0)); }
 
 struct PartPlan { uint32_t levels; uint32_t bits[4]; uint32_t total; };
 static PartPlan plan_levels(uint32_t total_bits, uint32_t max_bits = kPartMaxBits) {
@@ -1390,6 +1412,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   {
     ClearList c{};
     clear_add(c, ctx->d_acounters.ptr, 64 * sizeof(uint32_t));
+    clear_add(c, ctx->d_guard.ptr, 8 * sizeof(uint64_t));      // the guard's index counters: this build's
     clear_add(c, ctx->d_stream[kSbOver].ptr, ((uint64_t)n + 8) & ~3ull);
     // (the entry behind the last bucket's counts of each index: the scan of the counts reads one past the end)
     for (int i = 0; i < 2; ++i) { clear_add(c, static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr) + (uint64_t)kListKinds * buckets, sizeof(uint32_t)); }
@@ -1398,7 +1421,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);                // (cleared by the caller: index build, or the retry)
   auto * scal = static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr);      // [0..3] level-0 chunk tables, [8 + i] totals (u32)
   const uint32_t win_a = ctx->anchor_a, win_b = ctx->anchor_b;
-  const uint32_t minlen = win_a + win_b + kMinAnchoredLen, window_mode = (win_a != 0 || win_b != 0) ? 1u : 0u;
+  const uint32_t minlen = anchor_minlen(ctx), window_mode = (win_a != 0 || win_b != 0) ? 1u : 0u;
 
   // ---- keys: records into the PONG halves (level 0 reads them from there), fingerprints likewise
   KeyArgs k{};
@@ -1412,10 +1435,13 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   k.fp = static_cast<uint32_t *>(ctx->d_stream[kSbFp + 1].ptr);
   k.owner_rank = ctx->owner_rank; k.owner_world = ctx->owner_world;
   k.win_a = win_a; k.win_b = win_b; k.minlen = minlen; k.window_mode = window_mode;
+  k.nwin = ctx->anchor_w / 32u;
   k.flags = dflags;
+  k.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
+  if (const char * e = getenv("SWA_D1_GUARD_TEST")) { k.fault = e[0] == 'm' ? 1u : (e[0] == 'd' ? 2u : 0u); }   // (test hook: a wrong index, on purpose)
   if (routed) {
     hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(1), 0, ctx->stream, dflags,
-                       (ctx->db_shortest < minlen || (window_mode == 0u && ctx->db_run32)) ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
+                       ctx->db_shortest < minlen ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
   }
   // the first partition level's histogram is taken on the way (one read pass over the records less: 0.07 ms at 10 M);
   // not for routed id lists (their length is the device's to know), SWA_D1_KEYS_HIST=0: comparison switch
@@ -1462,6 +1488,24 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   swa_t0(ctx, 9);
   SWA_TRY(run_partition(ctx, j));
   swa_t1(ctx, 9);
+  if (!ctx->guard_keys_done) {
+    // the guard's second opinion on the key records, once per uploaded database: from the packed database against what the
+    // partition holds (k_guard_db / k_guard_records); compared at the next guard_check
+    auto * gsum = static_cast<unsigned long long *>(ctx->d_guard.ptr) + 16;
+    SWA_HIP(ctx, hipMemsetAsync(gsum, 0, 8 * sizeof(uint64_t), ctx->stream));
+    GuardDbArgs gd{};
+    gd.seqs = ctx->db.seqs; gd.seq_off = ctx->db.seq_off; gd.seqlen = ctx->db.seqlen; gd.n = n;
+    for (int i = 0; i < 2; ++i) { gd.list[i] = k.list[i]; gd.list_count[i] = k.list_count[i]; }
+    gd.owner_rank = k.owner_rank; gd.owner_world = k.owner_world; gd.win_a = win_a; gd.win_b = win_b; gd.nwin = k.nwin;
+    gd.out = gsum;
+    hipLaunchKernelGGL(k_guard_db, dim3((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u), dim3(256), 0, ctx->stream, gd);
+    GuardRecArgs gr{};
+    for (int i = 0; i < 2; ++i) { gr.rec[i] = j.out[i]; gr.total[i] = j.total[i]; }
+    gr.fp = j.out_f[0];
+    gr.out = gsum + 3;
+    hipLaunchKernelGGL(k_guard_records, dim3((unsigned)grid_for(ctx, records, 256, 8), 2u), dim3(256), 0, ctx->stream, gr);
+    ctx->guard_keys_pending = true;
+  }
 
   // ---- groups
   GroupArgs g{};
@@ -1478,6 +1522,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
   if (const char * env_cap = getenv("SWA_D1_GROUP_CAP")) { g.group_cap = std::max<uint32_t>(g.pair_big, (uint32_t)atoi(env_cap)); }   // (experiments)
   g.flags = dflags;
+  g.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
   g.over = static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr);
   g.dup_first = dup_first; g.dup_count = dup_count;
   g.lines = k.lines; g.line_quads = w == 5 ? 4u : 8u; g.line_w = (uint32_t)w;   // (64-byte lines for W = 5, 128-byte lines for W = 8, 13)
@@ -1521,6 +1566,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   ctx->anchor_slots = 0;
   ctx->anchor_ready = true;
   ctx->stream_index = true;
+  ctx->guard_index = true;
   return SWA_OK;
 }
 
@@ -1592,19 +1638,40 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
   return SWA_OK;
 }
 
+// the pair kernels by (pass, record width W in words, window width NW in words): W = 5 / 8 / 13, NW = 1 / 2 (and 4 with
+// W = 13: 128-nt windows need sequences of 257 nt)
+#define SWA_PAIR_CASE(KERNEL, P, WW, NN) \
+  if (pass == P && width == WW && nwin == NN) { hipLaunchKernelGGL((KERNEL<P, WW, NN>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); return SWA_OK; }
+#define SWA_PAIR_CASES(KERNEL) \
+  SWA_PAIR_CASE(KERNEL, 0, 5, 1) SWA_PAIR_CASE(KERNEL, 1, 5, 1) SWA_PAIR_CASE(KERNEL, 0, 5, 2) SWA_PAIR_CASE(KERNEL, 1, 5, 2) \
+  SWA_PAIR_CASE(KERNEL, 0, 8, 1) SWA_PAIR_CASE(KERNEL, 1, 8, 1) SWA_PAIR_CASE(KERNEL, 0, 8, 2) SWA_PAIR_CASE(KERNEL, 1, 8, 2) \
+  SWA_PAIR_CASE(KERNEL, 0, 13, 1) SWA_PAIR_CASE(KERNEL, 1, 13, 1) SWA_PAIR_CASE(KERNEL, 0, 13, 2) SWA_PAIR_CASE(KERNEL, 1, 13, 2) \
+  SWA_PAIR_CASE(KERNEL, 0, 13, 4) SWA_PAIR_CASE(KERNEL, 1, 13, 4)
+static int launch_group_pairs(swa_ctx * ctx, int pass, int width, int nwin, int grid, const AnchorArgs & a) {
+  SWA_PAIR_CASES(k_d1_group_pairs)
+  return swa_fail_msg(ctx, SWA_E_ARG, "pair kernels: no kernel for this record / window width");
+}
+static int launch_pairs_tiled(swa_ctx * ctx, int pass, int width, int nwin, int grid, const AnchorArgs & a) {
+  SWA_PAIR_CASES(k_d1_pairs_tiled)
+  return swa_fail_msg(ctx, SWA_E_ARG, "pair kernels: no kernel for this record / window width");
+}
+
 // workgroups of k_d1_group_pairs<*, W> that one CU holds at a time (registers and LDS: the occupancy API; 1..8)
 static int pair_blocks_per_cu(int width) {
   static int cached[3] = {0, 0, 0};
   int & c = cached[width == 5 ? 0 : (width == 8 ? 1 : 2)];
   if (c == 0) {
     int nb = 0;
-    const hipError_t e = width == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 5>, kThreads, 0)
-                       : width == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 8>, kThreads, 0)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 13>, kThreads, 0);
+    const hipError_t e = width == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 5, 1>, kThreads, 0)
+                       : width == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 8, 1>, kThreads, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 13, 1>, kThreads, 0);
     c = (e == hipSuccess && nb >= 1) ? std::min(nb, 8) : 4;
   }
   return c;
 }
+
+// per-wave link segments: one per wave of the largest launch (d_seg_fill: [fills | members staged, pass 0 | pass 1])
+static uint32_t seg_count(const swa_ctx * ctx) { return (uint32_t)ctx->num_cus * 8u * kWaves; }
 
 // anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
 // the plain kernel; edges / counts / edge counter as launch_network leaves them
@@ -1616,6 +1683,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
   ClearList clears{};
   clear_add(clears, ctx->d_stats.ptr, 16 * sizeof(uint64_t));
+  clear_add(clears, static_cast<uint64_t *>(ctx->d_guard.ptr) + 8, 8 * sizeof(uint64_t));   // the guard's counters of this network call
   if (count_links) { clear_add(clears, ctx->d_counts.ptr, uint64_t(count) * sizeof(uint32_t)); }
   // item counts [0,1] big / [3,4] small, fallback count [2], work counters of both passes [16..32)
   const int pairs_width = ctx->pair_lists ? pairs_width_for(ctx) : 0;
@@ -1675,9 +1743,13 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.seg_cap = ctx->seg_cap;
     a.seg_fill = static_cast<uint32_t *>(ctx->d_seg_fill.ptr);
     a.counts = count_links ? static_cast<uint32_t *>(ctx->d_counts.ptr) : nullptr;
-    a.minlen = ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen;
+    a.minlen = anchor_minlen(ctx);
     a.win_word = ctx->anchor_a / 32u;
+    a.win_word_b = ctx->anchor_b / 32u;
     a.window_mode = window_mode ? 1u : 0u;
+    a.run_rule = (!ctx->stream_index && !window_mode) ? 1u : 0u;
+    a.seg_staged = static_cast<uint32_t *>(ctx->d_seg_fill.ptr) + (uint64_t)(1 + pass) * seg_count(ctx);
+    a.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
     const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + 2 * kPend);   // in u64 units
     const int grid = ctx->num_cus * 8;
     // small groups: one wave per group
@@ -1702,32 +1774,16 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.pair_counters = acounters + 32 + 8 * pass;
     // (the pair kernel hands its work out through counters: exactly the workgroups that are resident together, no second round)
     const int pgrid = ctx->num_cus * pair_blocks_per_cu(pairs_width);
-    if (pairs_width == 5) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 5>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 5>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
-    } else if (pairs_width == 8) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 8>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 8>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
-    } else if (pairs_width == 13) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_group_pairs<0, 13>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_group_pairs<1, 13>), dim3(pgrid), dim3(kThreads), 0, ctx->stream, a); }
-    } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
+    if (pairs_width != 0) { SWA_TRY(launch_group_pairs(ctx, pass, pairs_width, (int)(ctx->anchor_w / 32u), pgrid, a)); }
+    else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
     // big groups: one workgroup per 64-seed chunk
     a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
     a.item_count = acounters + pass;
     a.table_slots = 2 * kGroupCap;
     const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 2 + a.table_slots / 4);
-    if (tiled_big && pairs_width == 5) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 5>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-    } else if (tiled_big && pairs_width == 13) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 13>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 13>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-    } else if (tiled_big) {
-      if (pass == 0) { hipLaunchKernelGGL((k_d1_pairs_tiled<0, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-      else { hipLaunchKernelGGL((k_d1_pairs_tiled<1, 8>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); }
-    } else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    if (tiled_big) { SWA_TRY(launch_pairs_tiled(ctx, pass, pairs_width, (int)(ctx->anchor_w / 32u), grid, a)); }
+    else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_d1_anchor<false, 1>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
     swa_t1(ctx, 11 + pass);
     SWA_HIP(ctx, hipGetLastError());
@@ -1738,14 +1794,13 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   if ((ctx->full_index || ctx->member_index) && ctx->stream_index) {
     hipLaunchKernelGGL(k_stream_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first, count,
                        static_cast<const uint8_t *>(ctx->d_stream[kSbOver].ptr), static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2,
-                       ctx->owner_rank, ctx->owner_world, ctx->db.seqs, ctx->db.seq_off, ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen,
-                       window_mode ? 1u : 0u);
+                       ctx->owner_rank, ctx->owner_world, ctx->db.seqs, ctx->db.seq_off, anchor_minlen(ctx));
   } else if (ctx->full_index) {
   hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
                      count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr),
                      static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
                      static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world,
-                     ctx->db.seqs, ctx->db.seq_off, ctx->anchor_a + ctx->anchor_b + kMinAnchoredLen, window_mode ? 1u : 0u);
+                     ctx->db.seqs, ctx->db.seq_off, anchor_minlen(ctx), window_mode ? 1u : 0u);
   }
   NetArgs f{};
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
@@ -1767,7 +1822,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   f.fallback_count = acounters + 2;
   f.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
   f.owner_rank = 0; f.owner_world = 1;                       // the list already is this rank's share
-  f.window_mode = window_mode ? 1u : 0u; f.win_word = ctx->anchor_a / 32u;
+  f.window_mode = window_mode ? 1u : 0u; f.win_word = ctx->anchor_a / 32u; f.anchor_w = ctx->anchor_w;
   const size_t flds = sizeof(uint64_t) * ((zlds ? 4ull * ctx->zobrist_len : 0ull) + 1024ull +
                                           kWaves * ((size_t)(maxwords + 2u) + kQueueCap + kQueueCap / 2));
   const int fgrid = grid_for(ctx, count, kWaves, 8);
@@ -1817,11 +1872,11 @@ static int launch_seqhash(swa_ctx * ctx, bool members_only) {
     if (zlds) {
       hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                          ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count);
+                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count, ctx->anchor_w);
     } else {
       hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                          ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count);
+                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count, ctx->anchor_w);
     }
   }
   SWA_HIP(ctx, hipGetLastError());
@@ -1862,9 +1917,10 @@ static int ensure_full_index(swa_ctx * ctx) {
 // the normal case.  Window mode needs the pair kernels (sequences up to 416 nt); SWA_D1_WINDOWS=0 switches it off.
 static int choose_anchor_windows(swa_ctx * ctx) {
   ctx->anchor_a = ctx->anchor_b = 0;
+  ctx->anchor_w = 32;
   const char * env_win = getenv("SWA_D1_WINDOWS");
-  if (ctx->db.longest > 416u || (env_win != nullptr && env_win[0] == '0')) { return SWA_OK; }
   const uint32_t n = ctx->db.n;
+  const uint32_t max_nwin = anchor_max_nwin(ctx);
   const uint32_t stride = std::max<uint32_t>(1u, n / 65536u);
   const uint32_t samples = (n + stride - 1) / stride;
   const size_t slots = (size_t)2 * kSampleCandidates * kSampleSlots;
@@ -1872,18 +1928,32 @@ static int choose_anchor_windows(swa_ctx * ctx) {
   SWA_TRY(swa_reserve(ctx, ctx->d_acounts[0], std::max<size_t>(ctx->d_acounts[0].bytes, (slots + 16) * sizeof(uint32_t))));
   auto * keys = static_cast<unsigned long long *>(ctx->d_akeys[0].ptr);
   auto * counts = static_cast<uint32_t *>(ctx->d_acounts[0].ptr);
-  uint32_t * stats = counts + slots;                         // [0..4) too short, [4..8) mass
-  SWA_HIP(ctx, hipMemsetAsync(keys, 0xFF, slots * sizeof(uint64_t), ctx->stream));
+  uint32_t * stats = counts + slots;                         // [0..4) too short, [4..8) mass, [8] 0xFFFFFFFF - shortest sequence
+  const bool sample = !(ctx->db.longest > 416u || (env_win != nullptr && env_win[0] == '0'));
   SWA_HIP(ctx, hipMemsetAsync(counts, 0, (slots + 16) * sizeof(uint32_t), ctx->stream));
-  hipLaunchKernelGGL(k_anchor_sample, dim3(grid_for(ctx, samples, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                     ctx->db.seqlen, n, stride, keys, counts, stats);
-  hipLaunchKernelGGL(k_sample_mass, dim3(grid_for(ctx, slots, 256, 8)), dim3(256), 0, ctx->stream, counts, stride, stats + 4);
-  uint32_t host[8] = {};
+  hipLaunchKernelGGL(k_shortest, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, n, stats + 8);
+  if (sample) {
+    SWA_HIP(ctx, hipMemsetAsync(keys, 0xFF, slots * sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(k_anchor_sample, dim3(grid_for(ctx, samples, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                       ctx->db.seqlen, n, stride, keys, counts, stats, stats + 8, max_nwin);
+    hipLaunchKernelGGL(k_sample_mass, dim3(grid_for(ctx, slots, 256, 8)), dim3(256), 0, ctx->stream, counts, stride, stats + 4);
+  }
+  uint32_t host[9] = {};
   SWA_HIP(ctx, hipMemcpyAsync(host, stats, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t shortest = 0xFFFFFFFFu - host[8];
+  ctx->db_shortest = shortest;
+  // the ends, as wide as the shortest sequence allows — unless the sample finds them skewed (conserved flanks), then 32-nt
+  // windows moved inwards
+  ctx->anchor_w = 32u * anchor_nwin_for(shortest, 0u, max_nwin);
+  if (!sample) { return SWA_OK; }
   for (uint32_t c = 0; c < kSampleCandidates; ++c) {
     const bool few_short = host[c] <= samples / 64u || c == 0;
-    if (host[4 + c] <= samples / 64u && few_short) { ctx->anchor_a = ctx->anchor_b = 32u * c; return SWA_OK; }
+    if (host[4 + c] <= samples / 64u && few_short) {
+      ctx->anchor_a = ctx->anchor_b = 32u * c;
+      ctx->anchor_w = 32u * anchor_nwin_for(shortest, 32u * c, max_nwin);
+      return SWA_OK;
+    }
     if (!few_short) { break; }                               // (larger offsets only strand more seeds)
   }
   return SWA_OK;                                             // nothing qualifies: the ends it is (and the plain kernel for the giants)
@@ -1895,9 +1965,11 @@ static int ensure_anchor_windows(swa_ctx * ctx) {
   if (!ctx->windows_ready) {
     SWA_TRY(choose_anchor_windows(ctx));
     ctx->windows_chosen = ctx->anchor_a;
+    ctx->windows_w = ctx->anchor_w;
     ctx->windows_ready = true;
   }
   ctx->anchor_a = ctx->anchor_b = ctx->windows_chosen;
+  ctx->anchor_w = ctx->windows_w;
   return SWA_OK;
 }
 
@@ -2073,7 +2145,11 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_guard, 24 * sizeof(uint64_t)));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_guard.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
+  ctx->guard_index = false;
+  ctx->anchor_w = 32;
   ctx->anchor_usable = anchor_applicable(ctx);
 
   bool owned_ok = false;                                    // served without the database-wide table
@@ -2100,6 +2176,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
       uint32_t best = sampled, best_mass = mass;
       for (uint32_t w = sampled + 32u; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
         ctx->anchor_a = ctx->anchor_b = w;
+        ctx->anchor_w = 32;                                     // (moved windows: anchor_nwin_for)
         SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
         uint32_t m = 0;
         SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &m));
@@ -2108,11 +2185,13 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
       }
       if (ctx->anchor_a != best) {                            // (the last one tried was not the best: build that one again)
         ctx->anchor_a = ctx->anchor_b = best;
+        ctx->anchor_w = best == sampled ? ctx->windows_w : 32u;
         SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
         SWA_TRY(build_owned_index(ctx, first, count, &needs_table));
       }
     }
     ctx->windows_chosen = ctx->anchor_a;                     // (what the safety net settled on, for the next build)
+    ctx->windows_w = ctx->anchor_w;
     owned_ok = !needs_table;
     if (!owned_ok && ctx->only_oversized && member_index_enabled()) {
       // nothing but groups too large for the pair kernels stands in the way: a table of their members is all the plain kernel needs
@@ -2157,6 +2236,9 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   return SWA_OK;
 }
 
+// width of the anchor windows the last index build chose, in nucleotides (32, 64 or 128)
+extern "C" uint32_t swa_d1_anchor_width(const swa_ctx * ctx) { return ctx != nullptr ? ctx->anchor_w : 0; }
+
 extern "C" uint64_t swa_d1_table_size(const swa_ctx * ctx) { return ctx != nullptr ? ctx->table_size : 0; }
 
 // the anchor windows the last index build chose: out2 = {nt from the start, nt from the end} (0, 0 = the first / last 32 nt)
@@ -2193,6 +2275,7 @@ static int launch_network(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count
   a.stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
   a.counts = static_cast<uint32_t *>(ctx->d_counts.ptr);
   a.owner_rank = ctx->owner_rank; a.owner_world = ctx->owner_world;
+  a.anchor_w = 32;
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_counts.ptr, 0, uint64_t(count) * sizeof(uint32_t), ctx->stream));   // skipped seeds keep 0
   const bool zlds = 4ull * ctx->zobrist_len * sizeof(uint64_t) <= kMaxZobristLds;
@@ -2213,6 +2296,54 @@ static int launch_network(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count
   return SWA_OK;
 }
 
+// The guard (round 4).  The reference's network thread is serialised by a mutex and cannot return a partial
+// network (src/algod1.cc:630-670); this pipeline is twenty kernels handing records to one another, and twice in three
+// rounds a run lost the links of a few wavefronts' worth of amplicons without any error (DESIGN: the anomaly).  So the
+// counts that must balance are kept and compared before a network leaves this file:
+//   records keyed per index (k_keys)  =  members of listed + singleton + oversized groups (k_group1)
+//   members of listed groups          =  members the pair kernels staged, per pass
+//   no member sits in a group whose window key is not its own (pair_misfiled; key collisions excepted, exactly)
+//   links in the wave segments        =  links the partition sorted  =  the last CSR offset
+// A mismatch is SWA_E_INTERNAL — never a short network.
+static int guard_check(swa_ctx * ctx, const uint64_t * g, const uint64_t * got, bool csr_stream, uint64_t csr_end, uint32_t links_sorted,
+                       uint64_t n_edges) {
+  char msg[256];
+  if (g[10] != 0) {
+    snprintf(msg, sizeof(msg), "d=1 guard: %llu member(s) filed under an anchor key that is not theirs", (unsigned long long)g[10]);
+    return swa_fail_msg(ctx, SWA_E_INTERNAL, msg);
+  }
+  if (ctx->stream_index && ctx->guard_keys_pending) {
+    ctx->guard_keys_pending = false;
+    for (int i = 0; i < 3; ++i) {
+      if (g[16 + i] != g[19 + i]) {
+        snprintf(msg, sizeof(msg), "d=1 guard: the %s derived from the amplicon lines are not the ones the packed database gives (%016llx / %016llx)",
+                 i == 2 ? "sequence fingerprints" : (i == 0 ? "prefix-side key records" : "suffix-side key records"), (unsigned long long)g[19 + i],
+                 (unsigned long long)g[16 + i]);
+        return swa_fail_msg(ctx, SWA_E_INTERNAL, msg);
+      }
+    }
+    ctx->guard_keys_done = true;
+  }
+  if (ctx->stream_index && ctx->guard_index) {
+    for (int i = 0; i < 2; ++i) {
+      if (g[i] != g[2 + i] + g[4 + i] + g[6 + i]) {
+        snprintf(msg, sizeof(msg), "d=1 guard: index %d has %llu key records but %llu + %llu + %llu grouped members", i, (unsigned long long)g[i],
+                 (unsigned long long)g[2 + i], (unsigned long long)g[4 + i], (unsigned long long)g[6 + i]);
+        return swa_fail_msg(ctx, SWA_E_INTERNAL, msg);
+      }
+      if (got[2 + i] != g[2 + i]) {
+        snprintf(msg, sizeof(msg), "d=1 guard: pass %d staged %llu members of %llu listed", i, (unsigned long long)got[2 + i], (unsigned long long)g[2 + i]);
+        return swa_fail_msg(ctx, SWA_E_INTERNAL, msg);
+      }
+    }
+  }
+  if (csr_stream && (csr_end != n_edges || (uint64_t)links_sorted != (n_edges & 0xFFFFFFFFull))) {
+    snprintf(msg, sizeof(msg), "d=1 guard: %llu links found, %u sorted, CSR ends at %llu", (unsigned long long)n_edges, links_sorted, (unsigned long long)csr_end);
+    return swa_fail_msg(ctx, SWA_E_INTERNAL, msg);
+  }
+  return SWA_OK;
+}
+
 // The network over [first, first + count), left in HBM either as CSR (d_offsets / d_neighbours)
 // or, when d_edge_list != nullptr, as one flat list of (source << 32 | target) links.
 static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count, uint64_t * d_offsets,
@@ -2226,7 +2357,8 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
   SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * sizeof(uint64_t)));
   // hits leave the kernels through per-wave segments of the edge buffer (no shared counter)
   const uint32_t nseg = (uint32_t)ctx->num_cus * 8u * kWaves;          // >= waves of any launch below
-  SWA_TRY(swa_reserve(ctx, ctx->d_seg_fill, uint64_t(nseg) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_seg_fill, 3ull * nseg * sizeof(uint32_t)));   // fills | members staged, pass 0 | pass 1
+  SWA_TRY(swa_reserve(ctx, ctx->d_guard, 24 * sizeof(uint64_t)));
   if (ctx->seg_cap == 0) {
     ctx->seg_cap = 512;
     while (ctx->seg_cap < 8ull * count / nseg) { ctx->seg_cap <<= 1; }
@@ -2240,7 +2372,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
   bool clean = false;                                        // the last attempt ran to the end without a retry condition
   for (int attempt = 0; attempt < 8 && !clean; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
-    SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, uint64_t(nseg) * sizeof(uint32_t), ctx->stream));
+    SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, 3ull * nseg * sizeof(uint32_t), ctx->stream));
     // CSR by the streaming route (links sorted by source with the partition primitive) unless a flat list is wanted
     const bool csr_stream = d_edge_list == nullptr && stream_csr_enabled() && ctx->anchor_usable && !stats;
     if (ctx->anchor_usable && !stats) {
@@ -2281,7 +2413,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     }
     hipLaunchKernelGGL(k_seg_reduce, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
                        nseg, static_cast<unsigned long long *>(ctx->d_stats.ptr) + 8);
-    uint64_t got[2] = {0, 0};
+    uint64_t got[4] = {0, 0, 0, 0};                           // links, fullest segment, members staged by pass
     uint32_t anchor_overflow = 0;
     SWA_HIP(ctx, hipMemcpyAsync(got, static_cast<uint64_t *>(ctx->d_stats.ptr) + 8, sizeof(got), hipMemcpyDeviceToHost,
                                 ctx->stream));
@@ -2329,6 +2461,17 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     }
     SWA_HIP(ctx, hipGetLastError());
     swa_t1(ctx, 4);
+    uint64_t guard[24] = {};
+    uint64_t csr_end = 0;
+    uint32_t links_sorted = 0;
+    const bool guarded = ctx->anchor_usable && !stats;
+    if (guarded) {
+      SWA_HIP(ctx, hipMemcpyAsync(guard, ctx->d_guard.ptr, sizeof(guard), hipMemcpyDeviceToHost, ctx->stream));
+      if (csr_stream) {
+        SWA_HIP(ctx, hipMemcpyAsync(&csr_end, d_offsets + count, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        SWA_HIP(ctx, hipMemcpyAsync(&links_sorted, static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr) + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     n_edges = got[0];
     if (ctx->anchor_usable && !stats && anchor_overflow != 0) {
@@ -2348,7 +2491,11 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
       stream_link_cap = n_edges + 1024;
       continue;
     }
-    if (got[1] <= ctx->seg_cap) { clean = true; break; }
+    if (got[1] <= ctx->seg_cap) {
+      clean = true;
+      if (guarded) { SWA_TRY(guard_check(ctx, guard, got, csr_stream, csr_end, links_sorted, n_edges)); }
+      break;
+    }
     // one wave found more hits than its segment holds: grow the segments and run again (rare).
     // The small-group passes hand out work dynamically, so a wave's fill differs from run to run:
     // twice the observed maximum, not just the maximum
@@ -2398,7 +2545,8 @@ extern "C" int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count,
   SWA_HIP(ctx, hipMemsetAsync(d_counts, 0, (2ull * world + 1) * sizeof(uint32_t), ctx->stream));
   if (count != 0) {
     hipLaunchKernelGGL(k_anchor_route, dim3(grid_for(ctx, (count + kRoutePerThread - 1) / kRoutePerThread, 256, 8)), dim3(256), 0, ctx->stream,
-                       ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, first, count, world, ctx->anchor_a, ctx->anchor_b, d_ids, cap, d_counts);
+                       ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, first, count, world, ctx->anchor_a, ctx->anchor_b, ctx->anchor_w / 32u, d_ids, cap,
+                       d_counts);
   }
   SWA_HIP(ctx, hipGetLastError());
   // the caller reads the counts next (and may do so from another stream: a context without a caller's stream works on

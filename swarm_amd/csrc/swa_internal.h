@@ -82,6 +82,12 @@ struct swa_ctx {
   uint32_t owner_rank = 0, owner_world = 1;   // swa_d1_set_ownership: this context serves the anchor groups of one rank
   uint32_t anchor_slack = 0;     // 1 after a share-sized anchor table overflowed: size for the whole range
   uint32_t anchor_a = 0, anchor_b = 0;   // anchor windows moved inwards by this many nt ("window mode", chosen at index build)
+  uint32_t anchor_w = 32;        // width of the anchor windows in nt: 32, 64 or 128 (wider: fewer pairs per group; needs 2 w + 1 nt)
+  uint32_t windows_w = 32;       // ... as chosen for this database (with windows_chosen)
+  swa_dbuf d_guard;              // u64[24] the guard's counters (d1.hip: guard_check)
+  bool guard_index = false;      // [0..8) describe the index in place (made by the streaming build since the last clear)
+  bool guard_keys_done = false;  // the key records of this upload have had their second opinion (k_guard_db / k_guard_records)
+  bool guard_keys_pending = false;   // ... its sums, [16..22), wait for the next guard_check
   // d_acounts: the slot tables (tag | group size); d_akeys[0]: scratch of the window sample; d_ainfo: member records in
   // group order; d_apos: position inside the group; d_afp: sequence fingerprints per amplicon / in group order
   swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_aoffsets[2], d_aslot[2], d_aitems[2], d_ainfo[2], d_apos[2], d_afp[2];

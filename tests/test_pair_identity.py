@@ -111,3 +111,88 @@ def test_division_between_the_passes_covers_every_link_once():
             continue
         same_prefix, same_suffix = a[:32] == b[:32], a[-32:] == b[-32:]
         assert same_prefix or same_suffix, (a, b)
+
+
+# ---- round 4: anchor windows of 32 NW nucleotides (NW = 1, 2, 4) --------------------------------------------------------
+def kernel_pair_near(a: str, b: str, W: int, NW: int, PASS: int):
+    """pair_near<PASS, W, NW> with `ends` (d1_anchor.inc), dword for dword: the first 2 NW forward dwords (PASS 0) / the top
+    2 NW end-aligned dwords (PASS 1) are compared for equality only, `same` is the equality of the head (PASS 0) or read off
+    the forward chain (PASS 1: first difference at or beyond nucleotide 32 NW)."""
+    wa, ta = pack(a, W)
+    wb, tb = pack(b, W)
+    f = l = 0xFFFFFFFF
+    head = tail = 0
+    for k in range(2 * W):
+        if PASS == 0 and k < 2 * NW:
+            head |= wa[k] ^ wb[k]
+        else:
+            f = min(f, ffbl(wa[k] ^ wb[k]) | (32 * k))
+        if PASS == 1 and k >= 2 * W - 2 * NW:
+            tail |= ta[k] ^ tb[k]
+        else:
+            l = min(l, ffbh(ta[k] ^ tb[k]) | (32 * (2 * W - 1 - k)))
+    ok = tail == 0 if PASS == 1 else True
+    same = head == 0 if PASS == 0 else f >= 64 * NW
+    n = min(len(a), len(b))
+    apart = max(len(a), len(b)) - n
+    total = min(f >> 1, n) + min(l >> 1, n)
+    near = (total + 1 == n) if apart == 0 else (apart == 1 and total >= n)
+    return ok and near and (same if PASS == 0 else not same)
+
+
+def _edit(rng, a):
+    p = int(rng.integers(0, len(a)))
+    kind = int(rng.integers(0, 3))
+    ch = str(rng.choice(list("ACGT")))
+    return a[:p] + ch + a[p + 1:] if kind == 0 else (a[:p] + a[p + 1:] if kind == 1 else a[:p] + ch + a[p:])
+
+
+@pytest.mark.parametrize("W,NW", [(5, 1), (5, 2), (8, 2), (13, 2), (13, 4)])
+def test_wide_windows_divide_every_link_between_the_passes_once(W, NW):
+    """Two sequences of >= 2 w + 1 nt one edit apart share their first w or their last w nucleotides (w = 32 NW).  Inside a
+    prefix group (first windows equal) PASS 0 reports the pair, inside a suffix group (last windows equal) PASS 1 reports it
+    unless the first windows are equal as well: exactly one report per link, none for pairs that are not one edit apart —
+    also for pairs whose shorter member has only 2 w nucleotides (a target, never a source), runs, and low-complexity
+    alphabets, where deletions and insertions move through repeats."""
+    w = 32 * NW
+    rng = np.random.default_rng(100 * W + NW)
+    checked = 0
+    for trial in range(4000):
+        length = int(rng.integers(2 * w, min(32 * W, 2 * w + 40) + 1))
+        alphabet = ["A", "AC", "ACGT"][trial % 3]
+        a = "".join(rng.choice(list(alphabet), length))
+        b = a
+        for _ in range(int(rng.integers(0, 3))):
+            b = _edit(rng, b)
+        if not (2 * w <= len(b) <= 32 * W) or abs(len(a) - len(b)) > 1:
+            continue
+        truth = one_edit_apart(a, b) and max(len(a), len(b)) >= 2 * w + 1
+        same_prefix, same_suffix = a[:w] == b[:w], a[-w:] == b[-w:]
+        if truth:
+            assert same_prefix or same_suffix, (a, b)
+        reports = 0
+        if same_prefix:                                  # the two meet in a prefix group
+            reports += kernel_pair_near(a, b, W, NW, 0)
+            assert kernel_pair_near(a, b, W, NW, 0) == kernel_pair_near(b, a, W, NW, 0)
+        if same_suffix:                                  # ... and / or in a suffix group
+            reports += kernel_pair_near(a, b, W, NW, 1)
+            assert kernel_pair_near(a, b, W, NW, 1) == kernel_pair_near(b, a, W, NW, 1)
+        assert reports == (1 if one_edit_apart(a, b) else 0), (a, b, same_prefix, same_suffix)
+        checked += 1
+    assert checked > 1500
+
+
+@pytest.mark.parametrize("NW", [1, 2, 4])
+def test_members_of_a_colliding_suffix_group_are_not_paired(NW):
+    """Two window keys with equal 32-bit values share a group: members whose windows differ must not be reported by that
+    group (their true groups, if any, report them).  PASS 1 checks the last window for equality, PASS 0 the first."""
+    W = 13
+    w = 32 * NW
+    rng = np.random.default_rng(NW)
+    for _ in range(500):
+        a = "".join(rng.choice(list("ACGT"), 2 * w + 20))
+        p = int(rng.integers(len(a) - w, len(a)))            # an edit inside the last window
+        b = a[:p] + "ACGT"[("ACGT".index(a[p]) + 1) % 4] + a[p + 1:]
+        assert one_edit_apart(a, b)
+        assert not kernel_pair_near(a, b, W, NW, 1)          # would be a pair of the suffix group by position, but the windows differ
+        assert kernel_pair_near(a, b, W, NW, 0)              # the prefix group has it

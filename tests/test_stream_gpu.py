@@ -57,7 +57,8 @@ def test_heavy_tailed_sets_equal_the_oracle(tmp_path, monkeypatch, name, env, li
     off, nb = ctx.d1_network()
     assert np.array_equal(off, woff) and np.array_equal(nb, wnb)
     if name == "core":
-        assert ctx.d1_anchor_windows() != (0, 0)
+        # conserved flanks are answered by wider windows at the ends (round 4) or by 32-nt windows moved inwards
+        assert ctx.d1_anchor_windows() != (0, 0) or ctx.d1_anchor_width() > 32
     ctx.close()
 
 

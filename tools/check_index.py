@@ -14,18 +14,22 @@ import support as S  # noqa: E402
 from swarm_amd import Context  # noqa: E402
 
 
-def windows(db, which):
-    """the exact 64-bit anchor window of every amplicon (first / last 32 nt)"""
+def windows(db, which, nwin=1):
+    """a number per amplicon that is equal exactly for equal anchor windows (first / last 32 nwin nt)"""
     off = db.seq_off[:-1].astype(np.int64)
-    if which == 0:
-        return db.seqs[off]
+    padded = np.concatenate([db.seqs, np.zeros(8, np.uint64)])
     ln = db.seqlen.astype(np.int64)
-    pos = ln - 32
-    w, sh = pos >> 5, ((pos & 31) << 1).astype(np.uint64)
-    lo = db.seqs[off + w] >> sh
-    nxt = np.concatenate([db.seqs, np.zeros(2, np.uint64)])[off + w + 1]
-    hi = np.where(sh == 0, np.uint64(0), nxt << ((np.uint64(64) - sh) & np.uint64(63)))
-    return lo | hi
+    cols = []
+    for q in range(nwin):
+        pos = np.full(db.n, 32 * q, dtype=np.int64) if which == 0 else ln - 32 * nwin + 32 * q
+        w, sh = pos >> 5, ((pos & 31) << 1).astype(np.uint64)
+        lo = padded[off + w] >> sh
+        hi = np.where(sh == 0, np.uint64(0), padded[off + w + 1] << ((np.uint64(64) - sh) & np.uint64(63)))
+        cols.append(lo | hi)
+    if nwin == 1:
+        return cols[0]
+    _, inverse = np.unique(np.stack(cols, axis=1), axis=0, return_inverse=True)
+    return inverse.reshape(-1).astype(np.uint64)
 
 
 def main() -> None:
@@ -37,6 +41,8 @@ def main() -> None:
     ctx = Context(0)
     ctx.upload_db(db.seqs, db.seq_off, db.seqlen, db.abundance, db.longest)
     assert not ctx.d1_index_build()
+    nwin = ctx.d1_anchor_width() // 32
+    print(f"anchor windows: {32 * nwin} nt")
     counters = np.zeros(32, dtype=np.uint64)
     ctx._check(ctx.lib.swa_d1_debug_read(ctx.h, 14, counters.ctypes.data, counters.nbytes))
     counters = counters.view(np.uint32)
@@ -55,7 +61,7 @@ def main() -> None:
         cnt = np.bincount(members, minlength=n)
         print(f"index {which}: members once each: {bool((cnt == 1).all())} (missing {int((cnt == 0).sum())}, repeated {int((cnt > 1).sum())})")
         bad += 0 if (cnt == 1).all() else 1
-        win = windows(db, which)
+        win = windows(db, which, nwin)
         lists = [items[region[c]:region[c] + int(counters[32 + 8 * which + c])] for c in range(6)]
         chunks = items[:int(counters[which])]
         groups = np.concatenate(lists + [chunks[chunks[:, 2] == 0]])

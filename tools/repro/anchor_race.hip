@@ -172,7 +172,7 @@ int main(int argc, char ** argv) {
     int bad_rounds = 0;
     for (int r = 0; r < rounds; ++r) {
       CK(hipMemsetAsync(d_flags, 0, 64, stream));
-      k_seqhash<true><<<grid(n), 256, 4ull * zlen * 8, stream>>>(d_seqs, d_seq_off, d_seqlen, d_zob, zlen, n, d_seqhash, d_aux, nullptr, nullptr);
+      k_seqhash<true><<<grid(n), 256, 4ull * zlen * 8, stream>>>(d_seqs, d_seq_off, d_seqlen, d_zob, zlen, n, d_seqhash, d_aux, nullptr, nullptr, 32u);
       if (flow == 0) {
         k_table_clear<<<grid(tsize), 256, 0, stream>>>(d_table, tsize, d_bloom, bwords);
         k_table_insert<<<grid(n), 256, 0, stream>>>(d_seqhash, n, nullptr, d_table, tsize - 1, (unsigned long long *)d_bloom, bwords - 1, d_pat);
