@@ -1579,8 +1579,11 @@ static bool stream_csr_enabled() {
   return !(e != nullptr && e[0] == 't');
 }
 
-static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t nseg, uint64_t link_cap, uint64_t * d_offsets,
-                             uint32_t * d_neighbours, uint64_t cap) {
+// (the chunks of the first level: `chunks` runs of links, run c = links[cstart[c] .. + min(csize[c], csize_cap)) — the per-wave
+// segments of the pair kernels, or the ranks' lists of a multi-GPU job gathered on one device)
+static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const unsigned long long * links, const uint64_t * d_cstart,
+                           const uint32_t * d_csize, uint32_t chunks, uint32_t csize_cap, uint64_t max_tiles0, uint64_t link_cap,
+                           uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap) {
   uint32_t nbits = 1;
   while (nbits < 32 && ((uint64_t)1 << nbits) < count) { ++nbits; }
   uint32_t r = std::min<uint32_t>(8, nbits - 1);
@@ -1591,10 +1594,9 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
   j.max_records = link_cap;
   j.out_cap = link_cap;
   j.tile = 4096;
-  const uint64_t tiles_per_seg = (ctx->seg_cap + j.tile - 1) / j.tile;
-  j.max_tiles0 = (uint64_t)nseg * tiles_per_seg + 2;
-  j.chunks0 = nseg; j.single0 = true; j.top_bit = nbits; j.bias = first;
-  j.csize_cap = (uint32_t)std::min<uint64_t>(ctx->seg_cap, 0xFFFFFFFFu);
+  j.max_tiles0 = max_tiles0;
+  j.chunks0 = chunks; j.single0 = true; j.top_bit = nbits; j.bias = first;
+  j.csize_cap = csize_cap;
   uint64_t e_cnt, e_tile, e_start, e_partial;
   part_scratch(j, &e_cnt, &e_tile, &e_start, &e_partial);
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbLinkA], (link_cap + 1) * sizeof(uint64_t)));
@@ -1604,14 +1606,11 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbStart], (2 * e_start + 4) * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbPartial], e_partial * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbScal], 64 * sizeof(uint64_t)));
-  SWA_TRY(swa_reserve(ctx, ctx->d_seg_base, uint64_t(nseg) * sizeof(uint64_t)));
-  auto * seg_starts = static_cast<uint64_t *>(ctx->d_seg_base.ptr);
-  hipLaunchKernelGGL(k_seg_starts, dim3((nseg + 255) / 256), dim3(256), 0, ctx->stream, seg_starts, nseg, ctx->seg_cap);
-  j.in[0] = static_cast<const unsigned long long *>(ctx->d_edges.ptr);
+  j.in[0] = links;
   j.buf[0][0] = static_cast<unsigned long long *>(ctx->d_stream[kSbLinkA].ptr);
   j.buf[0][1] = static_cast<unsigned long long *>(ctx->d_stream[kSbLinkB].ptr);
-  j.cstart0[0] = seg_starts;
-  j.csize0[0] = static_cast<const uint32_t *>(ctx->d_seg_fill.ptr);
+  j.cstart0[0] = d_cstart;
+  j.csize0[0] = d_csize;
   j.cnt[0] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt].ptr);
   j.ctile[0] = static_cast<uint32_t *>(ctx->d_stream[kSbTile].ptr);
   j.starts[0] = static_cast<uint64_t *>(ctx->d_stream[kSbStart].ptr);
@@ -1636,6 +1635,17 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
   swa_t1(ctx, 14);
   SWA_HIP(ctx, hipGetLastError());
   return SWA_OK;
+}
+
+static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t nseg, uint64_t link_cap, uint64_t * d_offsets,
+                             uint32_t * d_neighbours, uint64_t cap) {
+  SWA_TRY(swa_reserve(ctx, ctx->d_seg_base, uint64_t(nseg) * sizeof(uint64_t)));
+  auto * seg_starts = static_cast<uint64_t *>(ctx->d_seg_base.ptr);
+  hipLaunchKernelGGL(k_seg_starts, dim3((nseg + 255) / 256), dim3(256), 0, ctx->stream, seg_starts, nseg, ctx->seg_cap);
+  const uint64_t tiles_per_seg = (ctx->seg_cap + 4096 - 1) / 4096;
+  return csr_from_chunks(ctx, first, count, static_cast<const unsigned long long *>(ctx->d_edges.ptr), seg_starts,
+                         static_cast<const uint32_t *>(ctx->d_seg_fill.ptr), nseg, (uint32_t)std::min<uint64_t>(ctx->seg_cap, 0xFFFFFFFFu),
+                         (uint64_t)nseg * tiles_per_seg + 2, link_cap, d_offsets, d_neighbours, cap);
 }
 
 // the pair kernels by (pass, record width W in words, window width NW in words): W = 5 / 8 / 13, NW = 1 / 2 (and 4 with
@@ -2529,6 +2539,31 @@ extern "C" int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breakin
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network_edges: bad range or null buffer");
   }
   return network_run(ctx, no_cluster_breaking, first, count, nullptr, nullptr, d_edge_list, cap, total);
+}
+
+// multi.hip: the CSR of the whole database from the ranks' link lists as they lie gathered on this device — `lists` runs of
+// (source << 32 | target) links, run r = d_links[starts[r] .. + counts[r]) — by the partition + row kernels of the
+// single-GPU step (two levels by source bits, then a wave per 256 sources) instead of a 64-bit radix sort of everything.
+// Leaves offsets [n + 1] and, if they fit `cap`, the neighbours (rows ascending) in the caller's device buffers.
+int swa_d1_csr_from_lists(swa_ctx * ctx, const unsigned long long * d_links, const uint64_t * starts, const uint64_t * counts, uint32_t lists,
+                          uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap) {
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  uint64_t all = 0, tiles = 2;
+  std::vector<uint64_t> h_start(lists);
+  std::vector<uint32_t> h_size(lists);
+  for (uint32_t r = 0; r < lists; ++r) {
+    if (counts[r] > 0xFFFFFFFFull) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_csr_from_lists: a list of more than 2^32 links"); }
+    h_start[r] = starts[r]; h_size[r] = (uint32_t)counts[r];
+    all += counts[r]; tiles += (counts[r] + 4095) / 4096;
+  }
+  SWA_TRY(swa_reserve(ctx, ctx->d_seg_base, ((uint64_t)lists * 3 / 2 + 2) * sizeof(uint64_t)));
+  auto * d_start = static_cast<uint64_t *>(ctx->d_seg_base.ptr);
+  auto * d_size = reinterpret_cast<uint32_t *>(d_start + lists);
+  SWA_HIP(ctx, hipMemcpyAsync(d_start, h_start.data(), lists * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(d_size, h_size.data(), lists * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the host vectors are temporaries)
+  return csr_from_chunks(ctx, 0, n, d_links, d_start, d_size, lists, 0xFFFFFFFFu, tiles, all + 1, d_offsets, d_neighbours, cap);
 }
 
 extern "C" int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint32_t * d_ids, uint64_t cap,

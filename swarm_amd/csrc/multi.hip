@@ -8,7 +8,7 @@
 // link of the network is found by exactly one rank.  Exchange, as SURVEY 8e / the north star name it: the
 // per-rank hit counts are known on the host when the kernels return, then every rank's flat link list is
 // gathered on rank 0 — the one consumer: grouped ncclSend / ncclRecv (round 2 all-gathered the whole network into every
-// GPU) —, and the CSR is a radix sort + offsets on that device.  Fastidious: the heavy amplicons are split
+// GPU) —, and the CSR is made there by the partition + row kernels of the single-GPU step (swa_d1_csr_from_lists).  Fastidious: the heavy amplicons are split
 // (swa_d1_fastidious_shard), graft_cand is combined with ncclAllReduce(min) (src/algod1.cc:244-258 keeps
 // the smallest heavy id), the two heavy-side counters add up.
 //
@@ -19,7 +19,6 @@
 #include "swa_internal.h"
 
 #include <rccl/rccl.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <functional>
@@ -39,20 +38,35 @@ struct swa_multi {
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_links_offsets(const unsigned long long * __restrict__ keys, uint64_t count, uint32_t n,
-                                                       uint64_t * __restrict__ offsets) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long want = (unsigned long long)i << 32;
-    uint64_t lo = 0, hi = count;
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (keys[mid] < want) { lo = mid + 1; } else { hi = mid; } }
-    offsets[i] = lo;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_links_targets(const unsigned long long * __restrict__ keys, uint64_t count,
-                                                       uint32_t * __restrict__ neighbours) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
-    neighbours[i] = (uint32_t)keys[i];
+// The ranks' shares of the d >= 2 graph arrive SORTED (swa_dn_graph_compute ends with a sort of its own share) and no key
+// occurs in two of them (a pair is found through the first window it shares, and that window's group lives on one rank),
+// so the whole is a merge, not a sort: element i of list r goes to i + (the number of smaller keys in every other list) —
+// `world - 1` binary searches per element over lists that lie in L2 — where round 3 ran a 64-bit radix sort (8 passes).
+// Equal keys across lists (which cannot happen) would still land in distinct places: upper bound below r, lower bound above.
+struct MergeArgs {
+  const unsigned long long * keys; const uint32_t * vals;     // the gathered lists, list r = [at[r], at[r + 1])
+  uint64_t at[65];
+  uint32_t world;
+  unsigned long long * out_keys; uint32_t * out_vals;
+};
+__global__ __launch_bounds__(256) void k_merge_sorted_lists(const MergeArgs a) {
+  const uint64_t all = a.at[a.world];
+  for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < all; idx += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t r = 0;
+    while (idx >= a.at[r + 1]) { ++r; }
+    const unsigned long long key = a.keys[idx];
+    uint64_t pos = idx - a.at[r];
+    for (uint32_t s2 = 0; s2 < a.world; ++s2) {
+      if (s2 == r) { continue; }
+      uint64_t lo = a.at[s2], hi = a.at[s2 + 1];
+      while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const unsigned long long k2 = a.keys[mid];
+        if (s2 < r ? k2 <= key : k2 < key) { lo = mid + 1; } else { hi = mid; }
+      }
+      pos += lo - a.at[s2];
+    }
+    a.out_keys[pos] = key; a.out_vals[pos] = a.vals[idx];
   }
 }
 
@@ -337,8 +351,7 @@ extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint
   {
     swa_ctx * c = m->ctx[0];
     if (hipSetDevice(c->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
-    // (sorted in place below: twice the room, for the radix sort's output)
-    rc = swa_reserve(c, m->gathered[0], (2 * all + 2) * sizeof(uint64_t));
+    rc = swa_reserve(c, m->gathered[0], (all + 2) * sizeof(uint64_t));
     if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
   }
   // (SWARM_AMD_MULTI_EXCHANGE=allgather: the literal all-gather of SURVEY 8e — every GPU ends with every list)
@@ -348,7 +361,7 @@ extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint
     for (int r = 0; r < world; ++r) {
       swa_ctx * c = m->ctx[(size_t)r];
       if (hipSetDevice(c->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
-      rc = swa_reserve(c, m->gathered[(size_t)r], (2 * all + 2) * sizeof(uint64_t));
+      rc = swa_reserve(c, m->gathered[(size_t)r], (all + 2) * sizeof(uint64_t));
       if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
       dst[(size_t)r] = m->gathered[(size_t)r].ptr;
     }
@@ -358,27 +371,21 @@ extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint
     rc = gather_to_root_v(m, src, m->gathered[0].ptr, count, sizeof(uint64_t));
     if (rc != SWA_OK) { return rc; }
   }
-  // 3. rank 0: sort by (source, target) -> CSR -> host
+  // 3. rank 0: the gathered lists -> CSR -> host.  The partition + row kernels of the single-GPU step (d1.hip: csr_from_chunks,
+  // the ranks' lists as the chunks of its first level) where round 3 ran a 64-bit radix sort over all links.
   swa_ctx * c0 = m->ctx[0];
   if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
   auto * keys_in = static_cast<unsigned long long *>(m->gathered[0].ptr);
-  auto * keys_out = keys_in + all + 1;
   auto stage = [&]() -> int {
-    if (all != 0) {
-      size_t bytes = 0;
-      (void)rocprim::radix_sort_keys(nullptr, bytes, keys_in, keys_out, all, 0, 64, c0->stream);
-      SWA_TRY(swa_reserve(c0, c0->d_scan_hits, bytes + 16));
-      SWA_HIP(c0, rocprim::radix_sort_keys(c0->d_scan_hits.ptr, bytes, keys_in, keys_out, all, 0, 64, c0->stream));
-    }
     c0->csr_ready = false;                                   // (d_offsets_tmp / d_nb_tmp now hold the gathered network)
     SWA_TRY(swa_reserve(c0, c0->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
-    hipLaunchKernelGGL(k_links_offsets, dim3(blocks_for(c0, (uint64_t)n + 1)), dim3(256), 0, c0->stream, keys_out, all, n,
-                       static_cast<uint64_t *>(c0->d_offsets_tmp.ptr));
+    SWA_TRY(swa_reserve(c0, c0->d_nb_tmp, (all + 1) * sizeof(uint32_t)));
+    std::vector<uint64_t> starts((size_t)world, 0);
+    for (int r = 1; r < world; ++r) { starts[(size_t)r] = starts[(size_t)r - 1] + count[(size_t)r - 1]; }
+    SWA_TRY(swa_d1_csr_from_lists(c0, keys_in, starts.data(), count.data(), (uint32_t)world, static_cast<uint64_t *>(c0->d_offsets_tmp.ptr),
+                                  static_cast<uint32_t *>(c0->d_nb_tmp.ptr), all + 1));
     SWA_HIP(c0, hipMemcpyAsync(offsets, c0->d_offsets_tmp.ptr, ((uint64_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
     if (all != 0 && all <= cap) {
-      SWA_TRY(swa_reserve(c0, c0->d_nb_tmp, all * sizeof(uint32_t)));
-      hipLaunchKernelGGL(k_links_targets, dim3(blocks_for(c0, all)), dim3(256), 0, c0->stream, keys_out, all,
-                         static_cast<uint32_t *>(c0->d_nb_tmp.ptr));
       SWA_HIP(c0, hipMemcpyAsync(neighbours, c0->d_nb_tmp.ptr, all * sizeof(uint32_t), hipMemcpyDeviceToHost, c0->stream));
     }
     SWA_HIP(c0, hipGetLastError());
@@ -517,10 +524,12 @@ extern "C" int swa_multi_dn_graph(swa_multi * m, int no_cluster_breaking, uint64
   if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
   auto stage = [&]() -> int {
     if (all != 0) {
-      size_t bytes = 0;
-      (void)rocprim::radix_sort_pairs(nullptr, bytes, keys, keys + all + 1, vals, vals + all + 1, all, 0, 64, c0->stream);
-      SWA_TRY(swa_reserve(c0, c0->d_scan_hits, bytes + 16));
-      SWA_HIP(c0, rocprim::radix_sort_pairs(c0->d_scan_hits.ptr, bytes, keys, keys + all + 1, vals, vals + all + 1, all, 0, 64, c0->stream));
+      MergeArgs ma{};
+      ma.keys = keys; ma.vals = vals; ma.world = (uint32_t)world;
+      for (int r = 0; r <= world; ++r) { ma.at[r] = at[(size_t)r]; }
+      ma.out_keys = keys + all + 1; ma.out_vals = vals + all + 1;
+      hipLaunchKernelGGL(k_merge_sorted_lists, dim3(blocks_for(c0, all)), dim3(256), 0, c0->stream, ma);
+      SWA_HIP(c0, hipGetLastError());
     }
     return swa_dn_graph_emit(c0, all != 0 ? keys + all + 1 : nullptr, all != 0 ? vals + all + 1 : nullptr, all, offsets, neighbours, diffs, cap, total);
   };

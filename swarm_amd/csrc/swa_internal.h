@@ -165,6 +165,10 @@ int swa_dn_graph_compute(swa_ctx * ctx, int no_cluster_breaking);
 int swa_dn_graph_emit(swa_ctx * ctx, const unsigned long long * sorted, const uint32_t * svals, uint64_t nedges, uint64_t * offsets,
                       uint32_t * neighbours, uint8_t * diffs, uint64_t cap, uint64_t * total);
 
+// d1.hip, for multi.hip: CSR of the whole database from link lists gathered on this context's device (partition + row kernels)
+int swa_d1_csr_from_lists(swa_ctx * ctx, const unsigned long long * d_links, const uint64_t * starts, const uint64_t * counts, uint32_t lists,
+                          uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap);
+
 // RAII-less timing brackets: SWA_T0(ctx, slot) ... SWA_T1(ctx, slot)
 inline void swa_t0(swa_ctx * ctx, int slot) {
   if (ctx->timing && ctx->ev_ready) { (void)hipEventRecord(ctx->ev[2 * slot], ctx->stream); }

@@ -183,3 +183,58 @@ def combine_grafts(graft_cand, counters, device=None, group=None):
     out_c = np.array(counters, dtype=np.uint64, copy=True)
     out_c[1:3] = add.cpu().numpy().astype(np.uint64)
     return g.cpu().numpy().astype(np.uint32), out_c
+
+
+def merge_sorted_lists(lists: list, payloads: list):
+    """k-way merge of sorted int64 key lists whose keys are distinct across lists (what rank 0 of a multi-GPU d >= 2 job
+    does with the ranks' shares — multi.hip: k_merge_sorted_lists): element i of list r goes to i + the number of smaller
+    keys in every other list.  Returns (keys, payload) merged; no sort of the whole."""
+    total = sum(int(k.numel()) for k in lists)
+    dev = lists[0].device
+    out_k = torch.empty(total, dtype=torch.int64, device=dev)
+    out_p = torch.empty(total, dtype=payloads[0].dtype, device=dev)
+    for r, (k, p) in enumerate(zip(lists, payloads)):
+        if k.numel() == 0:
+            continue
+        pos = torch.arange(k.numel(), dtype=torch.int64, device=dev)
+        for s, other in enumerate(lists):
+            if s != r and other.numel() != 0:
+                pos += torch.searchsorted(other, k, right=s < r)
+        out_k[pos] = k
+        out_p[pos] = p
+    return out_k, out_p
+
+
+def gather_dn_graph(keys: torch.Tensor, diffs: torch.Tensor, n: int, group=None):
+    """d >= 2 on several GPUs (second paragraph; the reference's fan-out: src/scan.cc:221-256 under the loop of
+    src/algo.cc:505-602).  Every rank holds the pairs of the window groups it owns (swa_dn_set_ownership) as a SORTED list
+    of triples — keys = query << 32 | target, diffs = differences of the pair — and every pair of the graph is held by
+    exactly one rank.  The lists travel to rank 0 (collectives: one all_gather of the counts, one gather of the keys, one
+    of the diffs, both padded to the longest list), which merges them (merge_sorted_lists) into the CSR the greedy walk
+    runs over.
+
+    Returns on rank 0 (offsets int64 [n + 1], neighbours int32 [total], diffs uint8 [total]); None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = keys.device
+    mine = torch.tensor([keys.numel()], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    counts_h = [int(c) for c in counts.tolist()]
+    longest = max(max(counts_h), 1)
+    pad_k = torch.zeros(longest, dtype=torch.int64, device=dev)
+    pad_k[:keys.numel()] = keys
+    pad_d = torch.zeros(longest, dtype=torch.uint8, device=dev)
+    pad_d[:diffs.numel()] = diffs.to(torch.uint8)
+    got_k = [torch.empty(longest, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
+    got_d = [torch.empty(longest, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad_k, got_k, dst=0, group=group)
+    dist.gather(pad_d, got_d, dst=0, group=group)
+    if rank != 0:
+        return None
+    lists = [got_k[r][:counts_h[r]] for r in range(world)]
+    pays = [got_d[r][:counts_h[r]] for r in range(world)]
+    merged, mdiff = merge_sorted_lists(lists, pays)
+    bounds = torch.arange(n + 1, dtype=torch.int64, device=dev) << 32
+    offsets = torch.searchsorted(merged, bounds)
+    return offsets, (merged & 0xFFFFFFFF).to(torch.int32), mdiff

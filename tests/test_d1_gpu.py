@@ -469,11 +469,14 @@ def _conserved_flank_set(path, n, seed, flank=40):
     path.write_bytes(b"".join(out))
 
 
-@pytest.mark.parametrize("n,seed", [(30000, 71), (150000, 72)])
-def test_conserved_flanks_move_the_anchor_windows(tmp_path, n, seed):
-    """Groups far beyond the LDS limit under the default anchors: the index build moves the windows inwards (window
-    mode: pair kernels, tiled for groups of 65..2048, filtered plain kernel beyond) — same network as the oracle's."""
+@pytest.mark.parametrize("n,seed,width", [(30000, 71, 32), (150000, 72, 32), (30000, 71, 0)])
+def test_conserved_flanks_move_the_anchor_windows(tmp_path, monkeypatch, n, seed, width):
+    """Groups far beyond the LDS limit under 32-nt anchors at the ends: the index build moves the windows inwards (window
+    mode: pair kernels, tiled for groups of 65..2048, filtered plain kernel beyond) — same network as the oracle's.
+    width 0 = the default choice (round 4): 64-nt windows at the ends reach past the 40 conserved nucleotides."""
     from swarm_amd import Context
+    if width:
+        monkeypatch.setenv("SWA_D1_ANCHOR_W", str(width))
     fa = tmp_path / "flanks.fa"
     _conserved_flank_set(fa, n, seed)
     db = S.db_from_fasta(fa)
@@ -481,7 +484,10 @@ def test_conserved_flanks_move_the_anchor_windows(tmp_path, n, seed):
     try:
         off, nb = _check_vs_oracle(ctx, db)
         assert len(nb) > n // 2
-        assert ctx.d1_anchor_windows()[0] >= 32                # the windows did move
+        if width == 32:
+            assert ctx.d1_anchor_windows()[0] >= 32            # the windows did move
+        else:
+            assert ctx.d1_anchor_windows() == (0, 0) and ctx.d1_anchor_width() == 64
         _check_vs_oracle(ctx, db, ncb=True)
     finally:
         ctx.close()

@@ -236,3 +236,70 @@ def test_routed_ids_reach_their_owners(tmp_path, world):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == world
+
+
+DN_WORKER = textwrap.dedent('''
+    import sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, sys.argv[1])
+    from swarm_amd import sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    # a d >= 2 graph (same stream on every rank): n amplicons, directed pairs (query, target, diff) within d differences;
+    # the rank that owns a pair = the rank owning the first window group the two share (here: a hash of the pair)
+    rng = np.random.default_rng(9)
+    n, m = 4001, 30011
+    q = rng.integers(0, n, size=m).astype(np.uint64)
+    t = rng.integers(0, n, size=m).astype(np.uint64)
+    keep = q != t
+    keys = np.unique((q[keep] << np.uint64(32)) | t[keep])            # every pair once, sorted
+    diffs = ((keys * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(61)).astype(np.uint8) % 3 + 1
+    owner = ((keys * np.uint64(2654435761)) >> np.uint64(13)) % np.uint64(world)
+    if len(sys.argv) > 2 and sys.argv[2] == "empty_rank":
+        owner[owner == world - 1] = 0                                  # a rank that owns no group at all
+    sel = owner == rank
+    mine_k = torch.from_numpy(keys[sel].astype(np.int64))             # sorted: what swa_dn_graph_compute leaves in HBM
+    mine_d = torch.from_numpy(diffs[sel])
+    got = sharding.gather_dn_graph(mine_k, mine_d, n)
+    if rank == 0:
+        off, nb, df = got
+        want_off = np.searchsorted(keys, np.arange(n + 1, dtype=np.uint64) << np.uint64(32))
+        assert np.array_equal(off.numpy(), want_off), "offsets differ"
+        assert np.array_equal(nb.numpy().view(np.uint32), (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)), "neighbours differ"
+        assert np.array_equal(df.numpy(), diffs), "differences differ"
+        rows_sorted = all(np.all(np.diff(nb.numpy().view(np.uint32)[want_off[i]:want_off[i + 1]].astype(np.int64)) > 0) for i in range(0, n, 97))
+        assert rows_sorted
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+''')
+
+
+@pytest.mark.parametrize("world,mode", [(2, "plain"), (3, "plain"), (3, "empty_rank")])
+def test_dn_triples_merge_into_the_graph(tmp_path, world, mode):
+    """The d >= 2 exchange (SURVEY 8e, second paragraph; swa_multi_dn_graph in C++): every rank holds the sorted triples of
+    the window groups it owns, rank 0 gathers and MERGES them (no sort of the whole) into the CSR the greedy walk reads."""
+    script = tmp_path / "dn_worker.py"
+    script.write_text(DN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script), str(S.ROOT), mode],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == world
+
+
+def test_merge_of_sorted_lists_equals_a_sort():
+    import torch
+    rng = np.random.default_rng(4)
+    for world in (1, 2, 5):
+        keys = np.unique(rng.integers(0, 1 << 40, size=5000).astype(np.int64))
+        owner = rng.integers(0, world, size=len(keys))
+        lists = [torch.from_numpy(keys[owner == r]) for r in range(world)]
+        pays = [torch.from_numpy((keys[owner == r] % 251).astype(np.uint8)) for r in range(world)]
+        k, p = sharding.merge_sorted_lists(lists, pays)
+        assert np.array_equal(k.numpy(), keys) and np.array_equal(p.numpy(), (keys % 251).astype(np.uint8))
