@@ -165,10 +165,36 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
                 "sample": f"oracle/ C restatement, index build + network only, {sample_n} x {length} bp, {dt:.2f} s"}
 
 
-def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, flank: int = 0, zipf: float = 0.0) -> dict:
+def gen_mixed_fasta(n: int, length: int, seed: int) -> Path:
+    """n x length amplicons plus one per cent of 420-480 nt ones (five blocks of lengths 425, 438, 450, 462, 475, each with
+    its own families): the file a 16S V4 run with a few V3-V4 or chimeric reads in it looks like."""
+    fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{length}_s{seed}_mixed.fa"
+    if fasta.exists():
+        return fasta
+    base = gen_fasta(n, length, seed)
+    tmp = fasta.with_suffix(f".tmp{os.getpid()}")
+    tool = str(gen_tool())
+    with open(tmp, "wb") as out:
+        with open(base, "rb") as src:
+            while True:
+                chunk = src.read(64 << 20)
+                if not chunk:
+                    break
+                out.write(chunk)
+        per = max(1, n // 500)
+        for b, lng in enumerate((425, 438, 450, 462, 475)):
+            part = fasta.with_suffix(f".long{b}.{os.getpid()}")
+            subprocess.run([tool, str(per), str(lng), str(seed * 7919 + b), "1", "0", str(part), str(n + b * per)], check=True)
+            out.write(part.read_bytes())
+            part.unlink()
+    os.replace(tmp, fasta)
+    return fasta
+
+
+def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, flank: int = 0, zipf: float = 0.0, mixed: bool = False) -> dict:
     """The bench step (index build + network, db and CSR resident) on n x length amplicons."""
     from swarm_amd import Context, HostDb
-    hdb = HostDb(gen_fasta(n, args.length, args.seed, 1, 0.0, flank, zipf))
+    hdb = HostDb(gen_mixed_fasta(n, args.length, args.seed) if mixed else gen_fasta(n, args.length, args.seed, 1, 0.0, flank, zipf))
 
     def to_dev(a: np.ndarray, as_dtype):
         return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
@@ -195,11 +221,15 @@ def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, f
     k = float(np.mean(k_ms))
     abytes = algorithmic_bytes(hdb.seqlen, total)
     windows = ctx.d1_anchor_windows()
+    width = ctx.d1_anchor_width()
     t8, st = ctx.timing_read(), ctx.timing_read_stream()
     ctx.close()
+    nucleotides = float(hdb.seqlen.astype(np.int64).sum())
     return {"workload": f"{hdb.n} synthetic amplicons x {args.length} bp, d=1" + (f", all centroids share their first / last {flank} nt" if flank else "")
+            + (", of them one per cent 420-480 nt long" if mixed else "")
             + (f", Zipf family sizes (GEN_ZIPF={zipf}: the largest family of every 2 M block holds that share of it)" if zipf else ""),
-            "anchor_windows_nt_from_the_ends": list(windows), "value": hdb.n * steps / elapsed,
+            "anchor_windows_nt_from_the_ends": list(windows), "anchor_width_nt": width, "value": hdb.n * steps / elapsed,
+            "ns_per_nucleotide": 1e9 * (elapsed / steps) / nucleotides,
             "unit": "amplicons/s", "steps": steps, "ms_per_step": 1000.0 * elapsed / steps, "network_kernels_ms": k,
             "neighbour_links": int(total),
             "kernel_group_ms": {"keys": st[0], "partition_keys": st[1], "groups": st[2], "pairs0": st[3], "pairs1": st[4], "partition_links": st[5], "csr_rows": st[6],
@@ -521,6 +551,7 @@ def main() -> None:
     ap.add_argument("--length", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", default="all", help="comma list of the config.* measurements to run after the timed region (default: all)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline step: no cpu_baseline, no configs1/2/3, no whole-run / seam timings, no PMC traffic")
     ap.add_argument("--no-configs1", action="store_true",
@@ -812,10 +843,14 @@ def main() -> None:
                              ("heavy_tail", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 0, 0.1)),
                              # 400-bp amplicons: the pair route with 13-word records (128-byte lines), 1 M x 400, d = 1
                              ("d1_x400", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 400}), 1_000_000, 5)),
+                             ("d1_x460", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 460}), 1_000_000, 5)),
+                             ("mixed_lengths", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 0, 0.0, True)),
                              ("host_seam_ms", lambda: host_seam(args, n_total)),
                              ("whole_run", lambda: whole_run(args, n_total, ref_md5, sample_n)),
                              ("configs2", lambda: config2_fastidious(args, args.per_gpu)),
                              ("configs3", lambda: config3_dn(args, 1_000_000, 400, 3))):
+                if args.extras != "all" and name not in args.extras.split(","):
+                    continue
                 try:
                     out["config"][name] = fn()
                 except Exception as e:                    # an extra must never cost the headline line

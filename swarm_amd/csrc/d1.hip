@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
                                                  const uint32_t * __restrict__ seqlen,
                                                  const uint64_t * __restrict__ zobrist, uint32_t zlen,
                                                  uint32_t n, uint64_t * __restrict__ seqhash,
-                                                 swa_aux * __restrict__ aux, const uint4 * __restrict__ list,
-                                                 const uint64_t * __restrict__ list_count, uint32_t anchor_w) {
+                                                 swa_aux * __restrict__ aux, uint32_t anchor_w) {
   extern __shared__ uint64_t lds[];
   const uint64_t * zob = zobrist;
   if (ZLDS) {
@@ -100,11 +99,7 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
     __syncthreads();
     zob = lds;
   }
-  // list != nullptr: only the amplicons of that list (the members of the anchor groups a rank serves: dense
-  // waves, work proportional to the rank's share instead of a walk over the whole replicated database)
-  const uint32_t todo = list != nullptr ? (uint32_t)*list_count : n;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < todo; k += gridDim.x * blockDim.x) {
-    const uint32_t a = list != nullptr ? list[k].x : k;
+  for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
     const uint64_t * s = seqs + seq_off[a];
     const uint32_t len = seqlen[a];
     uint64_t h = 0, dall = 0, iall = 0;
@@ -694,109 +689,6 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const T * __restrict_
   }
 }
 
-// ---- the same scan over the group sizes of an anchor index, making the work lists of the pair kernels on the way
-// (what a list kernel and k_needs_plain_kernel did in passes of their own over the 2 x 33 M table slots):
-// the tile pass also counts, per tile, the groups of every list; the sums pass turns those into the tile's first
-// place in each list (no atomics: list order is the table order, the same from run to run, up to the order inside a
-// tile); the apply pass writes the offsets and drops every group into its place.
-constexpr uint32_t kListKinds = kPairClasses + 2;           // size classes | 65..pair_big | 64-seed chunks of larger groups
-
-__device__ __forceinline__ uint32_t list_kind(uint32_t g, uint32_t pair_big, uint32_t group_cap = kGroupCap) {      // kListKinds: none
-  if (g < 2u || g > group_cap) { return kListKinds; }
-  if (g <= kSmallGroup) { return pair_class(g); }
-  return g <= pair_big ? kPairClasses : kPairClasses + 1u;
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_scan_tiles_lists(const unsigned long long * __restrict__ counts, uint32_t n,
-                                                                 uint64_t * __restrict__ tile_sums, uint32_t * __restrict__ tile_kinds,
-                                                                 uint32_t tiles, uint32_t pair_big, uint32_t tiled_cap, uint32_t * flags) {
-  __shared__ uint64_t smem[4];
-  __shared__ uint32_t cnt[kListKinds];
-  if (threadIdx.x < kListKinds) { cnt[threadIdx.x] = 0u; }
-  __syncthreads();
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  uint64_t v = 0;
-  bool oversized = false, enumerated = false;
-  uint32_t mass = 0;
-  for (int i = 0; i < kScanItems; ++i) {
-    if (base + i < n) {
-      const uint32_t g = (uint32_t)counts[base + i];
-      v += g;
-      const uint32_t kind = list_kind(g, pair_big);
-      if (kind < kListKinds) { atomicAdd(&cnt[kind], kind == kPairClasses + 1u ? (g + kSeedsPerItem - 1u) / kSeedsPerItem : 1u); }
-      if (g > kGroupCap) { oversized = true; mass += g; }
-      enumerated |= g > tiled_cap;
-    }
-  }
-  uint64_t total;
-  (void)block_exclusive_scan(v, smem, total);                // (its barriers also cover cnt[])
-  if (threadIdx.x == 0) { tile_sums[blockIdx.x] = total; }
-  if (threadIdx.x < kListKinds) { tile_kinds[threadIdx.x * tiles + blockIdx.x] = cnt[threadIdx.x]; }
-  // [4] oversized group [5] members of oversized groups [7] a group for the enumerating kernels (k_needs_plain_kernel's flags)
-  if (oversized) { atomicOr(flags + 4, 1u); atomicAdd(flags + 5, mass); }
-  if (enumerated) { flags[7] = 1u; }
-}
-
-// block 0: the tile sums; block 1 + k: the tiles' counts of list k -> first place of each tile in the list, the list's length
-__global__ __launch_bounds__(kScanBlock) void k_scan_sums_lists(uint64_t * tile_sums, uint32_t * tile_kinds, uint32_t tiles,
-                                                                uint32_t * list_counters, uint32_t * chunk_counter) {
-  __shared__ uint64_t smem[4];
-  uint64_t carry = 0;
-  const uint32_t kind = blockIdx.x - 1u;
-  for (uint32_t base = 0; base < tiles; base += kScanBlock) {
-    const uint32_t i = base + threadIdx.x;
-    uint64_t v = 0;
-    if (i < tiles) { v = blockIdx.x == 0 ? tile_sums[i] : tile_kinds[kind * tiles + i]; }
-    uint64_t total;
-    const uint64_t ex = block_exclusive_scan(v, smem, total);
-    if (i < tiles) {
-      if (blockIdx.x == 0) { tile_sums[i] = carry + ex; } else { tile_kinds[kind * tiles + i] = (uint32_t)(carry + ex); }
-    }
-    carry += total;
-  }
-  if (blockIdx.x != 0 && threadIdx.x == 0) {
-    if (kind <= kPairClasses) { list_counters[kind] = (uint32_t)carry; } else { *chunk_counter = (uint32_t)carry; }
-  }
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply_lists(const unsigned long long * __restrict__ counts, uint32_t n,
-                                                                 const uint64_t * __restrict__ tile_sums,
-                                                                 const uint32_t * __restrict__ tile_kinds, uint32_t tiles,
-                                                                 uint64_t * __restrict__ offsets, const PairLists l) {
-  __shared__ uint64_t smem[4];
-  __shared__ uint32_t cnt[kListKinds];
-  if (threadIdx.x < kListKinds) { cnt[threadIdx.x] = tile_kinds[threadIdx.x * tiles + blockIdx.x]; }
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  uint32_t c[kScanItems];
-  uint64_t v = 0;
-  for (int i = 0; i < kScanItems; ++i) {
-    c[i] = (base + i < n) ? (uint32_t)counts[base + i] : 0u;
-    v += c[i];
-  }
-  uint64_t total;
-  uint64_t run = tile_sums[blockIdx.x] + block_exclusive_scan(v, smem, total);     // (barriers: cnt[] is set)
-  for (int i = 0; i < kScanItems; ++i) {
-    if (base + i < n) {
-      offsets[base + i] = run;
-      const uint32_t g = c[i];
-      const uint32_t kind = list_kind(g, l.pair_big);
-      if (kind < kListKinds) {
-        swa_item it;
-        it.begin = (uint32_t)run; it.size = g; it.chunk = 0;
-        if (kind <= kPairClasses) {
-          l.items[l.region[kind] + atomicAdd(&cnt[kind], 1u)] = it;
-        } else {
-          const uint32_t chunks = (g + kSeedsPerItem - 1u) / kSeedsPerItem;
-          const uint32_t at = atomicAdd(&cnt[kind], chunks);
-          for (uint32_t k = 0; k < chunks; ++k) { it.chunk = k; l.chunk_items[at + k] = it; }
-        }
-      }
-    }
-    run += c[i];
-    if (base + i + 1 == n) { offsets[n] = run; }
-  }
-}
-
 // total and largest fill of the per-wave edge segments -> out[0], out[1]; the members the pair kernels staged (the
 // guard; seg_fill + nseg, + 2 nseg: pass 0, pass 1) -> out[2], out[3]
 // (one workgroup of 1024 threads, eight loads in flight per thread: the 8192 fills of an MI355X in one round — with 256
@@ -968,13 +860,13 @@ int swa_d1_rebuild_table(swa_ctx * ctx, const uint8_t * d_is_member) {
 }
 
 
-// ---- the anchored index (see d1_anchor.inc) -------------------------------------------------
+// ---- the anchored index (see d1_anchor.inc, d1_stream.inc) ----------------------------------------------------------
 static bool anchored_enabled() {
   const char * e = getenv("SWA_D1_PLAIN");
   return !(e != nullptr && e[0] == '1');
 }
 
-// SWA_D1_OWNED_FULL=1: a rank of a multi-GPU job builds the full index like a single GPU (test hook)
+// SWA_D1_OWNED_FULL=1: the database-wide table and Bloom filter are built as well (test hook: the plain kernel's structures)
 static bool owned_index_enabled() {
   const char * e = getenv("SWA_D1_OWNED_FULL");
   return !(e != nullptr && e[0] == '1');
@@ -985,56 +877,63 @@ static uint32_t anchor_minlen(const swa_ctx * ctx) { return ctx->anchor_a + ctx-
 
 // whether the anchored passes may be used at all for this database (decided at index build)
 static bool anchor_applicable(const swa_ctx * ctx) {
-  // (the anchored kernel prefetches a seed's words into kPrefetchWords registers per lane)
   return anchored_enabled() && ctx->db.longest >= kMinAnchoredLen && ctx->db.longest <= 64u * kPrefetchWords * 32u - 64u;
 }
 
-// work items of an index.  d_aitems: 64-seed chunks of the groups served by the enumerating / tiled kernels (fewer
-// than n / 32) at the start, from small_items_at on EITHER the small-group items of k_anchor_items (at most n / 2 +
-// n / kSmallChunkPrefix) OR the lists of k_scan_apply_lists (pair_region: groups of a class have at least
-// 2, 5, 9, 17, 33 and 65 members, which bounds each list); sized for both
-static uint64_t small_items_at(uint32_t n) { return uint64_t(n) / 8 + 32; }
-static uint64_t pair_region(uint32_t c, uint32_t n) {
-  static const uint32_t least[kPairClasses + 2] = {2, 5, 9, 17, 33, 65, 0};
-  uint64_t at = small_items_at(n);
-  for (uint32_t k = 0; k < c; ++k) { at += uint64_t(n) / least[k] + 64; }
-  return at;
-}
-static uint64_t items_capacity(uint32_t n) { return std::max<uint64_t>(uint64_t(n) + 128, pair_region(kPairClasses + 1, n)); }
-constexpr uint32_t kSmallChunkPrefix = 16;  // prefix pass: seeds per small item (a seed walks its whole sequence)
-constexpr uint32_t kSmallChunkSuffix = 64;  // suffix pass: 32 positions per seed, the table build dominates: no split
+// 16-byte quads per amplicon line: by the longest sequence of the database (64 bytes hold 7 words, 128 hold 15, 256 hold 31;
+// longer sequences are cut off in their lines and served by the plain kernel)
+static uint32_t line_quads_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 4u : (ctx->db.longest <= 480u ? 8u : 16u); }
 
-static bool stream_enabled() {
-  const char * e = getenv("SWA_D1_BUILD");
-  return !(e != nullptr && e[0] == 't');
-}
-static int lines_width_for(const swa_ctx * ctx) { return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0)); }
-
-// small groups (2..64 members): by pairs when a member's words fit a lane's registers (k_d1_group_pairs), else by
-// enumeration like the big groups (SWA_D1_ENUM_SMALL=1 forces that: comparison / test switch)
-static int pairs_width_for(const swa_ctx * ctx) {
-  const char * env_enum = getenv("SWA_D1_ENUM_SMALL");
-  const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;       // (only chosen when the pair kernels apply)
-  if (env_enum != nullptr && env_enum[0] == '1' && !window_mode) { return 0; }
-  return ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0));
-}
-// the streaming build + pair kernels serve this database (else: round 2's table build, sequences beyond 416 nt)
-static bool stream_route(const swa_ctx * ctx) { return stream_enabled() && pairs_width_for(ctx) != 0 && lines_width_for(ctx) != 0; }
-// widest anchor windows the kernels in place take, in words of 32 nt (anchor_nwin_for): 4 with the streaming build (128-nt
-// windows need 257-nt sequences: the 13-word kernels), 1 with the table build, whose enumerating kernels divide a seed at
-// position 32.  SWA_D1_ANCHOR_W=32 / 64 / 128 caps it (comparison switch).
-static uint32_t anchor_max_nwin(const swa_ctx * ctx) {
-  if (!stream_route(ctx)) { return 1u; }
+// widest anchor windows, in words of 32 nt (anchor_nwin_for).  SWA_D1_ANCHOR_W=32 / 64 / 128 caps it (comparison switch).
+static uint32_t anchor_max_nwin(const swa_ctx *) {
   uint32_t cap = 4u;
   if (const char * e = getenv("SWA_D1_ANCHOR_W")) { cap = std::min(4u, std::max(1u, (uint32_t)atoi(e) / 32u)); }
   return cap;
 }
-
 // groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
-// them to the enumerating / tiled kernel (test switch)
+// them to the tiled kernel (test switch)
 static uint32_t pair_big_limit() {
   const char * env = getenv("SWA_D1_PAIR_BIG");
-  return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSmallGroup, (uint32_t)atoi(env))) : kPairBigCap;
+  return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSeedsPerItem, (uint32_t)atoi(env))) : kPairBigCap;
+}
+
+// Shortest sequence and the population of every width class: facts of the uploaded database (k_db_lengths), read once per
+// upload.  The work lists of an index are laid out from the populations (list_regions).
+static int ensure_db_lengths(swa_ctx * ctx) {
+  if (ctx->props_ready) { return SWA_OK; }
+  SWA_TRY(swa_reserve(ctx, ctx->d_rank_tmp, std::max<size_t>(ctx->d_rank_tmp.bytes, 64)));
+  auto * out = static_cast<uint32_t *>(ctx->d_rank_tmp.ptr);
+  SWA_HIP(ctx, hipMemsetAsync(out, 0, 8 * sizeof(uint32_t), ctx->stream));
+  hipLaunchKernelGGL(k_db_lengths, dim3(grid_for(ctx, ctx->db.n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, ctx->db.n, out);
+  uint32_t host[8] = {};
+  SWA_HIP(ctx, hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->db_shortest = 0xFFFFFFFFu - host[0];
+  for (uint32_t c = 0; c <= kWidthClasses; ++c) { ctx->class_pop[c] = host[1 + c]; }
+  ctx->props_ready = true;
+  return SWA_OK;
+}
+
+// Where the work lists of an index lie in its item buffer.  A group of width class c has a member of that class, and all
+// its members are of classes <= c; a group on size list k has at least least[k] members: so list (c, k) holds at most
+// min(pop[c], pop[<= c] / least[k]) groups, and the row tiles of class c (64 members each, of groups of more than 256)
+// number at most pop[<= c] / 64 + pop[<= c] / 257.  A database of one class — the usual one — pays for one class.
+static ListRegions list_regions(const swa_ctx * ctx, uint64_t * total_items) {
+  static const uint32_t least[kListKinds] = {2, 5, 9, 17, 33, 65, 257};
+  ListRegions r{};
+  uint64_t at = 0, upto = 0;
+  for (uint32_t c = 0; c < kWidthClasses; ++c) {
+    upto += ctx->class_pop[c];
+    for (uint32_t k = 0; k < kListKinds; ++k) {
+      r.at[c][k] = at;
+      uint64_t room = 64;
+      if (ctx->class_pop[c] != 0) { room += k + 1 < kListKinds ? std::min<uint64_t>(ctx->class_pop[c], upto / least[k]) : upto / 64 + upto / 257; }
+      at += room;
+    }
+    r.at[c][kListKinds] = at;
+  }
+  *total_items = at;
+  return r;
 }
 
 // abundance rank of every amplicon (k_abundance_rank: three streaming passes); flags[1] is raised when the database is
@@ -1060,147 +959,8 @@ static int launch_abundance_rank(swa_ctx * ctx) {
 
 __global__ void k_set_flags(uint32_t * flags, uint32_t unserved, uint32_t shortest_code) { flags[3] = unserved; flags[6] = shortest_code; }
 
-// shortest sequence / "some sequence starts with 32 equal nucleotides": facts of the uploaded database (k_db_properties),
-// what a routed build knows instead of finding out while it walks the database
-static int ensure_db_properties(swa_ctx * ctx) {
-  if (ctx->props_ready) { return SWA_OK; }
-  SWA_TRY(swa_reserve(ctx, ctx->d_rank_tmp, std::max<size_t>(ctx->d_rank_tmp.bytes, 64)));
-  auto * out = static_cast<uint32_t *>(ctx->d_rank_tmp.ptr);
-  SWA_HIP(ctx, hipMemsetAsync(out, 0, 2 * sizeof(uint32_t), ctx->stream));
-  hipLaunchKernelGGL(k_db_properties, dim3(grid_for(ctx, ctx->db.n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                     ctx->db.seqlen, ctx->db.n, out);
-  uint32_t host[2] = {0, 0};
-  SWA_HIP(ctx, hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
-  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->db_shortest = 0xFFFFFFFFu - host[0];
-  ctx->db_run32 = host[1] != 0;
-  ctx->props_ready = true;
-  return SWA_OK;
-}
-
-// (re)builds the two anchor indexes for the query range [first, first + count)
-static int build_anchor_index(swa_ctx * ctx, uint32_t first, uint32_t count) {
-  ctx->anchor_ready = false;
-  ctx->stream_index = false;
-  const uint32_t n = ctx->db.n;
-  // Slot tables.  Safe size (anchor_slack = 1): load <= 0.5 if every anchor that gets a slot were its own group.
-  // Amplicon sets are nothing like that — ten million amplicons make two million groups — and with one word per slot
-  // a table that fits the last-level cache is worth a quarter of the build (10 M: 3.2 ms at the safe size, 2.75 at a
-  // quarter of it, 2.57 at an eighth), so the first build of a database is optimistic: a quarter of the safe size
-  // (SWA_D1_TABLE_DIV), for a rank of a multi-GPU job of its share of the anchors (hashed ownership, 25 % headroom),
-  // keys at most 64 slots from home.  k_anchor_place reports a table that turns out too small (few members per group,
-  // skewed ownership): everything built on it is discarded and the next build — at once, and from then on for this
-  // database — takes the safe size.
-  const char * env_div = getenv("SWA_D1_TABLE_DIV");
-  const uint64_t div = ctx->anchor_slack == 0 ? (uint64_t)std::max(1, env_div != nullptr ? atoi(env_div) : 4) : 1;
-  const bool routed = ctx->route_ids[0] != nullptr;          // the members of this rank's groups came as id lists
-  const bool optimistic = (ctx->owner_world > 1 || div > 1) && ctx->anchor_slack == 0;
-  const uint64_t members = routed ? std::max(ctx->route_m[0], ctx->route_m[1])
-                                  : (ctx->owner_world > 1 && ctx->anchor_slack == 0 ? (uint64_t(count) / ctx->owner_world) * 5 / 4 + 64 : count);
-  const uint64_t share = (routed && ctx->anchor_slack != 0 ? members : members / div) + 64;
-  uint64_t asize = 64;
-  while (asize < 2ull * share) { asize <<= 1; }
-  ctx->anchor_slots = asize;
-  for (int which = 0; which < 2; ++which) {
-    SWA_TRY(swa_reserve(ctx, ctx->d_acounts[which], asize * sizeof(uint64_t)));      // slots: tag | group size
-    SWA_TRY(swa_reserve(ctx, ctx->d_aoffsets[which], (asize + 1) * sizeof(uint64_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_aslot[which], uint64_t(n) * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_apos[which], uint64_t(n) * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[which], items_capacity(n) * sizeof(swa_item)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_ainfo[which], uint64_t(n) * sizeof(uint4)));
-  }
-  SWA_TRY(swa_reserve(ctx, ctx->d_afp[0], uint64_t(n) * sizeof(uint64_t)));      // per amplicon
-  SWA_TRY(swa_reserve(ctx, ctx->d_afp[1], uint64_t(n) * sizeof(uint64_t)));      // prefix index, group order
-  SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
-  const uint32_t tiles = (uint32_t)((asize + kScanTile - 1) / kScanTile);
-  SWA_TRY(swa_reserve(ctx, ctx->d_scan_tmp, uint64_t(tiles) * (sizeof(uint64_t) + kListKinds * sizeof(uint32_t))));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_acounters.ptr, 0, 64 * sizeof(uint32_t), ctx->stream));
-  auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
-  SWA_HIP(ctx, hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), ctx->stream));
-  AnchorBuildArgs b{};
-  AnchorScatterArgs sc{};
-  b.seqs = ctx->db.seqs; b.seq_off = ctx->db.seq_off; b.seqlen = ctx->db.seqlen; b.n = n;
-  b.first = first; b.count = count; b.amask = asize - 1; b.probe_limit = optimistic ? std::min<uint64_t>(64, asize - 1) : asize - 1;
-  b.fingerprint = static_cast<uint64_t *>(ctx->d_afp[0].ptr);
-  b.owner_rank = ctx->owner_rank; b.owner_world = ctx->owner_world; b.flags = dflags;
-  b.win_a = ctx->anchor_a; b.win_b = ctx->anchor_b;
-  b.minlen = anchor_minlen(ctx);
-  b.window_mode = (ctx->anchor_a != 0 || ctx->anchor_b != 0) ? 1u : 0u;
-  for (int which = 0; which < 2; ++which) {
-    b.slots[which] = static_cast<unsigned long long *>(ctx->d_acounts[which].ptr);
-    b.slot_of[which] = static_cast<uint32_t *>(ctx->d_aslot[which].ptr);
-    b.pos_of[which] = static_cast<uint32_t *>(ctx->d_apos[which].ptr);
-    sc.slot_of[which] = b.slot_of[which]; sc.pos_of[which] = b.pos_of[which];
-    sc.offsets[which] = static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr);
-    sc.minfo[which] = static_cast<uint4 *>(ctx->d_ainfo[which].ptr);
-  }
-  sc.fingerprint = b.fingerprint; sc.member_fingerprint = static_cast<uint64_t *>(ctx->d_afp[1].ptr);
-  sc.seqlen = ctx->db.seqlen; sc.rank = static_cast<const uint32_t *>(ctx->d_arank.ptr); sc.seq_off = ctx->db.seq_off; sc.n = n;
-  hipLaunchKernelGGL(k_anchor_clear, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream, b.slots[0], b.slots[1], asize);
-  if (routed) {
-    // unserved seeds / shortest sequence: facts of the database (the lists say nothing about amplicons that went elsewhere)
-    hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(1), 0, ctx->stream, dflags,
-                       (ctx->db_shortest < b.minlen || (b.window_mode == 0u && ctx->db_run32)) ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
-    for (int which = 0; which < 2; ++which) {
-      b.list = ctx->route_ids[which]; b.list_count = ctx->route_m[which]; b.list_which = which;
-      if (b.list_count != 0) { hipLaunchKernelGGL(k_anchor_place_list, dim3(grid_for(ctx, b.list_count, 256, 8)), dim3(256), 0, ctx->stream, b); }
-    }
-  } else {
-    hipLaunchKernelGGL(k_anchor_place<true>, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, b);
-    if (count < n) {
-      hipLaunchKernelGGL(k_anchor_place<false>, dim3(grid_for(ctx, n - count, 256, 8)), dim3(256), 0, ctx->stream, b);
-    }
-  }
-  // (a table that turned out too small — flags[2] — still leaves a consistent index of the amplicons placed before
-  // that: what follows runs on it harmlessly until the host looks at the flag, at the next point where it waits anyway)
-  ctx->pair_lists = pairs_width_for(ctx) != 0;
-  auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
-  for (int which = 0; which < 2; ++which) {
-    auto * tsums = static_cast<uint64_t *>(ctx->d_scan_tmp.ptr);
-    auto * offs = static_cast<uint64_t *>(ctx->d_aoffsets[which].ptr);
-    if (ctx->pair_lists) {
-      // offsets and the work lists of the pair kernels / the duplicate check in the same three launches
-      auto * tkinds = reinterpret_cast<uint32_t *>(tsums + tiles);
-      PairLists l{};
-      l.items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
-      for (uint32_t c = 0; c <= kPairClasses; ++c) { l.region[c] = pair_region(c, n); }
-      l.counters = acounters + 32 + 8 * which;
-      l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[which].ptr);
-      l.chunk_counter = acounters + which;
-      l.pair_big = pair_big_limit();
-      hipLaunchKernelGGL(k_scan_tiles_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums,
-                         tkinds, tiles, l.pair_big, kPairTiledCap, dflags);
-      hipLaunchKernelGGL(k_scan_sums_lists, dim3(1 + kListKinds), dim3(kScanBlock), 0, ctx->stream, tsums, tkinds, tiles, l.counters,
-                         l.chunk_counter);
-      hipLaunchKernelGGL(k_scan_apply_lists, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums,
-                         tkinds, tiles, offs, l);
-      continue;
-    }
-    hipLaunchKernelGGL((k_scan_tiles<unsigned long long>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, tsums, tiles);
-    hipLaunchKernelGGL((k_scan_apply<unsigned long long>), dim3(tiles), dim3(kScanBlock), 0, ctx->stream, b.slots[which], (uint32_t)asize, tsums, offs);
-  }
-  if (routed) {
-    for (int which = 0; which < 2; ++which) {
-      if (ctx->route_m[which] != 0) {
-        hipLaunchKernelGGL(k_anchor_scatter_list, dim3(grid_for(ctx, ctx->route_m[which], 256, 8)), dim3(256), 0, ctx->stream, sc, which,
-                           ctx->route_ids[which], ctx->route_m[which]);
-      }
-    }
-  } else {
-    hipLaunchKernelGGL(k_anchor_scatter, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, sc);
-  }
-  SWA_HIP(ctx, hipGetLastError());
-  ctx->anchor_first = first;
-  ctx->anchor_count = count;
-  ctx->anchor_ready = true;
-  return SWA_OK;
-}
-
 // ---- the streaming build (d1_stream.inc) ------------------------------------------------------
-// SWA_D1_BUILD=table: round 2's hash-table build (k_anchor_place / k_anchor_scatter / k_scatter_edges), kept for
-// comparison and for sequences beyond 416 nt (the enumerating kernels read its structures)
-enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbSlot = 7, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
+enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
        kSbMembers = 17, kSbOver = 19, kSbKind = 20, kSbLinkA = 22, kSbLinkB = 23, kSbHeavy = 24, kSbMTable = 26, kSbMBloom = 27, kSbSched = 28 };
 
 struct PartPlan { uint32_t levels; uint32_t bits[4]; uint32_t total; };
@@ -1346,21 +1106,22 @@ __global__ void k_set_u64x2(uint64_t * p0, uint64_t a0, uint64_t b0, uint64_t * 
 
 // the amplicon lines of the uploaded database (once per upload; needs the abundance ranks)
 static int ensure_lines(swa_ctx * ctx) {
-  const int w = lines_width_for(ctx);
-  if (w == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "amplicon lines: sequences longer than 416 nt"); }
-  if (ctx->lines_ready && ctx->lines_w == w) { return SWA_OK; }
+  const uint32_t lq = line_quads_for(ctx);
+  if (ctx->lines_ready && ctx->lines_quads == lq) { return SWA_OK; }
   const uint32_t n = ctx->db.n;
-  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbLines], (uint64_t)n * (w == 5 ? 64u : 128u)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbLines], (uint64_t)n * lq * 16u + 64u));   // (+ what window_at may read behind the last line)
   auto * lines = static_cast<uint4 *>(ctx->d_stream[kSbLines].ptr);
   const auto * rank = static_cast<const uint32_t *>(ctx->d_arank.ptr);
+  SWA_HIP(ctx, hipMemsetAsync(reinterpret_cast<uint8_t *>(lines) + (uint64_t)n * lq * 16u, 0, 64, ctx->stream));
   swa_t0(ctx, 15);
-  if (w == 5) { hipLaunchKernelGGL(k_lines_build<5>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
-  else if (w == 13) { hipLaunchKernelGGL(k_lines_build<13>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
-  else { hipLaunchKernelGGL(k_lines_build<8>, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
+  const dim3 grid(grid_for(ctx, n, 256, 8));
+  if (lq == 4u) { hipLaunchKernelGGL(k_lines_build<4>, grid, dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
+  else if (lq == 8u) { hipLaunchKernelGGL(k_lines_build<8>, grid, dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
+  else { hipLaunchKernelGGL(k_lines_build<16>, grid, dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, rank, n, lines); }
   swa_t1(ctx, 15);
   SWA_HIP(ctx, hipGetLastError());
   ctx->lines_ready = true;
-  ctx->lines_w = w;
+  ctx->lines_quads = lq;
   return SWA_OK;
 }
 
@@ -1371,8 +1132,11 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   ctx->anchor_ready = false;
   ctx->stream_index = false;
   const uint32_t n = ctx->db.n;
-  const int w = lines_width_for(ctx);
+  SWA_TRY(ensure_db_lengths(ctx));
   SWA_TRY(ensure_lines(ctx));
+  const uint32_t lq = ctx->lines_quads;
+  uint64_t item_room = 0;
+  const ListRegions regions = list_regions(ctx, &item_room);
   const bool routed = ctx->route_ids[0] != nullptr;
   const uint64_t records = routed ? std::max<uint64_t>(std::max(ctx->route_m[0], ctx->route_m[1]), 1) : n;
   // buckets of ~10 000 records for k_group1: ONE partition level of up to 10 bits at 10 M amplicons
@@ -1394,7 +1158,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   uint64_t e_cnt, e_tile, e_start, e_partial;
   part_scratch(j, &e_cnt, &e_tile, &e_start, &e_partial);
   const uint64_t buckets = 1ull << total_bits;
-  e_partial = std::max<uint64_t>(e_partial, ((uint64_t)kListKinds * buckets + 1) / kFlatChunk + 2);
+  e_partial = std::max<uint64_t>(e_partial, ((uint64_t)kListsPerIndex * buckets + 1) / kFlatChunk + 2);
   for (int i = 0; i < 2; ++i) {
     for (int h = 0; h < 2; ++h) { SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbRec + 2 * i + h], (records + 1) * sizeof(uint64_t))); }
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbFp + i], (records + 1) * sizeof(uint32_t)));
@@ -1403,19 +1167,19 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbStart + i], (2 * e_start + 4) * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbPartial + i], e_partial * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbMembers + i], (records + 1) * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbKind + i], ((uint64_t)kListKinds * buckets + 2) * sizeof(uint32_t)));
-    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[i], items_capacity(n) * sizeof(swa_item)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbKind + i], ((uint64_t)kListsPerIndex * buckets + 2) * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(ctx, ctx->d_aitems[i], (item_room + 1) * sizeof(swa_item)));
   }
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbScal], 64 * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbOver], ((uint64_t)n + 8) & ~3ull));
-  SWA_TRY(swa_reserve(ctx, ctx->d_acounters, 64 * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_acounters, kCounterWords * sizeof(uint32_t)));
   {
     ClearList c{};
-    clear_add(c, ctx->d_acounters.ptr, 64 * sizeof(uint32_t));
+    clear_add(c, ctx->d_acounters.ptr, kCounterWords * sizeof(uint32_t));
     clear_add(c, ctx->d_guard.ptr, 8 * sizeof(uint64_t));      // the guard's index counters: this build's
     clear_add(c, ctx->d_stream[kSbOver].ptr, ((uint64_t)n + 8) & ~3ull);
     // (the entry behind the last bucket's counts of each index: the scan of the counts reads one past the end)
-    for (int i = 0; i < 2; ++i) { clear_add(c, static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr) + (uint64_t)kListKinds * buckets, sizeof(uint32_t)); }
+    for (int i = 0; i < 2; ++i) { clear_add(c, static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr) + (uint64_t)kListsPerIndex * buckets, sizeof(uint32_t)); }
     SWA_TRY(clear_launch(ctx, c));
   }
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);                // (cleared by the caller: index build, or the retry)
@@ -1426,6 +1190,8 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   // ---- keys: records into the PONG halves (level 0 reads them from there), fingerprints likewise
   KeyArgs k{};
   k.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
+  k.line_quads = lq; k.reg_words = lq == 4u ? 5u : 7u;
+  k.seqs = ctx->db.seqs; k.seq_off = ctx->db.seq_off;
   k.n = n;
   for (int i = 0; i < 2; ++i) {
     k.list[i] = routed ? ctx->route_ids[i] : nullptr;
@@ -1454,15 +1220,11 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     k.hist_bits = j.plan.bits[0]; k.hist_tile = j.tile; k.hist_ntiles = ntiles;
     k.hist_run_bits = j.max_tiles0 >= (uint64_t)ctx->num_cus * 8 ? 4u : 0u;
     const dim3 hgrid((unsigned)((std::min<uint64_t>(ntiles, (uint64_t)ctx->num_cus * 8) + 7) & ~7ull), 1u);
-    if (w == 5) { hipLaunchKernelGGL((k_keys<5, true>), hgrid, dim3(256), 0, ctx->stream, k); }
-    else if (w == 13) { hipLaunchKernelGGL((k_keys<13, true>), hgrid, dim3(256), 0, ctx->stream, k); }
-    else { hipLaunchKernelGGL((k_keys<8, true>), hgrid, dim3(256), 0, ctx->stream, k); }
+    hipLaunchKernelGGL(k_keys<true>, hgrid, dim3(256), 0, ctx->stream, k);
     j.hist0_done = true;
   } else {
     const dim3 kgrid((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u);
-    if (w == 5) { hipLaunchKernelGGL((k_keys<5, false>), kgrid, dim3(256), 0, ctx->stream, k); }
-    else if (w == 13) { hipLaunchKernelGGL((k_keys<13, false>), kgrid, dim3(256), 0, ctx->stream, k); }
-    else { hipLaunchKernelGGL((k_keys<8, false>), kgrid, dim3(256), 0, ctx->stream, k); }
+    hipLaunchKernelGGL(k_keys<false>, kgrid, dim3(256), 0, ctx->stream, k);
   }
   hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, ctx->stream, scal, (uint64_t)0, (uint64_t)(routed ? ctx->route_m[0] : n), scal + 2, (uint64_t)0,
                      (uint64_t)(routed ? ctx->route_m[1] : n));
@@ -1525,7 +1287,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
   g.over = static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr);
   g.dup_first = dup_first; g.dup_count = dup_count;
-  g.lines = k.lines; g.line_quads = w == 5 ? 4u : 8u; g.line_w = (uint32_t)w;   // (64-byte lines for W = 5, 128-byte lines for W = 8, 13)
+  g.lines = k.lines; g.line_quads = lq;
   g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
   swa_t0(ctx, 10);
   {
@@ -1543,24 +1305,22 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   ListArgs la{};
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   for (int i = 0; i < 2; ++i) {
-    f.v[i] = g.g[i].kind_cnt; f.units[i] = nullptr; f.fixed[i] = (uint64_t)kListKinds * buckets + 1;
+    f.v[i] = g.g[i].kind_cnt; f.units[i] = nullptr; f.fixed[i] = (uint64_t)kListsPerIndex * buckets + 1;
     f.partial[i] = j.partial[i]; f.total[i] = reinterpret_cast<uint32_t *>(scal + 10 + i);
     ListIdx & x = la.x[i];
     x.items_tmp = g.g[i].items_tmp; x.bstart = g.g[i].bstart; x.kind_pos = g.g[i].kind_cnt; x.buckets = (uint32_t)buckets;
     x.l.items = static_cast<swa_item *>(ctx->d_aitems[i].ptr);
-    for (uint32_t c = 0; c <= kPairClasses; ++c) { x.l.region[c] = pair_region(c, n); }
-    x.l.counters = acounters + 32 + 8 * i;
-    x.l.chunk_items = static_cast<swa_item *>(ctx->d_aitems[i].ptr);
-    x.l.chunk_counter = acounters + i;
+    x.l.region = regions;
+    x.l.counters = acounters + kCounterBase + (uint32_t)i * kWidthClasses * 8u;
     x.l.pair_big = g.pair_big;
   }
-  const dim3 grid_k((unsigned)std::min<uint64_t>(((uint64_t)kListKinds * buckets + kFlatChunk) / kFlatChunk, (uint64_t)ctx->num_cus * 8), 2);
+  const dim3 grid_k((unsigned)std::min<uint64_t>(((uint64_t)kListsPerIndex * buckets + kFlatChunk) / kFlatChunk, (uint64_t)ctx->num_cus * 8), 2);
   hipLaunchKernelGGL(k_flat_sums, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_flat_apply, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_group_lists, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, (uint64_t)ctx->num_cus * 8), 2), dim3(256), 0, ctx->stream, la);
   swa_t1(ctx, 10);
   SWA_HIP(ctx, hipGetLastError());
-  ctx->pair_lists = true;
+  ctx->list_regions_items = item_room;
   ctx->anchor_first = 0;
   ctx->anchor_count = n;
   ctx->anchor_slots = 0;
@@ -1648,17 +1408,27 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
                          (uint64_t)nseg * tiles_per_seg + 2, link_cap, d_offsets, d_neighbours, cap);
 }
 
-// the pair kernels by (pass, record width W in words, window width NW in words): W = 5 / 8 / 13, NW = 1 / 2 (and 4 with
-// W = 13: 128-nt windows need sequences of 257 nt)
+// the pair kernels by (pass, record width W in words, window width NW in words): W = 5 / 8 / 15 / 21 (width_words), NW = 1 / 2
+// — and 4 with W >= 15: 128-nt windows need sequences of 257 nt
 #define SWA_PAIR_CASE(KERNEL, P, WW, NN) \
   if (pass == P && width == WW && nwin == NN) { hipLaunchKernelGGL((KERNEL<P, WW, NN>), dim3(grid), dim3(kThreads), 0, ctx->stream, a); return SWA_OK; }
+#define SWA_PAIR_WIDTH(KERNEL, WW) \
+  SWA_PAIR_CASE(KERNEL, 0, WW, 1) SWA_PAIR_CASE(KERNEL, 1, WW, 1) SWA_PAIR_CASE(KERNEL, 0, WW, 2) SWA_PAIR_CASE(KERNEL, 1, WW, 2)
 #define SWA_PAIR_CASES(KERNEL) \
-  SWA_PAIR_CASE(KERNEL, 0, 5, 1) SWA_PAIR_CASE(KERNEL, 1, 5, 1) SWA_PAIR_CASE(KERNEL, 0, 5, 2) SWA_PAIR_CASE(KERNEL, 1, 5, 2) \
-  SWA_PAIR_CASE(KERNEL, 0, 8, 1) SWA_PAIR_CASE(KERNEL, 1, 8, 1) SWA_PAIR_CASE(KERNEL, 0, 8, 2) SWA_PAIR_CASE(KERNEL, 1, 8, 2) \
-  SWA_PAIR_CASE(KERNEL, 0, 13, 1) SWA_PAIR_CASE(KERNEL, 1, 13, 1) SWA_PAIR_CASE(KERNEL, 0, 13, 2) SWA_PAIR_CASE(KERNEL, 1, 13, 2) \
-  SWA_PAIR_CASE(KERNEL, 0, 13, 4) SWA_PAIR_CASE(KERNEL, 1, 13, 4)
+  SWA_PAIR_WIDTH(KERNEL, 5) SWA_PAIR_WIDTH(KERNEL, 8) SWA_PAIR_WIDTH(KERNEL, 15) SWA_PAIR_WIDTH(KERNEL, 21) \
+  SWA_PAIR_CASE(KERNEL, 0, 15, 4) SWA_PAIR_CASE(KERNEL, 1, 15, 4) SWA_PAIR_CASE(KERNEL, 0, 21, 4) SWA_PAIR_CASE(KERNEL, 1, 21, 4)
+// (k_d1_group_pairs keeps a record per thread in LDS: static up to W = 8, dynamic — opted in per launch: the attribute belongs
+// to the function on a device — for W = 15 / 21)
+#define SWA_PAIR_CASE_DYN(KERNEL, P, WW, NN) \
+  if (pass == P && width == WW && nwin == NN) { \
+    const int bytes = (int)PairLayout<WW>::kDynamicBytes; \
+    if (bytes != 0) { SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<P, WW, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); } \
+    hipLaunchKernelGGL((KERNEL<P, WW, NN>), dim3(grid), dim3(kThreads), (size_t)bytes, ctx->stream, a); return SWA_OK; }
+#define SWA_PAIR_WIDTH_DYN(KERNEL, WW) \
+  SWA_PAIR_CASE_DYN(KERNEL, 0, WW, 1) SWA_PAIR_CASE_DYN(KERNEL, 1, WW, 1) SWA_PAIR_CASE_DYN(KERNEL, 0, WW, 2) SWA_PAIR_CASE_DYN(KERNEL, 1, WW, 2)
 static int launch_group_pairs(swa_ctx * ctx, int pass, int width, int nwin, int grid, const AnchorArgs & a) {
-  SWA_PAIR_CASES(k_d1_group_pairs)
+  SWA_PAIR_WIDTH_DYN(k_d1_group_pairs, 5) SWA_PAIR_WIDTH_DYN(k_d1_group_pairs, 8) SWA_PAIR_WIDTH_DYN(k_d1_group_pairs, 15) SWA_PAIR_WIDTH_DYN(k_d1_group_pairs, 21)
+  SWA_PAIR_CASE_DYN(k_d1_group_pairs, 0, 15, 4) SWA_PAIR_CASE_DYN(k_d1_group_pairs, 1, 15, 4) SWA_PAIR_CASE_DYN(k_d1_group_pairs, 0, 21, 4) SWA_PAIR_CASE_DYN(k_d1_group_pairs, 1, 21, 4)
   return swa_fail_msg(ctx, SWA_E_ARG, "pair kernels: no kernel for this record / window width");
 }
 static int launch_pairs_tiled(swa_ctx * ctx, int pass, int width, int nwin, int grid, const AnchorArgs & a) {
@@ -1666,16 +1436,17 @@ static int launch_pairs_tiled(swa_ctx * ctx, int pass, int width, int nwin, int 
   return swa_fail_msg(ctx, SWA_E_ARG, "pair kernels: no kernel for this record / window width");
 }
 
-// workgroups of k_d1_group_pairs<*, W> that one CU holds at a time (registers and LDS: the occupancy API; 1..8)
-static int pair_blocks_per_cu(int width) {
-  static int cached[3] = {0, 0, 0};
-  int & c = cached[width == 5 ? 0 : (width == 8 ? 1 : 2)];
+// workgroups of k_d1_group_pairs<*, W, *> that one CU holds at a time (registers and LDS: the occupancy API; 1..8)
+static int pair_blocks_per_cu(uint32_t cls) {
+  static int cached[kWidthClasses] = {};
+  int & c = cached[cls];
   if (c == 0) {
     int nb = 0;
-    const hipError_t e = width == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 5, 1>, kThreads, 0)
-                       : width == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 8, 1>, kThreads, 0)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 13, 1>, kThreads, 0);
-    c = (e == hipSuccess && nb >= 1) ? std::min(nb, 8) : 4;
+    const hipError_t e = cls == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 5, 1>, kThreads, 0)
+                       : cls == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 8, 1>, kThreads, 0)
+                       : cls == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 15, 1>, kThreads, PairLayout<15>::kDynamicBytes)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 21, 1>, kThreads, PairLayout<21>::kDynamicBytes);
+    c = (e == hipSuccess && nb >= 1) ? std::min(nb, 8) : (cls <= 1u ? 4 : (cls == 2u ? 2 : 1));
   }
   return c;
 }
@@ -1683,31 +1454,27 @@ static int pair_blocks_per_cu(int width) {
 // per-wave link segments: one per wave of the largest launch (d_seg_fill: [fills | members staged, pass 0 | pass 1])
 static uint32_t seg_count(const swa_ctx * ctx) { return (uint32_t)ctx->num_cus * 8u * kWaves; }
 
-// anchored network over [first, first+count): pass P, pass S, then the fallback seeds through
-// the plain kernel; edges / counts / edge counter as launch_network leaves them
+// anchored network over [first, first+count): per pass and width class the pair kernels over that class's work lists,
+// then the seeds (or halves of seeds) left to the plain kernel; links in the per-wave segments
 static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint32_t count, bool count_links) {
-  // [0] P big items [1] S big items [2] fallback seeds [3] P small items [4] S small items [5, 6] / [7, 8] work counters of the
-  // 65..256 groups / of the tiled kernel, per pass [16..32) work counters of the enumerating kernels
-  // [32 + 8 pass + c] lists of k_scan_apply_lists
+  // d_acounters: [2] fallback seeds [8 + 2 (4 pass + class) + {0, 1}] work counters of the 65..256 groups / of the tiled kernel
+  // [kCounterBase + 8 (4 index + class) + kind] the lists of k_group_lists (made at index build, not cleared here)
   auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
   SWA_TRY(swa_reserve(ctx, ctx->d_afallback, (2ull * count + 16) * sizeof(swa_fallback)));
   ClearList clears{};
   clear_add(clears, ctx->d_stats.ptr, 16 * sizeof(uint64_t));
   clear_add(clears, static_cast<uint64_t *>(ctx->d_guard.ptr) + 8, 8 * sizeof(uint64_t));   // the guard's counters of this network call
   if (count_links) { clear_add(clears, ctx->d_counts.ptr, uint64_t(count) * sizeof(uint32_t)); }
-  // item counts [0,1] big / [3,4] small, fallback count [2], work counters of both passes [16..32)
-  const int pairs_width = ctx->pair_lists ? pairs_width_for(ctx) : 0;
-  // (with pair lists, made at index build: [0], [1] and [32..48) are the index's)
-  clear_add(clears, acounters + (pairs_width != 0 ? 2 : 0), (pairs_width != 0 ? 30 : 32) * sizeof(uint32_t));
-  // work counters of k_d1_group_pairs (both passes): 2^shard_bits of them, sched_stride entries apart
+  clear_add(clears, acounters, kCounterBase * sizeof(uint32_t));
+  // work counters of k_d1_group_pairs (per pass and class): 2^shard_bits of them, sched_stride entries apart
   uint32_t pair_batch = 4, shard_bits = 6, sched_stride = 64;
   if (const char * e = getenv("SWA_D1_PAIR_BATCH")) { pair_batch = (uint32_t)std::max(1, atoi(e)); }                           // (experiments)
   if (const char * e = getenv("SWA_D1_PAIR_SHARD_BITS")) { shard_bits = (uint32_t)std::min(10, std::max(0, atoi(e))); }
   if (const char * e = getenv("SWA_D1_SCHED_STRIDE")) { sched_stride = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
   // (a workgroup serves the bundles of shard blockIdx.x mod 2^shard_bits: every shard needs a workgroup — ADVICE r03)
-  while (shard_bits > 0 && (1u << shard_bits) > (uint32_t)(ctx->num_cus * (pairs_width != 0 ? pair_blocks_per_cu(pairs_width) : 1))) { --shard_bits; }
-  if (pairs_width != 0) {
-    const uint64_t bytes = (2ull << shard_bits) * sched_stride * sizeof(uint32_t);
+  while (shard_bits > 0 && (1u << shard_bits) > (uint32_t)ctx->num_cus) { --shard_bits; }
+  {
+    const uint64_t bytes = ((2ull * kWidthClasses) << shard_bits) * sched_stride * sizeof(uint32_t);
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbSched], bytes));
     clear_add(clears, ctx->d_stream[kSbSched].ptr, bytes);
   }
@@ -1716,36 +1483,14 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   const uint32_t maxwords = (ctx->db.longest + 31u) >> 5;
   auto * stats = static_cast<unsigned long long *>(ctx->d_stats.ptr);
   swa_t0(ctx, 3);
-  // work items: every group of the index (it was built for exactly this query range)
-  const uint64_t asize = ctx->anchor_slots;
   const bool window_mode = ctx->anchor_a != 0 || ctx->anchor_b != 0;
-  // groups beyond pair_big: the tiled pair kernel, unless some group is so large (> kPairTiledCap) that the index build
-  // prepared hashes and XOR streams for the enumerating kernel — which then takes the whole list (window mode has
-  // only the pair kernels).  SWA_D1_PAIRS_TILED=1 / 0: test switches
-  const char * env_tiled = getenv("SWA_D1_PAIRS_TILED");
-  const bool aux_ready = ctx->full_index || ctx->aux_members;
-  const bool tiled_big = ctx->stream_index ||
-                         (pairs_width != 0 && (window_mode || !aux_ready || (env_tiled != nullptr && env_tiled[0] == '1')) &&
-                          !(env_tiled != nullptr && env_tiled[0] == '0' && aux_ready && !window_mode));
-  for (int which = 0; which < 2 && pairs_width == 0; ++which) {
-    hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                       static_cast<const unsigned long long *>(ctx->d_acounts[which].ptr),
-                       static_cast<const uint64_t *>(ctx->d_aoffsets[which].ptr), asize,
-                       static_cast<swa_item *>(ctx->d_aitems[which].ptr), acounters + which,
-                       static_cast<swa_item *>(ctx->d_aitems[which].ptr) + small_items_at(ctx->db.n), acounters + 3 + which,
-                       which == 0 ? kSmallChunkPrefix : kSmallChunkSuffix);
-  }
-  SWA_HIP(ctx, hipGetLastError());
+  uint64_t item_room = 0;
+  const ListRegions regions = list_regions(ctx, &item_room);
+  if (item_room != ctx->list_regions_items) { return swa_fail_msg(ctx, SWA_E_ARG, "d=1 network: the work lists in place were laid out for another database"); }
+  const int nwin = (int)(ctx->anchor_w / 32u);
   for (int pass = 0; pass < 2; ++pass) {
     swa_t0(ctx, 11 + pass);
     AnchorArgs a{};
-    a.seqs = ctx->db.seqs; a.seq_off = ctx->db.seq_off; a.seqlen = ctx->db.seqlen; a.abundance = ctx->db.abundance;
-    a.zobrist = static_cast<const uint64_t *>(ctx->d_zobrist.ptr);
-    a.zlen = ctx->zobrist_len; a.maxwords = maxwords;
-    a.aux = static_cast<const swa_aux *>(ctx->d_aux.ptr);
-    a.rank = static_cast<const uint32_t *>(ctx->d_arank.ptr);
-    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
-    a.item_count = acounters + pass;
     a.pass = pass;
     a.no_cluster_breaking = ncb;
     a.first = first; a.count = count;
@@ -1757,60 +1502,41 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.win_word = ctx->anchor_a / 32u;
     a.win_word_b = ctx->anchor_b / 32u;
     a.window_mode = window_mode ? 1u : 0u;
-    a.run_rule = (!ctx->stream_index && !window_mode) ? 1u : 0u;
     a.seg_staged = static_cast<uint32_t *>(ctx->d_seg_fill.ptr) + (uint64_t)(1 + pass) * seg_count(ctx);
     a.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
-    const size_t common = 2ull * ctx->zobrist_len + kWaves * (2 * (size_t)(maxwords + 2u) + 2 * kPend);   // in u64 units
-    const int grid = ctx->num_cus * 8;
-    // small groups: one wave per group
-    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr) + small_items_at(ctx->db.n);
-    a.item_count = acounters + 3 + pass;
-    a.sched = acounters + 16 + 8 * pass;
-    a.sched_big = acounters + 5 + pass;
-    a.sched_tiled = acounters + 7 + pass;
     a.batch = pair_batch; a.shard_bits = shard_bits; a.sched_stride = sched_stride;
-    a.sched_wide = static_cast<uint32_t *>(ctx->d_stream[kSbSched].ptr) + ((uint64_t)pass << shard_bits) * sched_stride;
-    a.small_chunk = pass == 0 ? kSmallChunkPrefix : kSmallChunkSuffix;
-    a.table_slots = 2 * kSmallGroup;
-    const size_t lds_small = sizeof(uint64_t) * (common + kWaves * (2 * kSmallGroup + kSmallGroup + kSmallGroup));   // table + ranks + Bloom
-    a.minfo = static_cast<const uint4 *>(ctx->d_ainfo[pass].ptr);
-    if (ctx->stream_index) {                                  // members = ids in group order + the amplicon lines
-      a.minfo = nullptr;
-      a.ids = static_cast<const uint32_t *>(ctx->d_stream[kSbMembers + pass].ptr);
-      a.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
-    }
+    a.ids = static_cast<const uint32_t *>(ctx->d_stream[kSbMembers + pass].ptr);
+    a.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
+    a.line_quads = ctx->lines_quads;
     a.pair_items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
-    for (uint32_t c = 0; c <= kPairClasses; ++c) { a.pair_region[c] = pair_region(c, ctx->db.n); }
-    a.pair_counters = acounters + 32 + 8 * pass;
-    // (the pair kernel hands its work out through counters: exactly the workgroups that are resident together, no second round)
-    const int pgrid = ctx->num_cus * pair_blocks_per_cu(pairs_width);
-    if (pairs_width != 0) { SWA_TRY(launch_group_pairs(ctx, pass, pairs_width, (int)(ctx->anchor_w / 32u), pgrid, a)); }
-    else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<true, 0>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
-    else { hipLaunchKernelGGL((k_d1_anchor<true, 1>), dim3(grid), dim3(kThreads), lds_small, ctx->stream, a); }
-    // big groups: one workgroup per 64-seed chunk
-    a.items = static_cast<const swa_item *>(ctx->d_aitems[pass].ptr);
-    a.item_count = acounters + pass;
-    a.table_slots = 2 * kGroupCap;
-    const size_t lds_big = sizeof(uint64_t) * (common + a.table_slots + a.table_slots / 2 + a.table_slots / 4);
-    if (tiled_big) { SWA_TRY(launch_pairs_tiled(ctx, pass, pairs_width, (int)(ctx->anchor_w / 32u), grid, a)); }
-    else if (pass == 0) { hipLaunchKernelGGL((k_d1_anchor<false, 0>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
-    else { hipLaunchKernelGGL((k_d1_anchor<false, 1>), dim3(grid), dim3(kThreads), lds_big, ctx->stream, a); }
+    for (uint32_t cls = 0; cls < kWidthClasses; ++cls) {
+      // (a group of class c has a member of class c: no such sequences, no such groups.  Lines too narrow for the class's
+      // records cannot occur: the lines are as wide as the longest sequence needs)
+      if (ctx->class_pop[cls] == 0) { continue; }
+      const int width = width_words(cls);
+      if (nwin == 4 && width < 15) { return swa_fail_msg(ctx, SWA_E_ARG, "pair kernels: 128-nt windows with sequences of 256 nt or less"); }
+      const uint32_t pc = (uint32_t)pass * kWidthClasses + cls;
+      for (uint32_t k = 0; k <= kPairClasses; ++k) { a.pair_region[k] = regions.at[cls][k]; }
+      a.pair_counters = acounters + kCounterBase + pc * 8u;
+      a.items = a.pair_items + regions.at[cls][kPairClasses + 1u];
+      a.item_count = a.pair_counters + kPairClasses + 1u;
+      a.sched_big = acounters + 8 + 2 * pc;
+      a.sched_tiled = acounters + 9 + 2 * pc;
+      a.sched_wide = static_cast<uint32_t *>(ctx->d_stream[kSbSched].ptr) + ((uint64_t)pc << shard_bits) * sched_stride;
+      // (the pair kernel hands its work out through counters: exactly the workgroups that are resident together, no second round)
+      SWA_TRY(launch_group_pairs(ctx, pass, width, nwin, ctx->num_cus * pair_blocks_per_cu(cls), a));
+      SWA_TRY(launch_pairs_tiled(ctx, pass, width, nwin, ctx->num_cus * (cls <= 1u ? 8 : 4), a));
+    }
     swa_t1(ctx, 11 + pass);
     SWA_HIP(ctx, hipGetLastError());
   }
   // seeds (or halves of seeds) the anchored passes skipped (a lean build has made sure there are none: no sequence
   // too short, no oversized group — and what holds for the whole database holds for every part of it)
   const bool use_member_table = ctx->member_index && !ctx->full_index;
-  if ((ctx->full_index || ctx->member_index) && ctx->stream_index) {
+  if (ctx->full_index || ctx->member_index) {
     hipLaunchKernelGGL(k_stream_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first, count,
                        static_cast<const uint8_t *>(ctx->d_stream[kSbOver].ptr), static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2,
                        ctx->owner_rank, ctx->owner_world, ctx->db.seqs, ctx->db.seq_off, anchor_minlen(ctx));
-  } else if (ctx->full_index) {
-  hipLaunchKernelGGL(k_anchor_fallback, dim3(grid_for(ctx, count, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, first,
-                     count, static_cast<const uint32_t *>(ctx->d_aslot[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr),
-                     static_cast<const uint32_t *>(ctx->d_aslot[1].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
-                     static_cast<swa_fallback *>(ctx->d_afallback.ptr), acounters + 2, ctx->owner_rank, ctx->owner_world,
-                     ctx->db.seqs, ctx->db.seq_off, anchor_minlen(ctx), window_mode ? 1u : 0u);
   }
   NetArgs f{};
   f.seqs = ctx->db.seqs; f.seq_off = ctx->db.seq_off; f.seqlen = ctx->db.seqlen; f.abundance = ctx->db.abundance;
@@ -1865,29 +1591,21 @@ static int prepare_hashing(swa_ctx * ctx) {
   return SWA_OK;
 }
 
-// sequence hashes + the XOR streams of the anchored passes; members_only: just the amplicons that
-// have a slot in one of the two anchor indexes (a rank that serves only the groups it owns)
-static int launch_seqhash(swa_ctx * ctx, bool members_only) {
+// sequence hashes + the XOR streams the plain kernel's restricted enumeration reads (swa_aux)
+static int launch_seqhash(swa_ctx * ctx) {
   const uint32_t n = ctx->db.n;
   const size_t zbytes = 4ull * ctx->zobrist_len * sizeof(uint64_t);
   const bool zlds = zbytes <= kMaxZobristLds;
-  if (ctx->owner_world == 1) { members_only = false; }        // a single GPU owns every group: everybody is a member
   swa_t0(ctx, 0);
-  // members_only: the member lists of the two anchor indexes (an amplicon in both is hashed twice: same values)
-  for (int pass = 0; pass < (members_only ? 2 : 1); ++pass) {
-    const uint4 * list = members_only ? static_cast<const uint4 *>(ctx->d_ainfo[pass].ptr) : nullptr;
-    const uint64_t * list_count = members_only ? static_cast<const uint64_t *>(ctx->d_aoffsets[pass].ptr) + ctx->anchor_slots : nullptr;
-    const uint64_t upper = members_only && ctx->owner_world > 1 ? (uint64_t(n) / ctx->owner_world) * 2 + 1024 : n;
-    const int hgrid = grid_for(ctx, upper, 256, 8);
-    if (zlds) {
-      hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                         ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count, ctx->anchor_w);
-    } else {
-      hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                         ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                         static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), list, list_count, ctx->anchor_w);
-    }
+  const int hgrid = grid_for(ctx, n, 256, 8);
+  if (zlds) {
+    hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                       ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), ctx->anchor_w);
+  } else {
+    hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                       ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), ctx->anchor_w);
   }
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 0);
@@ -1898,7 +1616,7 @@ static int launch_seqhash(swa_ctx * ctx, bool members_only) {
 // anchored-index metadata; shared by the d = 1 index and the d = 0 dereplication
 int swa_hash_sequences(swa_ctx * ctx) {
   SWA_TRY(prepare_hashing(ctx));
-  return launch_seqhash(ctx, false);
+  return launch_seqhash(ctx);
 }
 
 extern "C" int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates) {
@@ -1928,9 +1646,15 @@ static int ensure_full_index(swa_ctx * ctx) {
 static int choose_anchor_windows(swa_ctx * ctx) {
   ctx->anchor_a = ctx->anchor_b = 0;
   ctx->anchor_w = 32;
+  SWA_TRY(ensure_db_lengths(ctx));
+  const uint32_t shortest = ctx->db_shortest;
   const char * env_win = getenv("SWA_D1_WINDOWS");
   const uint32_t n = ctx->db.n;
   const uint32_t max_nwin = anchor_max_nwin(ctx);
+  // the ends, as wide as the shortest sequence allows — unless the sample finds them skewed (conserved flanks), then 32-nt
+  // windows moved inwards
+  ctx->anchor_w = 32u * anchor_nwin_for(shortest, 0u, max_nwin);
+  if (env_win != nullptr && env_win[0] == '0') { return SWA_OK; }
   const uint32_t stride = std::max<uint32_t>(1u, n / 65536u);
   const uint32_t samples = (n + stride - 1) / stride;
   const size_t slots = (size_t)2 * kSampleCandidates * kSampleSlots;
@@ -1938,25 +1662,15 @@ static int choose_anchor_windows(swa_ctx * ctx) {
   SWA_TRY(swa_reserve(ctx, ctx->d_acounts[0], std::max<size_t>(ctx->d_acounts[0].bytes, (slots + 16) * sizeof(uint32_t))));
   auto * keys = static_cast<unsigned long long *>(ctx->d_akeys[0].ptr);
   auto * counts = static_cast<uint32_t *>(ctx->d_acounts[0].ptr);
-  uint32_t * stats = counts + slots;                         // [0..4) too short, [4..8) mass, [8] 0xFFFFFFFF - shortest sequence
-  const bool sample = !(ctx->db.longest > 416u || (env_win != nullptr && env_win[0] == '0'));
+  uint32_t * stats = counts + slots;                         // [0..4) too short, [4..8) mass
+  SWA_HIP(ctx, hipMemsetAsync(keys, 0xFF, slots * sizeof(uint64_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(counts, 0, (slots + 16) * sizeof(uint32_t), ctx->stream));
-  hipLaunchKernelGGL(k_shortest, dim3(grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqlen, n, stats + 8);
-  if (sample) {
-    SWA_HIP(ctx, hipMemsetAsync(keys, 0xFF, slots * sizeof(uint64_t), ctx->stream));
-    hipLaunchKernelGGL(k_anchor_sample, dim3(grid_for(ctx, samples, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
-                       ctx->db.seqlen, n, stride, keys, counts, stats, stats + 8, max_nwin);
-    hipLaunchKernelGGL(k_sample_mass, dim3(grid_for(ctx, slots, 256, 8)), dim3(256), 0, ctx->stream, counts, stride, stats + 4);
-  }
-  uint32_t host[9] = {};
+  hipLaunchKernelGGL(k_anchor_sample, dim3(grid_for(ctx, samples, 256, 8)), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
+                     ctx->db.seqlen, n, stride, keys, counts, stats, shortest, max_nwin);
+  hipLaunchKernelGGL(k_sample_mass, dim3(grid_for(ctx, slots, 256, 8)), dim3(256), 0, ctx->stream, counts, stride, stats + 4);
+  uint32_t host[8] = {};
   SWA_HIP(ctx, hipMemcpyAsync(host, stats, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t shortest = 0xFFFFFFFFu - host[8];
-  ctx->db_shortest = shortest;
-  // the ends, as wide as the shortest sequence allows — unless the sample finds them skewed (conserved flanks), then 32-nt
-  // windows moved inwards
-  ctx->anchor_w = 32u * anchor_nwin_for(shortest, 0u, max_nwin);
-  if (!sample) { return SWA_OK; }
   for (uint32_t c = 0; c < kSampleCandidates; ++c) {
     const bool few_short = host[c] <= samples / 64u || c == 0;
     if (host[4 + c] <= samples / 64u && few_short) {
@@ -2039,91 +1753,28 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair of
   // identical sequences is seen by exactly one rank); a single GPU honours the slice it was asked about
   const uint32_t dup_first = ctx->owner_world > 1 ? 0u : first, dup_count = ctx->owner_world > 1 ? n : count;
-  const bool stream = stream_enabled() && pairs_width_for(ctx) != 0 && lines_width_for(ctx) != 0;
-  if (stream) {
-    // streaming build (d1_stream.inc): keys, partition, groups + work lists + identical sequences, all in one go
-    swa_t0(ctx, 7);
-    SWA_TRY(build_stream_index(ctx, dup_first, dup_count));
-    swa_t1(ctx, 7);
-  } else {
-    swa_t0(ctx, 7);
-    SWA_TRY(build_anchor_index(ctx, 0, n));
-    swa_t1(ctx, 7);
-    const uint64_t asize = ctx->anchor_slots;
-    auto * acounters = static_cast<uint32_t *>(ctx->d_acounters.ptr);
-    if (!ctx->pair_lists) {                                   // (with pair lists the scan over the group sizes has set these flags)
-      hipLaunchKernelGGL(k_needs_plain_kernel, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                         static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const unsigned long long *>(ctx->d_acounts[1].ptr),
-                         asize, dflags, 0u);
-    }
-    // duplicates: all pairs inside the owned prefix groups (work items as the network passes use them)
-    swa_t0(ctx, 2);
-    if (!ctx->pair_lists) {
-      hipLaunchKernelGGL(k_anchor_items, dim3(grid_for(ctx, asize, 256, 8)), dim3(256), 0, ctx->stream,
-                         static_cast<const unsigned long long *>(ctx->d_acounts[0].ptr), static_cast<const uint64_t *>(ctx->d_aoffsets[0].ptr),
-                         asize, static_cast<swa_item *>(ctx->d_aitems[0].ptr), acounters + 0,
-                         static_cast<swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n), acounters + 3, kSmallGroup);
-    }
-    DupArgs da{};
-    da.seqs = ctx->db.seqs; da.seq_off = ctx->db.seq_off; da.seqlen = ctx->db.seqlen;
-    da.minfo = static_cast<const uint4 *>(ctx->d_ainfo[0].ptr);
-    da.member_fingerprint = static_cast<const uint64_t *>(ctx->d_afp[1].ptr);
-    da.flag = dflags;
-    // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair is
-    // seen by exactly one rank); a single GPU honours the slice it was asked about
-    da.first = ctx->owner_world > 1 ? 0u : first;
-    da.count = ctx->owner_world > 1 ? n : count;
-    if (ctx->pair_lists) {
-      da.pair_items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);
-      for (uint32_t c = 0; c <= kPairClasses; ++c) { da.pair_region[c] = pair_region(c, n); }
-      da.pair_counters = acounters + 32;
-      hipLaunchKernelGGL(k_dup_bundles, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
-      da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + pair_region(kPairClasses, n);   // groups of 65..pair_big
-      da.item_count = acounters + 32 + kPairClasses;
-      hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
-    } else {
-      da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr) + small_items_at(n);
-      da.item_count = acounters + 3;
-      hipLaunchKernelGGL(k_dup_groups_small, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, da);
-    }
-    da.items = static_cast<const swa_item *>(ctx->d_aitems[0].ptr);             // chunks of the groups beyond
-    da.item_count = acounters + 0;
-    hipLaunchKernelGGL(k_dup_groups_big, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, da);
-    SWA_HIP(ctx, hipGetLastError());
-    swa_t1(ctx, 2);
-  }
-  // [0] duplicates [1] order broken [2] anchor table overflow [3] short sequence / pb = 0 [4] oversized group
-  // [5] members of oversized groups [6] 0xFFFFFFFF - shortest sequence [7] groups for the enumerating kernels
+  // streaming build (d1_stream.inc): keys, partition, groups + work lists + identical sequences, all in one go
+  swa_t0(ctx, 7);
+  SWA_TRY(build_stream_index(ctx, dup_first, dup_count));
+  swa_t1(ctx, 7);
+  // [0] duplicates [1] order broken [2] a bucket's groups do not fit the table [3] a sequence too short for two windows
+  // [4] groups left to the plain kernel (oversized / a member too long) [5] their members [6] 0xFFFFFFFF - shortest sequence
   uint32_t flags[8] = {};
   SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
   if (shortest != nullptr) { *shortest = 0xFFFFFFFFu - flags[6]; }
-  if (flags[2] != 0 && ctx->stream_index) {                 // a bucket with more distinct keys than the group kernel's table: finer
+  if (flags[2] != 0) {                                      // a bucket with more distinct keys than the group kernel's table: finer
     if (ctx->stream_extra_bits >= 8) { return swa_fail_msg(ctx, SWA_E_DEVICE, "streaming index build: partition still too coarse"); }
     ctx->stream_extra_bits += 2;
     SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
     return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
   }
-  if (flags[2] != 0 && ctx->anchor_slack == 0) {            // the optimistic key tables were too small: once more, safe size
-    ctx->anchor_slack = 1;
-    SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
-    return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
-  }
   if (flags[1] != 0) { ctx->db_unordered = true; }
   *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
-  // (oversized groups are the ONLY reason: a table of their members alone serves the plain kernel — build_member_index)
-  ctx->only_oversized = ctx->stream_index && flags[4] != 0 && flags[1] == 0 && flags[3] == 0;
+  // (groups left to the plain kernel are the ONLY reason: a table of their members alone serves it — build_member_index)
+  ctx->only_oversized = flags[4] != 0 && flags[1] == 0 && flags[3] == 0;
   ctx->over_mass = flags[5];
-  // Zobrist hashes and XOR streams of the members: only the enumerating kernels read them (the pair kernels compare
-  // the sequences themselves, the duplicate check their fingerprints); the full route hashes everybody anyway
-  ctx->aux_members = false;
-  // (the groups of the whole database bound those of any later re-index — another query range, another owner)
-  ctx->aux_needed = !ctx->stream_index && (flags[7] != 0 || pairs_width_for(ctx) == 0);
-  if (!*needs_table && ctx->aux_needed) {
-    SWA_TRY(launch_seqhash(ctx, true));
-    ctx->aux_members = true;
-  }
   return SWA_OK;
 }
 
@@ -2138,7 +1789,6 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   ctx->anchor_ready = false;
   ctx->full_index = false;
   ctx->member_index = false;
-  ctx->aux_complete = false;
   ctx->anchor_a = ctx->anchor_b = 0;
   for (int slot : {0, 1, 2, 7, 8, 9, 10, 15}) { ctx->ev_used[slot] = false; }   // phases this build does not run report 0
   ctx->table_size = swa_hashtable_size(n);
@@ -2176,13 +1826,13 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     // Conserved flanks: when a noticeable part of the database sits in groups too large for LDS (everybody shares
     // the first or last 32 nt), the anchor windows move inwards, 32 nt at a time, as far as the shortest sequence
     // allows (every seed needs win_a + win_b + 65 nt), and the setting with the fewest stranded members wins.  Window
-    // mode needs the pair kernels (sequences up to 416 nt); SWA_D1_WINDOWS=0 switches the search off.
+    // SWA_D1_WINDOWS=0 switches the search off.
     const char * env_win = getenv("SWA_D1_WINDOWS");
     // (safety net behind the sample: the real build still found too many stranded members — try the next offsets.
     // Single GPU only: under ownership `mass` counts the oversized groups THIS rank owns, the ranks would settle on
     // different windows and divide the pairs differently; there the sampled choice — the same on every rank — stands
     // and oversized groups take the plain kernel)
-    if (!routed && ctx->owner_world == 1 && needs_table && mass > n / 64u && ctx->db.longest <= 416u && !(env_win != nullptr && env_win[0] == '0')) {
+    if (!routed && ctx->owner_world == 1 && needs_table && mass > n / 64u && !(env_win != nullptr && env_win[0] == '0')) {
       uint32_t best = sampled, best_mass = mass;
       for (uint32_t w = sampled + 32u; 2u * w + kMinAnchoredLen <= shortest && w <= 96u; w += 32u) {
         ctx->anchor_a = ctx->anchor_b = w;
@@ -2208,7 +1858,6 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
       SWA_TRY(build_member_index(ctx, ctx->owner_world > 1 ? 0u : first, ctx->owner_world > 1 ? n : count));
       owned_ok = true;
     }
-    ctx->aux_complete = owned_ok && ctx->owner_world == 1 && (ctx->aux_members || !ctx->aux_needed);
     SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!owned_ok) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream)); }
@@ -2225,9 +1874,6 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     }
     SWA_HIP(ctx, hipGetLastError());
     swa_t1(ctx, 2);
-    // the anchored index itself is built by the first network call, for that call's query range (the streaming
-    // index, made for the whole database above, stays)
-    if (!ctx->stream_index) { ctx->anchor_ready = false; }
     if (ctx->anchor_usable) {
       SWA_TRY(launch_abundance_rank(ctx));
       SWA_HIP(ctx, hipGetLastError());
@@ -2386,8 +2032,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     // CSR by the streaming route (links sorted by source with the partition primitive) unless a flat list is wanted
     const bool csr_stream = d_edge_list == nullptr && stream_csr_enabled() && ctx->anchor_usable && !stats;
     if (ctx->anchor_usable && !stats) {
-      const bool stream = stream_enabled() && pairs_width_for(ctx) != 0 && lines_width_for(ctx) != 0;
-      if (stream && !(ctx->anchor_ready && ctx->stream_index)) {
+      if (!(ctx->anchor_ready && ctx->stream_index)) {
         // (the streaming index serves any query range; it is rebuilt when the owner changed)
         swa_t0(ctx, 7);
         SWA_TRY(launch_abundance_rank(ctx));
@@ -2403,16 +2048,6 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
           SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
           ctx->member_index = false;
           if (fl[3] != 0 || fl[4] != 0) { SWA_TRY(ensure_full_index(ctx)); }
-        }
-      } else if (!stream && (!ctx->anchor_ready || ctx->anchor_first != first || ctx->anchor_count != count)) {
-        swa_t0(ctx, 7);
-        SWA_TRY(build_anchor_index(ctx, first, count));
-        swa_t1(ctx, 7);
-        // another owner's groups after a lean build: the enumerating kernels, if any group needs them, read hashes
-        // and XOR streams that exist for the previous owner's members only
-        if (!ctx->full_index && !ctx->aux_complete && ctx->aux_needed) {
-          SWA_TRY(launch_seqhash(ctx, true));
-          ctx->aux_members = true;
         }
       }
       SWA_TRY(launch_network_anchored(ctx, no_cluster_breaking, first, count, !csr_stream));
@@ -2485,10 +2120,8 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     n_edges = got[0];
     if (ctx->anchor_usable && !stats && anchor_overflow != 0) {
-      // this rank owns more anchors than its share-sized key tables hold (skewed ownership):
-      // size them for the whole range, which cannot overflow, and run again
-      ctx->anchor_slack = 1;
-      if (ctx->stream_index) { ctx->stream_extra_bits = std::min<uint32_t>(ctx->stream_extra_bits + 2, 8); }   // (partition too coarse: finer)
+      // a bucket of the index rebuilt above held more distinct keys than the group kernel's table: partition finer, again
+      ctx->stream_extra_bits = std::min<uint32_t>(ctx->stream_extra_bits + 2, 8);
       ctx->anchor_ready = false;
       continue;
     }
@@ -2597,7 +2230,7 @@ extern "C" int swa_d1_index_build_routed(swa_ctx * ctx, const uint32_t * d_ids_p
   if (ctx->owner_world <= 1) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_routed: call swa_d1_set_ownership(rank, world > 1) first"); }
   if ((n_prefix != 0 && d_ids_prefix == nullptr) || (n_suffix != 0 && d_ids_suffix == nullptr)) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_routed: null list"); }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
-  SWA_TRY(ensure_db_properties(ctx));
+  SWA_TRY(ensure_db_lengths(ctx));
   static const uint32_t nothing = 0;                         // (an empty list still marks the build as routed)
   ctx->route_ids[0] = n_prefix != 0 ? d_ids_prefix : &nothing; ctx->route_m[0] = n_prefix;
   ctx->route_ids[1] = n_suffix != 0 ? d_ids_suffix : &nothing; ctx->route_m[1] = n_suffix;
@@ -2615,7 +2248,6 @@ extern "C" int swa_d1_set_ownership(swa_ctx * ctx, uint32_t rank, uint32_t world
     ctx->owner_world = world;
     ctx->csr_ready = false;
     ctx->anchor_ready = false;                               // the next network call indexes this rank's groups
-    ctx->anchor_slack = 0;
     ctx->member_index = false;                               // (the table of the previous owner's oversized groups is not this one's)
   }
   return SWA_OK;
@@ -2647,14 +2279,25 @@ extern "C" int swa_d1_debug_read(swa_ctx * ctx, int what, void * out, size_t out
   if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: no index"); }
   if (what >= 10) {
     // the streaming index as it lies in HBM (tools/check_stream.py validates it on the host): 10 + i: ids in group order of
-    // index i, u32[n] · 12 + i: its item buffer, swa_item[items_capacity(n)] · 14: the counters, u32[64] · 15: the amplicon lines
+    // index i, u32[n] · 12 + i: its item buffer, swa_item[regions' end] · 14: the counters, u32[kCounterWords] · 15: the amplicon lines,
+    // lines_quads x 16 bytes each · 16: u64[kWidthClasses][kListKinds + 1] first items of the lists (ListRegions) + [.][0] = line quads behind
     if (!ctx->stream_index) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: no streaming index in place"); }
     const void * from = nullptr;
     size_t need = 0;
     if (what == 10 || what == 11) { from = ctx->d_stream[kSbMembers + (what - 10)].ptr; need = uint64_t(ctx->db.n) * sizeof(uint32_t); }
-    else if (what == 12 || what == 13) { from = ctx->d_aitems[what - 12].ptr; need = items_capacity(ctx->db.n) * sizeof(swa_item); }
-    else if (what == 14) { from = ctx->d_acounters.ptr; need = 64 * sizeof(uint32_t); }
-    else if (what == 15) { from = ctx->d_stream[kSbLines].ptr; need = uint64_t(ctx->db.n) * (ctx->lines_w == 5 ? 64u : 128u); }
+    else if (what == 12 || what == 13) { from = ctx->d_aitems[what - 12].ptr; need = ctx->list_regions_items * sizeof(swa_item); }
+    else if (what == 14) { from = ctx->d_acounters.ptr; need = kCounterWords * sizeof(uint32_t); }
+    else if (what == 15) { from = ctx->d_stream[kSbLines].ptr; need = uint64_t(ctx->db.n) * ctx->lines_quads * 16u; }
+    else if (what == 16) {                                    // (host-side facts: where the lists lie, how wide a line is)
+      uint64_t total = 0;
+      const ListRegions r = list_regions(ctx, &total);
+      const size_t bytes = sizeof(r) + 2 * sizeof(uint64_t);
+      if (out_bytes < bytes) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_debug_read: buffer too small"); }
+      memcpy(out, &r, sizeof(r));
+      const uint64_t tail[2] = {total, ctx->lines_quads};
+      memcpy(static_cast<char *>(out) + sizeof(r), tail, sizeof(tail));
+      return SWA_OK;
+    }
     else { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_debug_read: unknown selector"); }
     if (out_bytes < need) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_debug_read: buffer too small"); }
     SWA_HIP(ctx, hipSetDevice(ctx->device));
@@ -2842,8 +2485,9 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
   // pairs on the amplicon lines, sequences in registers (up to 416 nt; SWA_FAST_PAIRS=words: the round-2 kernel, which
   // walks the packed sequences — comparison switch)
   const char * env_fp = getenv("SWA_FAST_PAIRS");
-  const int pair_w = (env_fp != nullptr && env_fp[0] == 'w') ? 0 : lines_width_for(ctx);
-  if (pair_w != 0 && !(ctx->lines_ready && ctx->lines_w == pair_w)) {
+  // (the register kernels exist for 5, 8 and 13 words: sequences up to 416 nt, which 128-byte lines hold)
+  const int pair_w = (env_fp != nullptr && env_fp[0] == 'w') ? 0 : (ctx->db.longest <= 160u ? 5 : (ctx->db.longest <= 256u ? 8 : (ctx->db.longest <= 416u ? 13 : 0)));
+  if (pair_w != 0) {
     SWA_TRY(launch_abundance_rank(ctx));
     SWA_TRY(ensure_lines(ctx));
   }
@@ -2881,6 +2525,7 @@ static int fastidious_pair_route(swa_ctx * ctx, uint32_t n_light, uint32_t n_hea
       p.pairs = static_cast<unsigned long long *>(ctx->d_fpairs.ptr); p.pair_counter = fc + 5; p.pair_cap = ctx->fast_pair_cap;
       const dim3 gp(ctx->num_cus * 8);
       p.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
+      p.line_quads = ctx->lines_quads;
       if (pair_w == 5) {
         if (type == 0) { hipLaunchKernelGGL((k_fast_pairs_lines<0, 5>), gp, dim3(kThreads), 0, ctx->stream, p); }
         else if (type == 1) { hipLaunchKernelGGL((k_fast_pairs_lines<1, 5>), gp, dim3(kThreads), 0, ctx->stream, p); }

@@ -71,9 +71,9 @@ struct swa_ctx {
   uint32_t route_m[2] = {0, 0};
   bool rank_ready = false;       // d_arank holds the abundance ranks of this database
   bool db_unordered = false;     // ... which is not in abundance order (the anchored passes are then not used)
-  bool props_ready = false;      // db_shortest / db_run32 below
+  bool props_ready = false;      // db_shortest / class_pop below
   uint32_t db_shortest = 0;      // shortest sequence
-  bool db_run32 = false;         // some sequence starts with 32 equal nucleotides
+  uint32_t class_pop[8] = {};    // sequences per width class (d1_anchor.inc: width_class; [kTooLong]: beyond the pair kernels)
   bool windows_ready = false;    // the anchor windows of this database are known (choose_anchor_windows + the safety net):
   uint32_t windows_chosen = 0;   // anchor_a = anchor_b = this
   bool pair_lists = false;       // the anchor indexes carry the work lists of the pair kernels (k_scan_apply_lists)
@@ -133,7 +133,8 @@ struct swa_ctx {
 
   // streaming index build / CSR assembly (d1_stream.inc)
   bool lines_ready = false;      // d_lines holds this database's amplicon lines (made once per upload), lines_w words each
-  int lines_w = 0;
+  uint32_t lines_quads = 0;      // ... of this many 16-byte quads each (4, 8 or 16)
+  uint64_t list_regions_items = 0;   // entries of an index's item buffer (d1.hip: list_regions)
   bool stream_index = false;     // the anchor indexes in place were made by the streaming build: members = ids in d_members
   uint32_t stream_extra_bits = 0;   // finer partition after a bucket held more distinct keys than the group kernel's table
   // [0] lines [1..4] records ping / pong per index [5, 6] fingerprints ping / pong [7] table slots of big buckets

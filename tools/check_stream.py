@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tools/check_stream.py [n=200000] — triage of the streaming index build / CSR assembly (d1_stream.inc) on the GPU:
-the d=1 network of one synthetic set under the four combinations of {streaming, table} index x {streaming, table}
-CSR, each compared with the C oracle's network (whole database and one sub-range), so that a difference names the
-stage that made it.  Exit status 0 = all identical."""
+the d=1 network of one synthetic set under the streaming index with the streaming and with the counting (table) CSR
+assembly, each compared with the C oracle's network (whole database and one sub-range), and the amplicon lines read
+back and compared with the database, so that a difference names the stage that made it.  Exit status 0 = all identical."""
 import os
 import sys
 import time
@@ -26,7 +26,7 @@ def main() -> None:
     for i in range(db.n):
         wnb[int(woff[i]):int(woff[i + 1])].sort()
     bad = 0
-    order = sys.argv[2].split(",") if len(sys.argv) > 2 else ["stream", "table"]
+    order = sys.argv[2].split(",") if len(sys.argv) > 2 else ["stream"]
     # group sizes of every amplicon's prefix / suffix window (for the diagnosis of missing links)
     off0 = db.seq_off[:-1].astype(np.int64)
     pre = db.seqs[off0]
@@ -41,23 +41,22 @@ def main() -> None:
     gpre, gsuf = gsize(pre), gsize(suf)
     for build in order:
         for csr in ("stream", "table"):
-            os.environ["SWA_D1_BUILD"] = build
             os.environ["SWA_D1_CSR"] = csr
             ctx = Context(0)
             ctx.upload_db(db.seqs, db.seq_off, db.seqlen, db.abundance, db.longest)
             t0 = time.perf_counter()
             dup = ctx.d1_index_build()
             if build == "stream":
-                # the amplicon lines against the database they were made from (64-byte lines: 5 words, length, rank)
+                # the amplicon lines against the database they were made from (64-byte lines: length | rank, then the words)
                 raw = np.zeros(db.n * 8, dtype=np.uint64)
                 ctx._check(ctx.lib.swa_d1_debug_read(ctx.h, 15, raw.ctypes.data, raw.nbytes))
                 L = raw.reshape(db.n, 8)
                 nw = (db.seqlen.astype(np.int64) + 31) >> 5
                 wrong = np.zeros(db.n, dtype=bool)
-                for k in range(5):
+                for k in range(7):
                     want = np.where(k < nw, np.concatenate([db.seqs, np.zeros(8, np.uint64)])[off0 + k], np.uint64(0))
-                    wrong |= L[:, k] != want
-                meta = L[:, 5]
+                    wrong |= L[:, 1 + k] != want
+                meta = L[:, 0]
                 rank_want = np.searchsorted(-db.abundance.astype(np.int64), -db.abundance.astype(np.int64), side="left")
                 wrong_len = (meta & np.uint64(0xFFFFFFFF)) != db.seqlen.astype(np.uint64)
                 wrong_rank = (meta >> np.uint64(32)) != rank_want.astype(np.uint64)

@@ -57,26 +57,25 @@ int main(int argc, char ** argv) {
   uint32_t aw[2] = {0, 0};
   (void)swa_d1_anchor_windows(ctx, aw);
   {
-    // (the streaming index only: the table build has no lines / id lists — those selectors fail and the fields stay 0)
-    std::vector<uint8_t> lines((size_t)n * 128);
-    const size_t line_bytes = v.longest <= 160 ? 64 : 128;
-    if (swa_d1_debug_read(ctx, 15, lines.data(), lines.size()) == SWA_OK) { h_lines = chain(lines.data(), (size_t)n * line_bytes); }
-    std::vector<uint32_t> counters(64);
-    const bool have_counters = swa_d1_debug_read(ctx, 14, counters.data(), counters.size() * 4) == SWA_OK;
+    // where the lists lie and how wide a line is (selector 16): u64 [4 width classes][7 size kinds + end], items in all, quads per line
+    uint64_t layout[4 * 8 + 2] = {};
+    const bool have_layout = swa_d1_debug_read(ctx, 16, layout, sizeof(layout)) == SWA_OK;
+    const size_t line_bytes = have_layout ? (size_t)layout[33] * 16 : 0;
+    std::vector<uint8_t> lines((size_t)n * line_bytes + 16);
+    if (have_layout && swa_d1_debug_read(ctx, 15, lines.data(), (size_t)n * line_bytes) == SWA_OK) { h_lines = chain(lines.data(), (size_t)n * line_bytes); }
+    std::vector<uint32_t> counters(256);
+    const bool have_counters = have_layout && swa_d1_debug_read(ctx, 14, counters.data(), counters.size() * 4) == SWA_OK;
     for (int which = 0; which < 2 && have_counters; ++which) {
       std::vector<uint32_t> members((size_t)n + 2);
       if (swa_d1_debug_read(ctx, 10 + which, members.data(), (size_t)n * 4) != SWA_OK) { continue; }
       for (uint32_t i = 0; i < n; ++i) { h_members[which] += mix(members[i] + 1ull); }
-      // the lists of the pair kernels (regions as d1.hip lays them out: pair_region)
-      static const uint32_t least[6] = {2, 5, 9, 17, 33, 65};
-      uint64_t region[7];
-      region[0] = (uint64_t)n / 8 + 32;
-      for (int c = 0; c < 6; ++c) { region[c + 1] = region[c] + (uint64_t)n / least[c] + 64; }
-      const uint64_t cap_items = std::max<uint64_t>((uint64_t)n + 128, region[6]);
-      std::vector<uint32_t> items(cap_items * 3);
-      if (swa_d1_debug_read(ctx, 12 + which, items.data(), items.size() * 4) != SWA_OK) { continue; }
-      for (int c = 0; c < 6; ++c) {
-        for (uint32_t k = 0; k < counters[32 + 8 * which + c]; ++k) { h_sizes[which] += mix(items[(region[c] + k) * 3 + 1] + 77ull); }
+      std::vector<uint32_t> items((size_t)layout[32] * 3 + 4);
+      if (swa_d1_debug_read(ctx, 12 + which, items.data(), (size_t)layout[32] * 12) != SWA_OK) { continue; }
+      for (int cls = 0; cls < 4; ++cls) {
+        for (int k = 0; k < 6; ++k) {
+          const uint32_t cnt = counters[64 + (which * 4 + cls) * 8 + k];
+          for (uint32_t j = 0; j < cnt; ++j) { h_sizes[which] += mix(items[(layout[cls * 8 + k] + j) * 3 + 1] + 77ull); }
+        }
       }
     }
   }

@@ -5,7 +5,7 @@ Starts tools/stress/first_step `runs` times — every one a fresh process, a fre
 kernel of the d=1 step — under the runtime conditions only a first run has, in turn:
     warm-up of the context on a helper thread beside the FASTA read (as the command line does) / none
     AMD_SERIALIZE_KERNEL=3 (every kernel waits for the one before and is waited for) / unset
-    streaming index build / table build (every 8th run: the independent route)
+    64-nt anchor windows (what this set gets) / 32-nt windows (every 8th run: other groups, the same network)
 and compares every stage's checksum (amplicon lines, member lists, group sizes, CSR) with the first run's and the CSR
 with the C oracle's network.  Writes gpurun_out/stress/summary.json; exit 1 if any run differed or failed."""
 import json
@@ -58,20 +58,21 @@ def main():
     reference = {}
     t0 = time.time()
     for r in range(runs):
-        warm, serial, table = r & 1, (r >> 1) & 1, (r % 8) == 7
+        warm, serial, narrow = r & 1, (r >> 1) & 1, (r % 8) == 7
         env = dict(os.environ, STRESS_WARMUP=str(warm))
         env.pop("AMD_SERIALIZE_KERNEL", None)
         if serial:
             env["AMD_SERIALIZE_KERNEL"] = "3"
-        if table:
-            env["SWA_D1_BUILD"] = "table"
+        env.pop("SWA_D1_ANCHOR_W", None)
+        if narrow:
+            env["SWA_D1_ANCHOR_W"] = "32"
         p = subprocess.run([exe, fa, f"{want:016x}"], capture_output=True, text=True, env=env, timeout=300)
         line = p.stdout.strip().splitlines()[0] if p.stdout.strip() else ""
         fields = dict(kv.split("=", 1) for kv in line.split() if "=" in kv)
-        cond = f"warm{warm}_serial{serial}_{'table' if table else 'stream'}"
+        cond = f"warm{warm}_serial{serial}_{'w32' if narrow else 'auto'}"
         rec = {"run": r, "cond": cond, "rc": p.returncode, "line": line}
         ok = p.returncode == 0
-        key = "table" if table else "stream"
+        key = "w32" if narrow else "auto"
         if ok:
             ref = reference.setdefault(key, fields)
             differing = [k for k in fields if fields[k] != ref.get(k)]
