@@ -806,7 +806,7 @@ def main() -> None:
             "roofline": roof,
         }
         extras = world == 1 and not sim_world and not args.no_extras
-        if world == 1 and not sim_world and not args.no_configs1 and not args.no_cpu_baseline:
+        if world == 1 and not sim_world and not args.no_configs1:
             # BASELINE.json configs[1] (1 M x 150, d=1): the same step at that size, same run
             out["config"]["configs1"] = extra_measurement(torch, dev, device_index, args, 1_000_000, 10)
         if world > 1 and not one_gpu and not args.no_extras:

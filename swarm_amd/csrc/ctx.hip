@@ -60,6 +60,17 @@ extern "C" int swa_ctx_create(int device, void * stream, swa_ctx ** out) {
     }
     ctx->own_stream = true;
   }
+  // the status block and the views into it (swa_internal.h)
+  if (swa_reserve(ctx, ctx->d_status, 4096) != SWA_OK || hipMemset(ctx->d_status.ptr, 0, 4096) != hipSuccess) {
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+    return SWA_E_NOMEM;
+  }
+  auto * base = static_cast<uint8_t *>(ctx->d_status.ptr);
+  ctx->d_flags.ptr = base;            ctx->d_flags.bytes = 64;
+  ctx->d_stats.ptr = base + 64;       ctx->d_stats.bytes = 128;
+  ctx->d_guard.ptr = base + 192;      ctx->d_guard.bytes = 192;
+  ctx->d_acounters.ptr = base + 1024; ctx->d_acounters.bytes = 1024;
   *out = ctx;
   return SWA_OK;
 }
@@ -92,17 +103,16 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (swa_dbuf * b : {&ctx->d_seqs, &ctx->d_seq_off, &ctx->d_seqlen, &ctx->d_abund, &ctx->d_zobrist,
-                       &ctx->d_seqhash, &ctx->d_table, &ctx->d_bloom, &ctx->d_patterns, &ctx->d_flags,
-                       &ctx->d_stats, &ctx->d_edges, &ctx->d_counts, &ctx->d_cursor, &ctx->d_scan_tmp,
+                       &ctx->d_seqhash, &ctx->d_table, &ctx->d_bloom, &ctx->d_patterns, &ctx->d_status,
+                       &ctx->d_edges, &ctx->d_counts, &ctx->d_cursor, &ctx->d_scan_tmp,
                        &ctx->d_offsets_tmp, &ctx->d_nb_tmp, &ctx->d_qgrams, &ctx->d_list_a, &ctx->d_list_b,
                        &ctx->d_list_c, &ctx->d_list_d, &ctx->d_light, &ctx->d_graft, &ctx->d_bloomflex,
                        &ctx->d_fpatterns, &ctx->d_queue, &ctx->d_fcounters, &ctx->d_scan_est, &ctx->d_scan_swarmed,
-                       &ctx->d_scan_targets, &ctx->d_scan_diffs, &ctx->d_scan_hits, &ctx->d_scan_counters, &ctx->d_scan_cand, &ctx->d_scan_seeds, &ctx->d_scan_compares, &ctx->d_aux, &ctx->d_acounters,
-                       &ctx->d_afallback, &ctx->d_arank, &ctx->d_rank_tmp, &ctx->d_wfa, &ctx->d_long_rows, &ctx->d_seg_fill, &ctx->d_seg_base, &ctx->d_akeys[0], &ctx->d_akeys[1], &ctx->d_acounts[0], &ctx->d_acounts[1],
-                       &ctx->d_aoffsets[0], &ctx->d_aoffsets[1], &ctx->d_aslot[0],
-                       &ctx->d_aslot[1], &ctx->d_aitems[0], &ctx->d_aitems[1], &ctx->d_ainfo[0], &ctx->d_ainfo[1], &ctx->d_apos[0], &ctx->d_apos[1], &ctx->d_afp[0], &ctx->d_afp[1],
+                       &ctx->d_scan_targets, &ctx->d_scan_diffs, &ctx->d_scan_hits, &ctx->d_scan_counters, &ctx->d_scan_cand, &ctx->d_scan_seeds, &ctx->d_scan_compares, &ctx->d_aux,
+                       &ctx->d_afallback, &ctx->d_arank, &ctx->d_rank_tmp, &ctx->d_wfa, &ctx->d_long_rows, &ctx->d_seg_fill, &ctx->d_seg_base, &ctx->d_akeys[0], &ctx->d_acounts[0],
+                       &ctx->d_aitems[0], &ctx->d_aitems[1],
                        &ctx->d_frole, &ctx->d_fkeys, &ctx->d_fcnt, &ctx->d_foff, &ctx->d_fslot, &ctx->d_fmembers, &ctx->d_fitems,
-                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster, &ctx->d_guard}) {
+                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster}) {
     swa_release(*b);
   }
   for (auto & b : ctx->d_stream) { swa_release(b); }
@@ -161,9 +171,7 @@ static int check_view(swa_ctx * ctx, const swa_db_view * v) {
 static void invalidate(swa_ctx * ctx) {
   ctx->d1_ready = false;
   ctx->full_index = false;
-  ctx->aux_complete = false;
   ctx->anchor_ready = false;
-  ctx->anchor_slack = 0;
   ctx->rank_ready = false;
   ctx->db_unordered = false;
   ctx->props_ready = false;

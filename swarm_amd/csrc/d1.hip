@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
                                                  const uint32_t * __restrict__ seqlen,
                                                  const uint64_t * __restrict__ zobrist, uint32_t zlen,
                                                  uint32_t n, uint64_t * __restrict__ seqhash,
-                                                 swa_aux * __restrict__ aux, uint32_t anchor_w) {
+                                                 swa_aux * __restrict__ aux, uint32_t anchor_w, const uint8_t * __restrict__ only) {
   extern __shared__ uint64_t lds[];
   const uint64_t * zob = zobrist;
   if (ZLDS) {
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void k_seqhash(const uint64_t * __restrict__ s
     zob = lds;
   }
   for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+    if (only != nullptr && only[a] == 0) { continue; }         // (the member table of the groups left to the plain kernel: only those)
     const uint64_t * s = seqs + seq_off[a];
     const uint32_t len = seqlen[a];
     uint64_t h = 0, dall = 0, iall = 0;
@@ -980,7 +981,8 @@ struct PartJob {
   const uint32_t * in_f[kMaxIdx] = {};
   unsigned long long * buf[kMaxIdx][2] = {};
   uint32_t * buf_f[kMaxIdx][2] = {};
-  const uint64_t * cstart0[kMaxIdx] = {};           // level-0 chunks
+  const uint64_t * cstart0[kMaxIdx] = {};           // level-0 chunks (nullptr: regular, PartIdx::cstride)
+  uint64_t cstride0[kMaxIdx] = {};
   const uint32_t * csize0[kMaxIdx] = {};
   uint32_t csize_cap = 0, chunks0 = 1;
   bool single0 = true;
@@ -1060,6 +1062,7 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
       p.out32 = last_level ? j.out32[i] : nullptr;
       p.out_cap = j.out_cap;
       p.cstart = l == 0 ? j.cstart0[i] : j.starts[i] + ((l - 1) & 1u) * j.starts_stride;
+      p.cstride = l == 0 ? j.cstride0[i] : 0;
       p.csize = l == 0 ? j.csize0[i] : nullptr;
       p.csize_cap = j.csize_cap;
       p.chunks = (uint32_t)chunks;
@@ -1099,11 +1102,6 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
   return SWA_OK;
 }
 
-__global__ void k_set_u64x2(uint64_t * p0, uint64_t a0, uint64_t b0, uint64_t * p1, uint64_t a1, uint64_t b1) {
-  p0[0] = a0; p0[1] = b0;
-  if (p1 != nullptr) { p1[0] = a1; p1[1] = b1; }
-}
-
 // the amplicon lines of the uploaded database (once per upload; needs the abundance ranks)
 static int ensure_lines(swa_ctx * ctx) {
   const uint32_t lq = line_quads_for(ctx);
@@ -1131,6 +1129,7 @@ static int ensure_lines(swa_ctx * ctx) {
 static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_count) {
   ctx->anchor_ready = false;
   ctx->stream_index = false;
+  ctx->list_counts_ready = false;
   const uint32_t n = ctx->db.n;
   SWA_TRY(ensure_db_lengths(ctx));
   SWA_TRY(ensure_lines(ctx));
@@ -1226,8 +1225,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     const dim3 kgrid((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u);
     hipLaunchKernelGGL(k_keys<false>, kgrid, dim3(256), 0, ctx->stream, k);
   }
-  hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, ctx->stream, scal, (uint64_t)0, (uint64_t)(routed ? ctx->route_m[0] : n), scal + 2, (uint64_t)0,
-                     (uint64_t)(routed ? ctx->route_m[1] : n));
   swa_t1(ctx, 8);
 
   // ---- partition by the top bits of the key
@@ -1235,7 +1232,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     j.buf[i][0] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i].ptr);
     j.buf[i][1] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i + 1].ptr);
     j.in[i] = j.buf[i][1];
-    j.cstart0[i] = scal + 2 * i;
+    j.cstart0[i] = nullptr; j.cstride0[i] = routed ? ctx->route_m[i] : n;   // (one chunk: [0, records of this index))
     j.cnt[i] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt + i].ptr);
     j.ctile[i] = static_cast<uint32_t *>(ctx->d_stream[kSbTile + i].ptr);
     j.starts[i] = static_cast<uint64_t *>(ctx->d_stream[kSbStart + i].ptr);
@@ -1284,6 +1281,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
   if (const char * env_cap = getenv("SWA_D1_GROUP_CAP")) { g.group_cap = std::max<uint32_t>(g.pair_big, (uint32_t)atoi(env_cap)); }   // (experiments)
   g.flags = dflags;
+  if (const char * e = getenv("SWA_D1_NO_DUP")) { g.no_dups = e[0] == '1' ? 1u : 0u; }   // (experiment)
   g.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
   g.over = static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr);
   g.dup_first = dup_first; g.dup_count = dup_count;
@@ -1321,9 +1319,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   swa_t1(ctx, 10);
   SWA_HIP(ctx, hipGetLastError());
   ctx->list_regions_items = item_room;
-  ctx->anchor_first = 0;
-  ctx->anchor_count = n;
-  ctx->anchor_slots = 0;
   ctx->anchor_ready = true;
   ctx->stream_index = true;
   ctx->guard_index = true;
@@ -1341,7 +1336,7 @@ static bool stream_csr_enabled() {
 
 // (the chunks of the first level: `chunks` runs of links, run c = links[cstart[c] .. + min(csize[c], csize_cap)) — the per-wave
 // segments of the pair kernels, or the ranks' lists of a multi-GPU job gathered on one device)
-static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const unsigned long long * links, const uint64_t * d_cstart,
+static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const unsigned long long * links, const uint64_t * d_cstart, uint64_t cstride,
                            const uint32_t * d_csize, uint32_t chunks, uint32_t csize_cap, uint64_t max_tiles0, uint64_t link_cap,
                            uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap) {
   uint32_t nbits = 1;
@@ -1369,13 +1364,14 @@ static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const 
   j.in[0] = links;
   j.buf[0][0] = static_cast<unsigned long long *>(ctx->d_stream[kSbLinkA].ptr);
   j.buf[0][1] = static_cast<unsigned long long *>(ctx->d_stream[kSbLinkB].ptr);
-  j.cstart0[0] = d_cstart;
+  j.cstart0[0] = d_cstart; j.cstride0[0] = cstride;
   j.csize0[0] = d_csize;
   j.cnt[0] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt].ptr);
   j.ctile[0] = static_cast<uint32_t *>(ctx->d_stream[kSbTile].ptr);
   j.starts[0] = static_cast<uint64_t *>(ctx->d_stream[kSbStart].ptr);
   j.partial[0] = static_cast<uint32_t *>(ctx->d_stream[kSbPartial].ptr);
-  j.total[0] = reinterpret_cast<uint32_t *>(static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr) + 12);
+  auto * extra = static_cast<uint64_t *>(ctx->d_status.ptr) + 48;   // (status block, bytes [384, 512): [0] last CSR offset [1] links sorted)
+  j.total[0] = reinterpret_cast<uint32_t *>(extra + 1);
   j.starts_stride = e_start + 2;
   swa_t0(ctx, 13);
   SWA_TRY(run_partition(ctx, j));
@@ -1386,6 +1382,7 @@ static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const 
   SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbHeavy], ((uint64_t)j.buckets + 2) * sizeof(uint32_t)));
   c.heavy = static_cast<uint32_t *>(ctx->d_stream[kSbHeavy].ptr) + 1;
   c.heavy_count = static_cast<uint32_t *>(ctx->d_stream[kSbHeavy].ptr);
+  c.end_copy = extra;
   SWA_HIP(ctx, hipMemsetAsync(c.heavy_count, 0, sizeof(uint32_t), ctx->stream));
   swa_t0(ctx, 14);
   const dim3 cgrid((unsigned)std::min<uint64_t>(((uint64_t)j.buckets + 3) / 4, (uint64_t)ctx->num_cus * 8));
@@ -1399,11 +1396,8 @@ static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const 
 
 static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t nseg, uint64_t link_cap, uint64_t * d_offsets,
                              uint32_t * d_neighbours, uint64_t cap) {
-  SWA_TRY(swa_reserve(ctx, ctx->d_seg_base, uint64_t(nseg) * sizeof(uint64_t)));
-  auto * seg_starts = static_cast<uint64_t *>(ctx->d_seg_base.ptr);
-  hipLaunchKernelGGL(k_seg_starts, dim3((nseg + 255) / 256), dim3(256), 0, ctx->stream, seg_starts, nseg, ctx->seg_cap);
   const uint64_t tiles_per_seg = (ctx->seg_cap + 4096 - 1) / 4096;
-  return csr_from_chunks(ctx, first, count, static_cast<const unsigned long long *>(ctx->d_edges.ptr), seg_starts,
+  return csr_from_chunks(ctx, first, count, static_cast<const unsigned long long *>(ctx->d_edges.ptr), nullptr, ctx->seg_cap,
                          static_cast<const uint32_t *>(ctx->d_seg_fill.ptr), nseg, (uint32_t)std::min<uint64_t>(ctx->seg_cap, 0xFFFFFFFFu),
                          (uint64_t)nseg * tiles_per_seg + 2, link_cap, d_offsets, d_neighbours, cap);
 }
@@ -1466,6 +1460,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   clear_add(clears, static_cast<uint64_t *>(ctx->d_guard.ptr) + 8, 8 * sizeof(uint64_t));   // the guard's counters of this network call
   if (count_links) { clear_add(clears, ctx->d_counts.ptr, uint64_t(count) * sizeof(uint32_t)); }
   clear_add(clears, acounters, kCounterBase * sizeof(uint32_t));
+  clear_add(clears, ctx->d_seg_fill.ptr, 3ull * seg_count(ctx) * sizeof(uint32_t));   // segment fills | members staged, per pass
   // work counters of k_d1_group_pairs (per pass and class): 2^shard_bits of them, sched_stride entries apart
   uint32_t pair_batch = 4, shard_bits = 6, sched_stride = 64;
   if (const char * e = getenv("SWA_D1_PAIR_BATCH")) { pair_batch = (uint32_t)std::max(1, atoi(e)); }                           // (experiments)
@@ -1523,9 +1518,13 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
       a.sched_big = acounters + 8 + 2 * pc;
       a.sched_tiled = acounters + 9 + 2 * pc;
       a.sched_wide = static_cast<uint32_t *>(ctx->d_stream[kSbSched].ptr) + ((uint64_t)pc << shard_bits) * sched_stride;
-      // (the pair kernel hands its work out through counters: exactly the workgroups that are resident together, no second round)
-      SWA_TRY(launch_group_pairs(ctx, pass, width, nwin, ctx->num_cus * pair_blocks_per_cu(cls), a));
-      SWA_TRY(launch_pairs_tiled(ctx, pass, width, nwin, ctx->num_cus * (cls <= 1u ? 8 : 4), a));
+      // (the pair kernel hands its work out through counters: exactly the workgroups that are resident together, no second round;
+      // no launch over lists the index build found empty)
+      const uint32_t * have = ctx->list_counts_ready ? ctx->list_counts + pc * 8u : nullptr;
+      bool any_pairs = have == nullptr;
+      for (uint32_t k = 0; k <= kPairClasses && have != nullptr; ++k) { any_pairs = any_pairs || have[k] != 0u; }
+      if (any_pairs) { SWA_TRY(launch_group_pairs(ctx, pass, width, nwin, ctx->num_cus * pair_blocks_per_cu(cls), a)); }
+      if (have == nullptr || have[kPairClasses + 1u] != 0u) { SWA_TRY(launch_pairs_tiled(ctx, pass, width, nwin, ctx->num_cus * (cls <= 1u ? 8 : 4), a)); }
     }
     swa_t1(ctx, 11 + pass);
     SWA_HIP(ctx, hipGetLastError());
@@ -1592,7 +1591,7 @@ static int prepare_hashing(swa_ctx * ctx) {
 }
 
 // sequence hashes + the XOR streams the plain kernel's restricted enumeration reads (swa_aux)
-static int launch_seqhash(swa_ctx * ctx) {
+static int launch_seqhash(swa_ctx * ctx, const uint8_t * only = nullptr) {
   const uint32_t n = ctx->db.n;
   const size_t zbytes = 4ull * ctx->zobrist_len * sizeof(uint64_t);
   const bool zlds = zbytes <= kMaxZobristLds;
@@ -1601,11 +1600,11 @@ static int launch_seqhash(swa_ctx * ctx) {
   if (zlds) {
     hipLaunchKernelGGL(k_seqhash<true>, dim3(hgrid), dim3(256), zbytes, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                        ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), ctx->anchor_w);
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), ctx->anchor_w, only);
   } else {
     hipLaunchKernelGGL(k_seqhash<false>, dim3(hgrid), dim3(256), 0, ctx->stream, ctx->db.seqs, ctx->db.seq_off,
                        ctx->db.seqlen, static_cast<const uint64_t *>(ctx->d_zobrist.ptr), ctx->zobrist_len, n,
-                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), ctx->anchor_w);
+                       static_cast<uint64_t *>(ctx->d_seqhash.ptr), static_cast<swa_aux *>(ctx->d_aux.ptr), ctx->anchor_w, only);
   }
   SWA_HIP(ctx, hipGetLastError());
   swa_t1(ctx, 0);
@@ -1711,7 +1710,9 @@ static bool member_index_enabled() {
 static int build_member_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_count) {
   ctx->member_index = false;
   const uint32_t n = ctx->db.n;
-  SWA_TRY(swa_hash_sequences(ctx));                          // Zobrist hashes + the XOR streams of every amplicon (k_seqhash)
+  // Zobrist hashes + the XOR streams of the members (k_seqhash: nobody else is inserted, probed for or enumerated)
+  SWA_TRY(prepare_hashing(ctx));
+  SWA_TRY(launch_seqhash(ctx, static_cast<const uint8_t *>(ctx->d_stream[kSbOver].ptr)));
   uint64_t slots = 1024;
   while (slots < 2ull * ctx->over_mass) { slots <<= 1; }
   const uint64_t words = std::max<uint64_t>(slots >> 3, 1);  // one byte of filter per slot, as the reference sizes it
@@ -1759,9 +1760,14 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   swa_t1(ctx, 7);
   // [0] duplicates [1] order broken [2] a bucket's groups do not fit the table [3] a sequence too short for two windows
   // [4] groups left to the plain kernel (oversized / a member too long) [5] their members [6] 0xFFFFFFFF - shortest sequence
-  uint32_t flags[8] = {};
-  SWA_HIP(ctx, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+  // (ONE copy of the status block: the flags, and how long the work lists are — the network call then launches no kernel
+  // over an empty one)
+  uint32_t status[512] = {};
+  SWA_HIP(ctx, hipMemcpyAsync(status, ctx->d_status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t * flags = status;
+  memcpy(ctx->list_counts, status + 256 + kCounterBase, sizeof(ctx->list_counts));
+  ctx->list_counts_ready = true;
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
   if (shortest != nullptr) { *shortest = 0xFFFFFFFFu - flags[6]; }
   if (flags[2] != 0) {                                      // a bucket with more distinct keys than the group kernel's table: finer
@@ -1806,8 +1812,8 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_stats, 16 * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_guard, 24 * sizeof(uint64_t)));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
-  SWA_HIP(ctx, hipMemsetAsync(ctx->d_guard.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
+  // (flags, stats and the guard's index / network counters lie together in the status block: one fill)
+  SWA_HIP(ctx, hipMemsetAsync(ctx->d_status.ptr, 0, 64 + 128 + 16 * sizeof(uint64_t), ctx->stream));
   ctx->guard_index = false;
   ctx->anchor_w = 32;
   ctx->anchor_usable = anchor_applicable(ctx);
@@ -2028,7 +2034,8 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
   bool clean = false;                                        // the last attempt ran to the end without a retry condition
   for (int attempt = 0; attempt < 8 && !clean; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
-    SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, 3ull * nseg * sizeof(uint32_t), ctx->stream));
+    // (the segment fills start at zero: the anchored route clears them with its other counters — one launch —, the plain one here)
+    if (!(ctx->anchor_usable && !stats)) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_seg_fill.ptr, 0, 3ull * nseg * sizeof(uint32_t), ctx->stream)); }
     // CSR by the streaming route (links sorted by source with the partition primitive) unless a flat list is wanted
     const bool csr_stream = d_edge_list == nullptr && stream_csr_enabled() && ctx->anchor_usable && !stats;
     if (ctx->anchor_usable && !stats) {
@@ -2058,18 +2065,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     }
     hipLaunchKernelGGL(k_seg_reduce, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seg_fill.ptr),
                        nseg, static_cast<unsigned long long *>(ctx->d_stats.ptr) + 8);
-    uint64_t got[4] = {0, 0, 0, 0};                           // links, fullest segment, members staged by pass
-    uint32_t anchor_overflow = 0;
-    SWA_HIP(ctx, hipMemcpyAsync(got, static_cast<uint64_t *>(ctx->d_stats.ptr) + 8, sizeof(got), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    SWA_HIP(ctx, hipMemcpyAsync(&anchor_overflow, static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, sizeof(uint32_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    uint32_t unserved = 0;                                   // fallback seeds listed while there is no table to serve them
     const bool check_unserved = ctx->anchor_usable && !stats && !ctx->full_index && !ctx->member_index;
-    if (check_unserved) {
-      SWA_HIP(ctx, hipMemcpyAsync(&unserved, static_cast<uint32_t *>(ctx->d_acounters.ptr) + 2, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, ctx->stream));
-    }
     // CSR assembly is enqueued right behind, before the host looks at the totals: every kernel
     // below guards its writes with `cap` / the segment capacity, so a run that turns out to
     // need bigger segments or a bigger neighbour buffer has only wasted these launches.
@@ -2106,18 +2102,21 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     }
     SWA_HIP(ctx, hipGetLastError());
     swa_t1(ctx, 4);
-    uint64_t guard[24] = {};
-    uint64_t csr_end = 0;
-    uint32_t links_sorted = 0;
-    const bool guarded = ctx->anchor_usable && !stats;
-    if (guarded) {
-      SWA_HIP(ctx, hipMemcpyAsync(guard, ctx->d_guard.ptr, sizeof(guard), hipMemcpyDeviceToHost, ctx->stream));
-      if (csr_stream) {
-        SWA_HIP(ctx, hipMemcpyAsync(&csr_end, d_offsets + count, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        SWA_HIP(ctx, hipMemcpyAsync(&links_sorted, static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr) + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-      }
+    // ONE copy of the status block's first 512 bytes: flags | stats (links, fullest segment, members staged) | the guard's
+    // counters | last CSR offset, links sorted
+    uint64_t status[64] = {};
+    SWA_HIP(ctx, hipMemcpyAsync(status, ctx->d_status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t unserved = 0;                                   // fallback seeds listed while there is no table to serve them
+    if (check_unserved) {
+      SWA_HIP(ctx, hipMemcpyAsync(&unserved, static_cast<uint32_t *>(ctx->d_acounters.ptr) + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t * got = status + 8 + 8;                    // d_stats[8 ..]: links, fullest segment, members staged by pass
+    const uint64_t * guard = status + 24;
+    const uint32_t anchor_overflow = reinterpret_cast<const uint32_t *>(status)[2];
+    const uint64_t csr_end = status[48];
+    const uint32_t links_sorted = (uint32_t)status[49];
+    const bool guarded = ctx->anchor_usable && !stats;
     n_edges = got[0];
     if (ctx->anchor_usable && !stats && anchor_overflow != 0) {
       // a bucket of the index rebuilt above held more distinct keys than the group kernel's table: partition finer, again
@@ -2196,7 +2195,7 @@ int swa_d1_csr_from_lists(swa_ctx * ctx, const unsigned long long * d_links, con
   SWA_HIP(ctx, hipMemcpyAsync(d_start, h_start.data(), lists * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   SWA_HIP(ctx, hipMemcpyAsync(d_size, h_size.data(), lists * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the host vectors are temporaries)
-  return csr_from_chunks(ctx, 0, n, d_links, d_start, d_size, lists, 0xFFFFFFFFu, tiles, all + 1, d_offsets, d_neighbours, cap);
+  return csr_from_chunks(ctx, 0, n, d_links, d_start, 0, d_size, lists, 0xFFFFFFFFu, tiles, all + 1, d_offsets, d_neighbours, cap);
 }
 
 extern "C" int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint32_t * d_ids, uint64_t cap,

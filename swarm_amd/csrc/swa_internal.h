@@ -54,17 +54,20 @@ struct swa_ctx {
   uint32_t zobrist_resident = 0; // length of the table currently in d_zobrist (0 = none)
   bool patterns_resident = false;
   swa_dbuf d_zobrist, d_seqhash, d_table, d_bloom, d_patterns;
+  // One 4 KB block holds every small status array of the context, so that the host reads them with ONE copy per phase (a
+  // device-to-host copy of a few bytes is a kernel of its own, ~5 us with its gap: the step made nine):
+  //   [0, 64) d_flags · [64, 192) d_stats · [192, 384) d_guard · [384, 512) d_extra: [0] last CSR offset [1] links the
+  //   partition sorted · [1024, 2048) d_acounters.  d_flags / d_stats / d_guard / d_acounters are VIEWS into it (never freed
+  //   on their own; their `bytes` is their room, so swa_reserve leaves them alone).
+  swa_dbuf d_status;
   swa_dbuf d_flags;              // u32[16]: [0] duplicate flag
   swa_dbuf d_stats;              // u64[8] probe statistics + [8] edge counter
   swa_dbuf d_edges;              // u64 edge list (src << 32 | dst)
   swa_dbuf d_counts, d_cursor, d_scan_tmp, d_offsets_tmp, d_nb_tmp, d_long_rows;
-  // anchored d=1 index (d1_anchor.inc): [0] prefix groups, [1] suffix groups
+  // anchored d=1 index (d1_anchor.inc, d1_stream.inc): [0] prefix groups, [1] suffix groups
   bool anchor_usable = false;    // decided by swa_d1_index_build: lengths fit, db order holds, not switched off
-  bool anchor_ready = false;     // the index below exists, built for [anchor_first, anchor_first + anchor_count)
-  uint32_t anchor_first = 0, anchor_count = 0;
-  uint64_t anchor_slots = 0;
+  bool anchor_ready = false;     // the streaming index below exists (for the owner in owner_rank / owner_world)
   bool full_index = false;       // d_seqhash / d_aux cover ALL amplicons and d_table / d_bloom are built (ensure_full_index)
-  bool aux_members = false;      // d_seqhash / d_aux hold the members of the anchor indexes (lean build that needed them)
   // routed build (swa_d1_index_build_routed): the members of this rank's groups arrive as id lists; and what is a fact
   // of the uploaded database rather than of one index build, kept until the next upload
   const uint32_t * route_ids[2] = {nullptr, nullptr};
@@ -76,11 +79,7 @@ struct swa_ctx {
   uint32_t class_pop[8] = {};    // sequences per width class (d1_anchor.inc: width_class; [kTooLong]: beyond the pair kernels)
   bool windows_ready = false;    // the anchor windows of this database are known (choose_anchor_windows + the safety net):
   uint32_t windows_chosen = 0;   // anchor_a = anchor_b = this
-  bool pair_lists = false;       // the anchor indexes carry the work lists of the pair kernels (k_scan_apply_lists)
-  bool aux_needed = true;        // some anchor group is served by the enumerating kernels (they read d_seqhash / d_aux)
-  bool aux_complete = false;     // d_seqhash / d_aux cover every amplicon that has an anchor (lean build with world = 1)
   uint32_t owner_rank = 0, owner_world = 1;   // swa_d1_set_ownership: this context serves the anchor groups of one rank
-  uint32_t anchor_slack = 0;     // 1 after a share-sized anchor table overflowed: size for the whole range
   uint32_t anchor_a = 0, anchor_b = 0;   // anchor windows moved inwards by this many nt ("window mode", chosen at index build)
   uint32_t anchor_w = 32;        // width of the anchor windows in nt: 32, 64 or 128 (wider: fewer pairs per group; needs 2 w + 1 nt)
   uint32_t windows_w = 32;       // ... as chosen for this database (with windows_chosen)
@@ -88,9 +87,8 @@ struct swa_ctx {
   bool guard_index = false;      // [0..8) describe the index in place (made by the streaming build since the last clear)
   bool guard_keys_done = false;  // the key records of this upload have had their second opinion (k_guard_db / k_guard_records)
   bool guard_keys_pending = false;   // ... its sums, [16..22), wait for the next guard_check
-  // d_acounts: the slot tables (tag | group size); d_akeys[0]: scratch of the window sample; d_ainfo: member records in
-  // group order; d_apos: position inside the group; d_afp: sequence fingerprints per amplicon / in group order
-  swa_dbuf d_aux, d_akeys[2], d_acounts[2], d_aoffsets[2], d_aslot[2], d_aitems[2], d_ainfo[2], d_apos[2], d_afp[2];
+  // d_akeys[0] / d_acounts[0]: scratch of the window sample; d_aitems: the work lists of the two indexes
+  swa_dbuf d_aux, d_akeys[1], d_acounts[1], d_aitems[2];
   swa_dbuf d_acounters, d_afallback, d_arank, d_rank_tmp;
   swa_dbuf d_seg_fill;           // u32 fill of every per-wave edge segment
   swa_dbuf d_seg_base;           // u64 start of every segment in the compacted edge list (swa_d1_network_edges_device)
@@ -134,6 +132,8 @@ struct swa_ctx {
   // streaming index build / CSR assembly (d1_stream.inc)
   bool lines_ready = false;      // d_lines holds this database's amplicon lines (made once per upload), lines_w words each
   uint32_t lines_quads = 0;      // ... of this many 16-byte quads each (4, 8 or 16)
+  uint32_t list_counts[2 * 4 * 8] = {};   // items per work list of the index in place ([index][width class][8]: d_acounters + kCounterBase)
+  bool list_counts_ready = false;
   uint64_t list_regions_items = 0;   // entries of an index's item buffer (d1.hip: list_regions)
   bool stream_index = false;     // the anchor indexes in place were made by the streaming build: members = ids in d_members
   uint32_t stream_extra_bits = 0;   // finer partition after a bucket held more distinct keys than the group kernel's table
