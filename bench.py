@@ -629,7 +629,7 @@ def main() -> None:
     else:
         q_first, q_count = first, count
     cap = 8 * count
-    if owned and world > 1:
+    if owned and (world > 1 or sim_world):
         d_links = torch.zeros(cap, dtype=torch.int64, device=dev)   # flat list: source << 32 | target
     else:
         d_offsets = torch.zeros(q_count + 1, dtype=torch.int64, device=dev)
@@ -677,7 +677,8 @@ def main() -> None:
             dist.all_reduce(dup_flag, op=dist.ReduceOp.MAX)
             dup = bool(dup_flag.item())
         assert not dup
-        if owned and world > 1:
+        if owned and (world > 1 or sim_world):
+            # (a rank of an ownership-sharded job hands its links on as a flat list: no CSR over every source of the job)
             total = ctx.d1_network_edges_device(d_links, cap, False, q_first, q_count)
         else:
             total = ctx.d1_network_device(d_offsets, d_nb, cap, False, q_first, q_count)
@@ -753,7 +754,7 @@ def main() -> None:
                 kernels[g] = {"ms": ms, "algorithmic_bytes": model[g], "GB/s": model[g] / (ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": model[g] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         dominant = max(kernels, key=lambda g: kernels[g]["ms"]) if kernels else None
-        names = {"keys": "k_keys", "partition_keys": "k_part_hist / k_flat_* / k_part_scatter over the key records", "groups": "k_group + k_group_lists",
+        names = {"keys": "k_keys", "partition_keys": "k_part_hist / k_flat_* / k_part_scatter over the key records", "groups": "k_group1 + k_group_lists",
                  "partition_links": "k_part_hist / k_flat_* / k_part_scatter over the links",
                  "pairs0": "k_d1_group_pairs<0> (prefix groups)", "pairs1": "k_d1_group_pairs<1> (suffix groups)", "csr_rows": "k_csr_bucket"}
         if streaming and dominant is not None:
