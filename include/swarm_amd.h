@@ -107,7 +107,7 @@ int swa_db_attach(swa_ctx * ctx, const swa_db_view * device_db);
 /* The index the network calls work on — what the reference's hash_insert loop builds (src/algod1.cc:188-208,
    1122-1150) — and its duplicate check: *has_duplicates != 0 (and SWA_E_DUPLICATES returned) when two amplicons have
    identical sequences.  What is built depends on the database: sequences of 65..256 nt in abundance order get the two
-   anchor indexes of the streaming build (amplicons grouped by their first / last 32 nt; members, work lists and the
+   anchor indexes of the streaming build (amplicons grouped by their first / last w nt, w = 32, 64 or 128: swa_d1_anchor_width; members, work lists and the
    identical-sequence check in one pass over the amplicon lines: swarm_amd/csrc/d1_stream.inc) and nothing else; the
    database-wide structures of the reference — Zobrist table (bit-identical, src/zobrist.cc:49-80), seqhash[]
    (src/db.cc:761), amplicon hash table + Bloom filter (src/hashtable.cc, src/bloompat.cc) — are built only for what
@@ -120,7 +120,7 @@ int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates);
    cheaply than every rank checking everything.  Returns SWA_E_DUPLICATES like the above. */
 int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates);
 /* Where the last index build put the two anchor windows that group the amplicons: out2 = {nt from the start, nt from
-   the end}; (0, 0) = the first / last 32 nt, moved inwards when those are (nearly) the same for everybody. */
+   the end}; (0, 0) = the first / last w nt, moved inwards (32-nt windows then) when those are (nearly) the same for everybody. */
 int swa_d1_anchor_windows(const swa_ctx * ctx, uint32_t * out2);
 /* ... and how wide it made them, in nucleotides: 32, 64 or 128 — the widest that leaves the shortest sequence of the
    database two windows and a nucleotide.  Two sequences of at least 2 w + 1 nt one edit apart share their first w or
@@ -128,7 +128,7 @@ int swa_d1_anchor_windows(const swa_ctx * ctx, uint32_t * out2);
 uint32_t swa_d1_anchor_width(const swa_ctx * ctx);
 /* Multi-GPU by ownership (no reference counterpart: src/algod1.cc:641-669 splits the seeds over
    threads that share one table).  With world > 1 this context serves only its share of the
-   probes: the anchor groups (amplicons sharing their first / last 32 nucleotides) whose key maps
+   probes: the anchor groups (amplicons sharing their first / last w nucleotides) whose key maps
    to `rank` — with ALL their members, so the groups' LDS tables are built once per job instead
    of once per rank —, its share of the seeds only the plain kernel can serve, and, when the
    anchored route is not in use, the seeds with id mod world == rank.  swa_d1_network[_device]

@@ -12,6 +12,7 @@
 #include "out.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -108,17 +109,28 @@ static int cluster_over_graph(swa_ctx * ctx, swa_multi * multi, const swa_hostdb
 // its seed reaches, a member's generation = its distance from the seed, its parent = the smallest id of the previous
 // generation that points at it — cluster_gpu.hip), and only five arrays of n entries come back instead of the graph.
 // Radii and the -i lines (acceptance order: sub-seeds in queue order, each one's hits by id) follow from the parents.
+// SWARM_AMD_TIMING=1: milliseconds since the first stamp of the clustering phase at every milestone, on stderr
+static void dn_stamp(const char * what) {
+  static const bool on = std::getenv("SWARM_AMD_TIMING") != nullptr;
+  static const auto t0 = std::chrono::steady_clock::now();
+  if (on) { std::fprintf(stderr, "[dn %8.3f ms] %s\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); }
+}
+
 static int cluster_on_device(swa_ctx * ctx, const swa_hostdb * db, int no_cluster_breaking, swa_dn_result * r) {
   const uint32_t n = db->n;
   uint64_t total = 0;
+  dn_stamp("graph: start");
   int rc = swa_dn_graph_resident(ctx, no_cluster_breaking, &total);
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  dn_stamp("graph: resident");
   std::vector<uint32_t> swarmid(n), generation(n), parent(n), order(n), begins((size_t)n + 1);
   std::vector<uint8_t> pdiff(n);
   uint32_t nswarms = 0;
   rc = swa_d1_cluster_device(ctx, swarmid.data(), generation.data(), parent.data(), order.data(), begins.data(), n, &nswarms);
+  dn_stamp("walk on the device: labels, generations, parents, order");
   if (rc == SWA_OK) { rc = swa_dn_parent_diffs(ctx, pdiff.data()); }
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
+  dn_stamp("parent differences");
   std::vector<uint32_t> radius(n, 0), pos_of(n, 0), fill;
   r->order.resize(n);
   r->swarms.resize(nswarms);
@@ -157,6 +169,7 @@ static int cluster_on_device(swa_ctx * ctx, const swa_hostdb * db, int no_cluste
     r->largest = std::max<uint64_t>(r->largest, size);
     r->maxgenerations = std::max<uint64_t>(r->maxgenerations, sw.maxgen);
   }
+  dn_stamp("swarm tables on the host");
   return SWA_OK;
 }
 
@@ -196,9 +209,12 @@ extern "C" int swa_dn_cluster(swa_ctx * ctx, const swa_hostdb * db, int64_t diff
   r->pen_mismatch = mismatch; r->pen_gapopen = gapopen; r->pen_gapextend = gapextend;
   const uint32_t n = db->n;
   if (n == 0) { return SWA_OK; }
+  dn_stamp("clustering: start");
   int rc = swa_qgram_build(ctx);
+  dn_stamp("q-gram signatures");
   if (rc == SWA_OK) { rc = swa_search_begin(ctx, mismatch, gapopen, gapextend, (uint64_t)differences); }
   if (rc == SWA_OK) { rc = swa_scan_begin(ctx); }
+  dn_stamp("search / scan begin");
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
 
   // Bulk route (dn_graph.hip): when every sequence has room for d + 1 windows the GPU returns the whole graph of
