@@ -315,6 +315,7 @@ def config3_dn(args, n: int, length: int, d: int) -> dict:
     hdb = HostDb(fa, check_duplicate_sequences=True)
     t_read = time.perf_counter() - t0
     ctx = Context(0)
+    ctx.warmup()                                  # (code objects loaded beside the FASTA read, as the command line does it)
     ctx.timing_enable(True)
     ctx.upload_hostdb(hdb)
     t0 = time.perf_counter()

@@ -317,6 +317,12 @@ class Context:
             raise SwaError(rc, self.lib.swa_last_error(self.h).decode())
         return rc
 
+    def warmup(self) -> None:
+        """First-use costs of the device (code objects of every kernel file, copy queues) now, not inside the first call that
+        needs them: what the command line does on a helper thread beside the FASTA read (swa_ctx_warmup)."""
+        self.lib.swa_ctx_warmup.argtypes = [C.c_void_p]
+        self._check(self.lib.swa_ctx_warmup(self.h))
+
     def synchronize(self) -> None:
         self._check(self.lib.swa_ctx_synchronize(self.h))
 

@@ -673,3 +673,7 @@ extern "C" int swa_search_do(swa_ctx * ctx, uint64_t query_no, uint64_t listleng
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SWA_OK;
 }
+
+// loads this translation unit's code object (see swa_ctx_warmup): an empty launch
+__global__ void k_warm_align() {}
+void swa_warm_align(swa_ctx * ctx) { hipLaunchKernelGGL(k_warm_align, dim3(1), dim3(64), 0, ctx->stream); }

@@ -80,6 +80,10 @@ extern "C" int swa_ctx_create(int device, void * stream, swa_ctx ** out) {
 // (reading a FASTA file) runs this on a helper thread right after swa_ctx_create.
 void swa_warm_d1(swa_ctx * ctx);          // d1.hip
 void swa_warm_cluster(swa_ctx * ctx);     // cluster_gpu.hip
+void swa_warm_dn(swa_ctx * ctx);          // dn_graph.hip
+void swa_warm_align(swa_ctx * ctx);       // align.hip
+void swa_warm_qgram(swa_ctx * ctx);       // qgram.hip
+void swa_warm_scan(swa_ctx * ctx);        // scan.hip
 __global__ void k_warm(uint32_t * p) { if (threadIdx.x == 0u && p != nullptr) { p[0] = 1u; } }
 
 extern "C" int swa_ctx_warmup(swa_ctx * ctx) {
@@ -92,6 +96,7 @@ extern "C" int swa_ctx_warmup(swa_ctx * ctx) {
   hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, ctx->stream, static_cast<uint32_t *>(d));
   swa_warm_d1(ctx);
   swa_warm_cluster(ctx);
+  swa_warm_dn(ctx); swa_warm_align(ctx); swa_warm_qgram(ctx); swa_warm_scan(ctx);
   SWA_HIP(ctx, hipMemcpyAsync(host.data(), d, 4096, hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SWA_HIP(ctx, hipFree(d));

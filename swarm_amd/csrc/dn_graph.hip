@@ -690,3 +690,7 @@ extern "C" int swa_dn_graph_totals(swa_ctx * ctx, uint64_t * out3) {
   out3[0] = ctx->dn_comparisons; out3[1] = ctx->dn_aligned; out3[2] = ctx->dn_launches;
   return SWA_OK;
 }
+
+// loads this translation unit's code object (see swa_ctx_warmup): an empty launch
+__global__ void k_warm_dn() {}
+void swa_warm_dn(swa_ctx * ctx) { hipLaunchKernelGGL(k_warm_dn, dim3(1), dim3(64), 0, ctx->stream); }

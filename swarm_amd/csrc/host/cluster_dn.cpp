@@ -131,20 +131,27 @@ static int cluster_on_device(swa_ctx * ctx, const swa_hostdb * db, int no_cluste
   if (rc == SWA_OK) { rc = swa_dn_parent_diffs(ctx, pdiff.data()); }
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
   dn_stamp("parent differences");
-  std::vector<uint32_t> radius(n, 0), pos_of(n, 0), fill;
+  std::vector<uint32_t> radius(n, 0), pos_of(n, 0);
   r->order.resize(n);
   r->swarms.resize(nswarms);
   r->links.resize((size_t)n - nswarms);
-  uint32_t link_at = 0;
+  // Swarm by swarm, independently: swarm s owns order[begins[s], begins[s + 1]) and — one link per member but the seed —
+  // links[begins[s] - s, begins[s + 1] - s - 1).  (31 ms of a 91 ms clustering phase at 1 M x 400 as one thread's loop;
+  // the sums r->largest / maxgenerations are folded behind it.)
+  uint64_t largest = 0, maxgenerations = 0;
+  bool broken = false;
+#pragma omp parallel for schedule(dynamic, 64) reduction(max : largest, maxgenerations) reduction(|| : broken)
   for (uint32_t s = 0; s < nswarms; ++s) {
+    std::vector<uint32_t> fill;
     swa_dn_result::Swarm & sw = r->swarms[s];
     sw.begin = begins[s]; sw.end = begins[s + 1];
+    uint32_t link_at = begins[s] - s;
     sw.link_begin = link_at;
     const uint32_t size = sw.end - sw.begin;
     for (uint32_t at = sw.begin; at < sw.end; ++at) {       // (generation, id) order: a parent comes before its children
       const uint32_t v = order[at];
       const uint32_t g = generation[v];
-      if (g != 0 && pdiff[v] == 0xFF) { r->error = "d >= 2 clustering on the GPU: a parent without a link to its child"; return SWA_E_DEVICE; }
+      if (g != 0 && pdiff[v] == 0xFF) { broken = true; }
       const uint32_t rad = g == 0 ? 0u : radius[parent[v]] + pdiff[v];
       radius[v] = rad;
       pos_of[v] = at;
@@ -166,9 +173,12 @@ static int cluster_on_device(swa_ctx * ctx, const swa_hostdb * db, int no_cluste
       link_at += size - 1;
     }
     sw.link_end = link_at;
-    r->largest = std::max<uint64_t>(r->largest, size);
-    r->maxgenerations = std::max<uint64_t>(r->maxgenerations, sw.maxgen);
+    largest = std::max<uint64_t>(largest, size);
+    maxgenerations = std::max<uint64_t>(maxgenerations, sw.maxgen);
   }
+  if (broken) { r->error = "d >= 2 clustering on the GPU: a parent without a link to its child"; return SWA_E_DEVICE; }
+  r->largest = std::max<uint64_t>(r->largest, largest);
+  r->maxgenerations = std::max<uint64_t>(r->maxgenerations, maxgenerations);
   dn_stamp("swarm tables on the host");
   return SWA_OK;
 }

@@ -116,3 +116,7 @@ extern "C" int swa_qgram_debug_read(swa_ctx * ctx, uint8_t * out, size_t out_byt
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SWA_OK;
 }
+
+// loads this translation unit's code object (see swa_ctx_warmup): an empty launch
+__global__ void k_warm_qgram() {}
+void swa_warm_qgram(swa_ctx * ctx) { hipLaunchKernelGGL(k_warm_qgram, dim3(1), dim3(64), 0, ctx->stream); }

@@ -428,3 +428,7 @@ extern "C" int swa_scan_totals(swa_ctx * ctx, uint64_t * out3) {
   out3[0] = compared; out3[1] = t[1]; out3[2] = ctx->scan_launches;
   return SWA_OK;
 }
+
+// loads this translation unit's code object (see swa_ctx_warmup): an empty launch
+__global__ void k_warm_scan() {}
+void swa_warm_scan(swa_ctx * ctx) { hipLaunchKernelGGL(k_warm_scan, dim3(1), dim3(64), 0, ctx->stream); }
