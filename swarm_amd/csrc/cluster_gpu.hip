@@ -8,7 +8,8 @@
 // nodes and 2 x 10^7 links: 0.36 s on a 256-core host, a few milliseconds here, and the 150 MB CSR no longer
 // has to cross PCIe at all (only the four result arrays do).
 //
-//   k_label_step      label[v] = min(label[v], label[u]) along every link u -> v, until nothing changes
+//   k_label_step      label[v] = min(label[v], label[u]) along every link u -> v — and label[v] = label[label[v]]: pointer
+//                     jumping — until nothing changes
 //   k_level_step      level-synchronous distances from the seeds + parents (atomicMin of the claiming ids)
 //   rocPRIM           seeds -> swarm numbers (exclusive scan); members ordered by one stable radix sort of
 //                     (swarm << 32 | generation) with the ids ascending as payload; swarm sizes -> begins (scan)
@@ -30,7 +31,12 @@ __global__ __launch_bounds__(256) void k_label_step(const uint64_t * __restrict_
                                                     uint32_t * label, uint32_t * changed) {
   bool any = false;
   for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-    const uint32_t lu = label[u];
+    uint32_t lu = label[u];
+    // pointer jumping (round 4): label[u] = l says "l reaches u"; whatever reaches l reaches u as well, so u may take l's
+    // label at once instead of waiting for it to travel link by link — the sweeps until nothing changes fall from the
+    // depth of the deepest swarm towards its logarithm
+    const uint32_t ll = label[lu];
+    if (ll < lu) { atomicMin(&label[u], ll); lu = ll; any = true; }
     for (uint64_t e = offsets[u]; e < offsets[u + 1]; ++e) {
       const uint32_t v = nb[e];
       if (lu < label[v]) { atomicMin(&label[v], lu); any = true; }
