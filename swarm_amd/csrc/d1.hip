@@ -1270,7 +1270,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   GroupArgs g{};
   for (int i = 0; i < 2; ++i) {
     GroupIdx & x = g.g[i];
-    x.rec = j.out[i];
+    x.rec = const_cast<unsigned long long *>(j.out[i]);
     x.fp = i == 0 ? j.out_f[0] : nullptr;
     x.bstart = j.bstart[i];
     x.buckets = j.buckets;
