@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 4, lease r: k_group1 with one straight-line attempt per record and the listed groups side by side — stages, parity
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4r; mkdir -p $O
+# round 4, lease s: k_group1 — tail records asked for early, members staged in LDS, no loop-invariant spills
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4s; mkdir -p $O
 cd $R
 python -c "import bench; bench.gen_fasta(10000000,150,1)"
 for v in base stop1 stop2 stop3 stop4; do
