@@ -1083,11 +1083,21 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     const dim3 grid_f((unsigned)std::min<uint64_t>(((tiles << bits) + 1 + kFlatChunk - 1) / kFlatChunk, (uint64_t)cu_grid), j.nidx);
     hipLaunchKernelGGL(k_flat_sums, grid_f, dim3(256), 0, ctx->stream, f);
     hipLaunchKernelGGL(k_flat_apply, grid_f, dim3(256), 0, ctx->stream, f);
-    if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<2, 4096, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
-    else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 4096) { hipLaunchKernelGGL((k_part_scatter<1, 4096, 1024>), grid_t, dim3(256), 0, ctx->stream, a); }
-    else if (j.buf_f[0][0] != nullptr && bins1024) { hipLaunchKernelGGL((k_part_scatter<1, 2048, 1024>), grid_t, dim3(256), 0, ctx->stream, a); }
-    else if (j.buf_f[0][0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<1, 2048, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
-    else { hipLaunchKernelGGL((k_part_scatter<0, 4096, 512>), grid_t, dim3(256), 0, ctx->stream, a); }
+    {
+      static const int part_threads = [] { const char * e = getenv("SWA_D1_PART_THREADS"); const int v = e != nullptr ? atoi(e) : 512; return v == 256 || v == 1024 ? v : 512; }();   // (512: key partition 0.269 -> 0.239, link partition 0.317 -> 0.303 ms at 10 M against 256; 1024: 0.244 / 0.384)
+#define SWA_SCATTER(M, T, B)                                                                                                          \
+      do {                                                                                                                            \
+        if (part_threads == 1024) { hipLaunchKernelGGL((k_part_scatter<M, T, B, 1024>), grid_t, dim3(1024), 0, ctx->stream, a); }     \
+        else if (part_threads == 512) { hipLaunchKernelGGL((k_part_scatter<M, T, B, 512>), grid_t, dim3(512), 0, ctx->stream, a); }   \
+        else { hipLaunchKernelGGL((k_part_scatter<M, T, B, 256>), grid_t, dim3(256), 0, ctx->stream, a); }                            \
+      } while (0)
+      if (last_level && j.out32[0] != nullptr) { SWA_SCATTER(2, 4096, 512); }
+      else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 4096) { SWA_SCATTER(1, 4096, 1024); }
+      else if (j.buf_f[0][0] != nullptr && bins1024) { SWA_SCATTER(1, 2048, 1024); }
+      else if (j.buf_f[0][0] != nullptr) { SWA_SCATTER(1, 2048, 512); }
+      else { SWA_SCATTER(0, 4096, 512); }
+#undef SWA_SCATTER
+    }
     chunks = (single ? 1 : chunks) << bits;
     single = false;
     hipLaunchKernelGGL(k_part_starts, dim3((unsigned)std::min<uint64_t>((chunks + 256) / 256, (uint64_t)cu_grid), j.nidx), dim3(256), 0, ctx->stream, a);
@@ -1297,6 +1307,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     }
     hipLaunchKernelGGL(k_group1, dim3((unsigned)std::min<uint64_t>(buckets, (uint64_t)ctx->num_cus), 2), dim3(kG1Threads), kG1LdsBytes, ctx->stream, g);
   }
+  swa_t1(ctx, 10);                                            // (slot 10: k_group1 alone; the work lists below count in slot 7, the whole build)
 
   // ---- work lists
   FlatScanArgs f{};
@@ -1316,7 +1327,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   hipLaunchKernelGGL(k_flat_sums, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_flat_apply, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_group_lists, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, (uint64_t)ctx->num_cus * 8), 2), dim3(256), 0, ctx->stream, la);
-  swa_t1(ctx, 10);
   SWA_HIP(ctx, hipGetLastError());
   ctx->list_regions_items = item_room;
   ctx->anchor_ready = true;
