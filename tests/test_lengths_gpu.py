@@ -108,3 +108,36 @@ def test_sequences_beyond_the_widest_kernel(tmp_path):
     S.gen_fasta(fa, 3000, 900, 64)
     links, _ = _check(S.db_from_fasta(fa))
     assert links > 1500
+
+
+def test_a_window_shared_by_more_amplicons_than_sixteen_bits_count(tmp_path):
+    """70 000 amplicons behind one 64-nt prefix window (a dominant organism's variants in a deep run): the bucket of that
+    key holds more records than k_group1's 16-bit ranks count, so all of them are left to the plain kernel — the network
+    must still be the oracle's, and two identical sequences among them must still be reported"""
+    rng = np.random.default_rng(77)
+    head = "".join(rng.choice(list("ACGT"), 64))
+    tails = set()
+    while len(tails) < 69000:
+        tails.add("".join(rng.choice(list("ACGT"), 86)))
+    tails = sorted(tails)
+    seqs = {head + t for t in tails}
+    for t in tails[:1500]:                                       # ... 1500 of them with a neighbour one edit away, in the tail
+        p = int(rng.integers(0, 86))
+        k = int(rng.integers(0, 3))
+        b = str(rng.choice(list("ACGT")))
+        seqs.add(head + (t[:p] + b + t[p + 1:] if k == 0 else (t[:p] + t[p + 1:] if k == 1 else t[:p] + b + t[p:])))
+    db = _write(tmp_path / "giant.fa", list(seqs), rng)
+    assert db.n > 65534
+    links, _ = _check(db)
+    assert links >= 1300                                         # (one direction per pair: the lighter one does not link up)
+    # the same set with one sequence twice: the duplicate is found by the plain kernel's table
+    from swarm_amd import Context
+    twice = sorted(seqs)
+    (tmp_path / "twice.fa").write_text("".join(f">b{i}_{1 + i % 7}\n{s}\n" for i, s in enumerate(twice + [twice[12345]])))
+    db2 = S.db_from_fasta(tmp_path / "twice.fa")
+    ctx = Context(0)
+    try:
+        ctx.upload_db(db2.seqs, db2.seq_off, db2.seqlen, db2.abundance, db2.longest)
+        assert ctx.d1_index_build() is True
+    finally:
+        ctx.close()
