@@ -1087,11 +1087,21 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
       static const int part_threads = [] { const char * e = getenv("SWA_D1_PART_THREADS"); const int v = e != nullptr ? atoi(e) : 512; return v == 256 || v == 1024 ? v : 512; }();   // (512: key partition 0.269 -> 0.239, link partition 0.317 -> 0.303 ms at 10 M against 256; 1024: 0.244 / 0.384)
 #define SWA_SCATTER(M, T, B)                                                                                                          \
       do {                                                                                                                            \
-        if (part_threads == 1024) { hipLaunchKernelGGL((k_part_scatter<M, T, B, 1024>), grid_t, dim3(1024), 0, ctx->stream, a); }     \
-        else if (part_threads == 512) { hipLaunchKernelGGL((k_part_scatter<M, T, B, 512>), grid_t, dim3(512), 0, ctx->stream, a); }   \
-        else { hipLaunchKernelGGL((k_part_scatter<M, T, B, 256>), grid_t, dim3(256), 0, ctx->stream, a); }                            \
+        constexpr size_t lds = part_scatter_lds(M, T, B);                                                                             \
+        if (part_threads == 1024) { hipLaunchKernelGGL((k_part_scatter<M, T, B, 1024>), grid_t, dim3(1024), lds, ctx->stream, a); }   \
+        else if (part_threads == 512) { hipLaunchKernelGGL((k_part_scatter<M, T, B, 512>), grid_t, dim3(512), lds, ctx->stream, a); } \
+        else { hipLaunchKernelGGL((k_part_scatter<M, T, B, 256>), grid_t, dim3(256), lds, ctx->stream, a); }                          \
       } while (0)
       if (last_level && j.out32[0] != nullptr) { SWA_SCATTER(2, 4096, 512); }
+      else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 8192) {
+        // (108 KB of dynamic LDS: the attribute belongs to the function on a device — once per context)
+        constexpr size_t lds = part_scatter_lds(1, 8192, 1024);
+        if (!ctx->part_lds_opt_in) {
+          SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter<1, 8192, 1024, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          ctx->part_lds_opt_in = true;
+        }
+        hipLaunchKernelGGL((k_part_scatter<1, 8192, 1024, 1024>), grid_t, dim3(1024), lds, ctx->stream, a);
+      }
       else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 4096) { SWA_SCATTER(1, 4096, 1024); }
       else if (j.buf_f[0][0] != nullptr && bins1024) { SWA_SCATTER(1, 2048, 1024); }
       else if (j.buf_f[0][0] != nullptr) { SWA_SCATTER(1, 2048, 512); }
@@ -1160,8 +1170,18 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   j.out_cap = records + 1;
   // (tiles of 2048 records for 512 bins; one level of 1024 bins: 4096, or the flat count array — bins x tiles — and the 16-byte runs
   // a tile leaves per bin cost more than the saved level: 0.56 -> 0.43 ms at 10 M amplicons)
-  j.tile = (total_bits > kPartMaxBits && j.plan.levels == 1) ? 4096 : 2048;
-  if (const char * e = getenv("SWA_D1_KEY_TILE")) { if (atoi(e) == 2048 || (atoi(e) == 4096 && total_bits > kPartMaxBits && j.plan.levels == 1)) { j.tile = (uint32_t)atoi(e); } }   // (experiment)
+  {
+    // tiles of 2048 records for 512 bins; one level of 1024 bins: 4096 — or 8192 when k_keys takes the histogram (k_part_hist
+    // holds 4096 a workgroup): a tile then leaves runs of 64 bytes per bin, whole lines (key partition 0.239 -> 0.225 ms at 10 M)
+    const bool one_wide_level = total_bits > kPartMaxBits && j.plan.levels == 1;
+    const char * kh = getenv("SWA_D1_KEYS_HIST");
+    const bool hist_by_keys = !routed && !(kh != nullptr && kh[0] == '0');
+    j.tile = one_wide_level ? (hist_by_keys ? 8192 : 4096) : 2048;
+    if (const char * e = getenv("SWA_D1_KEY_TILE")) {          // (experiment)
+      const int v = atoi(e);
+      if (v == 2048 || (v == 4096 && one_wide_level) || (v == 8192 && one_wide_level && hist_by_keys)) { j.tile = (uint32_t)v; }
+    }
+  }
   j.max_tiles0 = records / j.tile + 2;
   j.chunks0 = 1; j.single0 = true; j.top_bit = 32; j.bias = 0;
   uint64_t e_cnt, e_tile, e_start, e_partial;
