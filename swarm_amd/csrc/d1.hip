@@ -1075,8 +1075,9 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     hipLaunchKernelGGL(k_part_tiles, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a);
     const bool bins1024 = bits > kPartMaxBits;                 // (the key records of the one-level form: 10 bits)
     if (l == 0 && j.hist0_done) { /* (k_keys has left the counts) */ }
-    else if (bins1024) { hipLaunchKernelGGL(k_part_hist<1024>, grid_t, dim3(256), 0, ctx->stream, a); }
-    else { hipLaunchKernelGGL(k_part_hist<512>, grid_t, dim3(256), 0, ctx->stream, a); }
+    else if (bins1024) { hipLaunchKernelGGL((k_part_hist<1024, kPartTileMax, 256>), grid_t, dim3(256), 0, ctx->stream, a); }
+    else if (j.tile == 8192) { hipLaunchKernelGGL((k_part_hist<512, 8192, 512>), grid_t, dim3(512), 0, ctx->stream, a); }
+    else { hipLaunchKernelGGL((k_part_hist<512, kPartTileMax, 256>), grid_t, dim3(256), 0, ctx->stream, a); }
     FlatScanArgs f{};
     f.unit_bits = bits;
     for (uint32_t i = 0; i < j.nidx; ++i) { f.v[i] = j.cnt[i]; f.units[i] = j.ctile[i] + chunks; f.partial[i] = j.partial[i]; f.total[i] = j.total[i]; }
@@ -1092,21 +1093,29 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
         else if (part_threads == 512) { hipLaunchKernelGGL((k_part_scatter<M, T, B, 512>), grid_t, dim3(512), lds, ctx->stream, a); } \
         else { hipLaunchKernelGGL((k_part_scatter<M, T, B, 256>), grid_t, dim3(256), lds, ctx->stream, a); }                          \
       } while (0)
-      if (last_level && j.out32[0] != nullptr) { SWA_SCATTER(2, 4096, 512); }
-      else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 8192) {
-        // (108 KB of dynamic LDS: the attribute belongs to the function on a device — once per context)
-        constexpr size_t lds = part_scatter_lds(1, 8192, 1024);
-        if (!ctx->part_lds_opt_in) {
-          SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter<1, 8192, 1024, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          ctx->part_lds_opt_in = true;
-        }
-        hipLaunchKernelGGL((k_part_scatter<1, 8192, 1024, 1024>), grid_t, dim3(1024), lds, ctx->stream, a);
+      // (beyond 64 KB of dynamic LDS the attribute is asked for: it belongs to the function on a device — once per context)
+#define SWA_SCATTER_WIDE(M, B, BIT)                                                                                                   \
+      do {                                                                                                                            \
+        constexpr size_t lds = part_scatter_lds(M, 8192, B);                                                                          \
+        if ((ctx->part_lds_opt_in & (1u << BIT)) == 0u) {                                                                             \
+          SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter<M, 8192, B, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+          ctx->part_lds_opt_in |= 1u << BIT;                                                                                          \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((k_part_scatter<M, 8192, B, 1024>), grid_t, dim3(1024), lds, ctx->stream, a);                              \
+      } while (0)
+      if (j.buf_f[0][0] == nullptr && j.tile == 8192 && !bins1024) {
+        if (last_level && j.out32[0] != nullptr) { SWA_SCATTER_WIDE(2, 512, 1); } else { SWA_SCATTER_WIDE(0, 512, 2); }
+      }
+      else if (last_level && j.out32[0] != nullptr) { SWA_SCATTER(2, 4096, 512); }
+      else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 8192) { SWA_SCATTER_WIDE(1, 1024, 0); }
+      else if (false) {
       }
       else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 4096) { SWA_SCATTER(1, 4096, 1024); }
       else if (j.buf_f[0][0] != nullptr && bins1024) { SWA_SCATTER(1, 2048, 1024); }
       else if (j.buf_f[0][0] != nullptr) { SWA_SCATTER(1, 2048, 512); }
       else { SWA_SCATTER(0, 4096, 512); }
 #undef SWA_SCATTER
+#undef SWA_SCATTER_WIDE
     }
     chunks = (single ? 1 : chunks) << bits;
     single = false;
@@ -1379,6 +1388,7 @@ static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const 
   j.max_records = link_cap;
   j.out_cap = link_cap;
   j.tile = 4096;
+  if (const char * e = getenv("SWA_D1_LINK_TILE")) { if (atoi(e) == 8192) { j.tile = 8192; } }   // (experiment: runs of 128 bytes, half the flat counts)
   j.max_tiles0 = max_tiles0;
   j.chunks0 = chunks; j.single0 = true; j.top_bit = nbits; j.bias = first;
   j.csize_cap = csize_cap;

@@ -150,7 +150,7 @@ struct swa_ctx {
   // the d = 1 network kept in d_offsets_tmp / d_nb_tmp (swa_d1_network_resident) and its clustering (cluster_gpu.hip)
   bool csr_ready = false;
   bool g1_lds_opt_in = false;                  // k_group1's dynamic-LDS attribute has been set on this context's device
-  bool part_lds_opt_in = false;    // ... and k_part_scatter<1, 8192, 1024, 1024>'s 108 KB
+  uint32_t part_lds_opt_in = 0;    // ... and the wide-tile forms of k_part_scatter (one bit each)
   bool csr_has_diffs = false;                 // the resident network is a d >= 2 graph: one byte of differences per link behind the neighbours
   uint64_t csr_total = 0;
   swa_dbuf d_cluster;
