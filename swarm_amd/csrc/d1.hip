@@ -1502,7 +1502,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
   clear_add(clears, acounters, kCounterBase * sizeof(uint32_t));
   clear_add(clears, ctx->d_seg_fill.ptr, 3ull * seg_count(ctx) * sizeof(uint32_t));   // segment fills | members staged, per pass
   // work counters of k_d1_group_pairs (per pass and class): 2^shard_bits of them, sched_stride entries apart
-  uint32_t pair_batch = 4, shard_bits = 6, sched_stride = 64;
+  uint32_t pair_batch = 0, shard_bits = 6, sched_stride = 64;   // (pair_batch 0: by the number of bundles, below)
   if (const char * e = getenv("SWA_D1_PAIR_BATCH")) { pair_batch = (uint32_t)std::max(1, atoi(e)); }                           // (experiments)
   if (const char * e = getenv("SWA_D1_PAIR_SHARD_BITS")) { shard_bits = (uint32_t)std::min(10, std::max(0, atoi(e))); }
   if (const char * e = getenv("SWA_D1_SCHED_STRIDE")) { sched_stride = (uint32_t)std::min(4096, std::max(1, atoi(e))); }
@@ -1563,7 +1563,18 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
       const uint32_t * have = ctx->list_counts_ready ? ctx->list_counts + pc * 8u : nullptr;
       bool any_pairs = have == nullptr;
       for (uint32_t k = 0; k <= kPairClasses && have != nullptr; ++k) { any_pairs = any_pairs || have[k] != 0u; }
-      if (any_pairs) { SWA_TRY(launch_group_pairs(ctx, pass, width, nwin, ctx->num_cus * pair_blocks_per_cu(cls), a)); }
+      // Bundles per visit of a work counter: 4 where every wave has dozens of bundles to go through (10 M amplicons: the counters
+      // are what limits then — 0.78 / 1.21 / 2.2 ms with 4 / 2 / 1), fewer where the waves' shares are what limits (1 M: 2.4
+      // bundles a wave — 0.072 / 0.049 / 0.037 ms a pass with 4 / 2 / 1)
+      const int pgrid = ctx->num_cus * pair_blocks_per_cu(cls);
+      a.batch = pair_batch;
+      if (pair_batch == 0) {
+        uint64_t bundles = 0;
+        for (uint32_t k = 0; k < kPairClasses && have != nullptr; ++k) { bundles += ((uint64_t)have[k] + (16u >> k) - 1u) >> (4u - k); }
+        const uint64_t waves = (uint64_t)pgrid * 4u;
+        a.batch = have == nullptr || bundles >= 16u * waves ? 4u : (bundles >= 8u * waves ? 2u : 1u);
+      }
+      if (any_pairs) { SWA_TRY(launch_group_pairs(ctx, pass, width, nwin, pgrid, a)); }
       if (have == nullptr || have[kPairClasses + 1u] != 0u) { SWA_TRY(launch_pairs_tiled(ctx, pass, width, nwin, ctx->num_cus * (cls <= 1u ? 8 : 4), a)); }
     }
     swa_t1(ctx, 11 + pass);
