@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, lease v: the artefacts of the round's last build — default bench line (as the driver runs it), kernel stats,
+# tools/closing_artefacts.sh — the artefacts a round closes with (run on the GPU box: gpurun -- bash tools/closing_artefacts.sh):
 # PMC traffic, smoke, the whole GPU suite
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4v; mkdir -p $O
 cd $R
