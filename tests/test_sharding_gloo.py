@@ -64,7 +64,7 @@ def _star_fasta(path, arms=300):
     path.write_text("".join(f">s{i}_{a}\n{s}\n" for i, (s, a) in enumerate(recs)))
 
 
-@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "length"), (3, "length"), (2, "star")])
+@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "length"), (3, "length"), (2, "star"), (4, "even")])
 def test_sharded_network_equals_single(tmp_path, world, mode):
     fa = tmp_path / "in.fa"
     if mode == "star":
@@ -173,7 +173,7 @@ OWNED_WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "length")])
+@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "length"), (4, "even"), (8, "length")])   # (8: what the driver's scaling run starts)
 def test_owned_links_merge_into_the_network(tmp_path, world, mode):
     """Ownership sharding (swa_d1_set_ownership): every rank holds some of the links (flat list),
     all-to-all by seed range, CSR slice per rank, then the usual all-gather of the slices."""
@@ -224,7 +224,7 @@ ROUTE_WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_routed_ids_reach_their_owners(tmp_path, world):
     """sharding.exchange_routed_ids: what swa_d1_route_slice leaves on every rank (ids of its slice by owning rank and
     index) arrives, all-to-all, as the member lists of swa_d1_index_build_routed."""
