@@ -16,8 +16,6 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-#include <omp.h>
-#include <parallel/algorithm>
 
 #include <algorithm>
 #include <atomic>
@@ -41,7 +39,7 @@ struct RawEntry {
   uint64_t abundance;
   uint64_t key8;         // first 8 header bytes, big endian (sort accelerator)
   uint32_t hdr_len;
-  uint32_t lineno;       // line of the '>' header, local to the piece until fixed up
+  uint32_t lineno;       // line of the '>' header, counted from the start of the piece
   uint32_t seqlen;
   int32_t ab_start;      // abundance annotation [start, end) inside the header
   int32_t ab_end;
@@ -309,6 +307,54 @@ void run_parallel(unsigned threads, F && fn) {
   for (auto & th : pool) { th.join(); }
 }
 
+// sorts a[0, n) by `less` (a strict weak order) on `threads` threads; tmp[0, n) is scratch; the result is in a
+template <class Rec, class Less>
+void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less less) {
+  if (threads <= 1 || n < 100000) { std::sort(a, a + n, less); return; }
+  const unsigned buckets = std::min<unsigned>(threads * 8u, 1024u);
+  constexpr uint64_t kOver = 64;                            // sampled records per bucket
+  const uint64_t nsample = (uint64_t)buckets * kOver;
+  std::vector<Rec> sample(nsample);
+  for (uint64_t i = 0; i < nsample; ++i) { sample[i] = a[(n - 1) * i / (nsample - 1)]; }
+  std::sort(sample.begin(), sample.end(), less);
+  std::vector<Rec> split(buckets - 1);
+  for (unsigned b = 1; b < buckets; ++b) { split[b - 1] = sample[(uint64_t)b * kOver]; }
+  std::vector<uint64_t> place((size_t)threads * buckets, 0);
+  swa_vec<uint16_t> where(n);
+  run_parallel(threads, [&](unsigned t) {
+    uint64_t * c = &place[(size_t)t * buckets];
+    for (uint64_t i = n * t / threads; i < n * (t + 1) / threads; ++i) {
+      unsigned lo = 0, hi = buckets - 1;                    // bucket = number of splitters not above the record
+      while (lo < hi) {
+        const unsigned mid = (lo + hi) / 2;
+        if (less(a[i], split[mid])) { hi = mid; } else { lo = mid + 1; }
+      }
+      where[i] = (uint16_t)lo;
+      ++c[lo];
+    }
+  });
+  std::vector<uint64_t> start(buckets + 1, 0);
+  uint64_t at = 0;
+  for (unsigned b = 0; b < buckets; ++b) {
+    start[b] = at;
+    for (unsigned t = 0; t < threads; ++t) { const uint64_t c = place[(size_t)t * buckets + b]; place[(size_t)t * buckets + b] = at; at += c; }
+  }
+  start[buckets] = at;
+  run_parallel(threads, [&](unsigned t) {
+    uint64_t * c = &place[(size_t)t * buckets];
+    for (uint64_t i = n * t / threads; i < n * (t + 1) / threads; ++i) { tmp[c[where[i]]++] = a[i]; }
+  });
+  std::atomic<unsigned> next{0};
+  run_parallel(threads, [&](unsigned) {
+    for (;;) {
+      const unsigned b = next.fetch_add(1);
+      if (b >= buckets) { break; }
+      std::sort(tmp + start[b], tmp + start[b + 1], less);
+      std::copy(tmp + start[b], tmp + start[b + 1], a + start[b]);
+    }
+  });
+}
+
 }  // namespace
 
 namespace {
@@ -376,7 +422,6 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
       }
       return SWA_E_ARG;
     }
-    for (auto & e : pc.entries) { e.lineno += (uint32_t)lines_before; }
     if (pc.missing != 0) { pc.missing_line += (uint32_t)lines_before; }
     lines_before += pc.lines;
   }
@@ -571,15 +616,17 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   // touching the header text (equal prefixes fall through to strcmp: same order).
   // The sort moves compact records (the keys travel with the index, no pointer chasing);
   // inputs that are already in db order (swarm's own -w output, vsearch output) skip it.
-  struct SortRec { uint64_t abundance, key8; uint32_t entry, words, hdr_bytes; };   // + what the offsets need
+  // 16-byte records: the abundance saturates at 32 bits (two saturated ones are told apart through their entries)
+  struct SortRec { uint64_t key8; uint32_t abundance, entry; };
   swa_vec<SortRec> recs(n);
   run_parallel(threads, [&](unsigned t) {
     for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads; ++i) {
-      recs[i] = SortRec{ent[i]->abundance, ent[i]->key8, (uint32_t)i, (ent[i]->seqlen + 31u) >> 5, ent[i]->hdr_len + 1u};
+      recs[i] = SortRec{ent[i]->key8, (uint32_t)std::min<uint64_t>(ent[i]->abundance, 0xFFFFFFFFull), (uint32_t)i};
     }
   });
   auto less = [&](const SortRec & a, const SortRec & b) {
     if (a.abundance != b.abundance) { return a.abundance > b.abundance; }
+    if (a.abundance == 0xFFFFFFFFu && ent[a.entry]->abundance != ent[b.entry]->abundance) { return ent[a.entry]->abundance > ent[b.entry]->abundance; }
     if (a.key8 != b.key8) { return a.key8 < b.key8; }
     return std::strcmp(hdr_of(ent[a.entry]), hdr_of(ent[b.entry])) < 0;
   };
@@ -591,13 +638,14 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     }
   });
   if (!sorted.load()) {
-    // libstdc++ parallel mode: multiway merge sort over the host cores (OpenMP); the order is a
-    // strict total order (identifiers are unique), so the result equals std::sort's
-    // (thread count for this sort only: the process-wide setting belongs to the caller)
-    const int caller_threads = omp_get_max_threads();
-    omp_set_num_threads((int)threads);
-    __gnu_parallel::sort(recs.begin(), recs.end(), less);
-    omp_set_num_threads(caller_threads);
+    // Sample sort over the host cores: splitters from a regular sample, every thread files its share of the records
+    // under them (a binary search per record, the counts per thread and bucket give every record its place without
+    // atomics), the buckets — 8 per thread, so that an unlucky splitter costs little — are sorted independently.  The
+    // order is a strict total order (identifiers are unique), so the result equals std::sort's.  (r04 used libstdc++'s
+    // parallel multiway merge sort on 32-byte records: 151 ms at 10 M amplicons on 64 threads, the largest phase of the
+    // reader.)
+    swa_vec<SortRec> other(n);
+    parallel_sample_sort(recs.data(), other.data(), n64, threads, less);
   }
   auto order = [&](uint64_t k) { return recs[k].entry; };
   timer.lap("sort");
@@ -614,7 +662,15 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     std::vector<uint64_t> wsum(threads + 1, 0), hsum(threads + 1, 0);
     run_parallel(threads, [&](unsigned t) {
       uint64_t w = 0, h = 0;
-      for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) { w += recs[k].words; h += recs[k].hdr_bytes; }
+      const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
+      for (uint64_t k = lo; k < hi; ++k) {
+        if (k + 16 < hi) { __builtin_prefetch(ent[recs[k + 16].entry]); }
+        const RawEntry * e = ent[recs[k].entry];
+        const uint32_t words = (e->seqlen + 31u) >> 5;
+        db->seqlen[k] = words;                               // (parked here for the second pass; the gather overwrites it)
+        db->ab_end[k] = (int32_t)e->hdr_len;
+        w += words; h += e->hdr_len + 1u;
+      }
       wsum[t + 1] = w; hsum[t + 1] = h;
     });
     for (unsigned t = 0; t < threads; ++t) { wsum[t + 1] += wsum[t]; hsum[t + 1] += hsum[t]; }
@@ -623,8 +679,8 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
       for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
         db->seq_off[k] = w;
         db->hdr_off[k] = h;
-        w += recs[k].words;
-        h += recs[k].hdr_bytes;
+        w += db->seqlen[k];
+        h += (uint64_t)db->ab_end[k] + 1u;
       }
     });
     woff = wsum[threads];

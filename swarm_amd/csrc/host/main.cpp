@@ -337,7 +337,9 @@ int main(int argc, char ** argv) {
     const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
     early = std::thread([&early_ctx, &early_rc, device]() {
       early_rc = swa_ctx_create(device, nullptr, &early_ctx);
+      stamp("(helper thread) context created");
       if (early_rc == SWA_OK) { (void)swa_ctx_warmup(early_ctx); }
+      stamp("(helper thread) code objects loaded, first copies done");
     });
   }
 

@@ -9,7 +9,7 @@
 // per-rank hit counts are known on the host when the kernels return, then every rank's flat link list is
 // gathered on rank 0 — the one consumer: grouped ncclSend / ncclRecv (round 2 all-gathered the whole network into every
 // GPU) —, and the CSR is made there by the partition + row kernels of the single-GPU step (swa_d1_csr_from_lists).  Fastidious: the heavy amplicons are split
-// (swa_d1_fastidious_shard), graft_cand is combined with ncclAllReduce(min) (src/algod1.cc:244-258 keeps
+// (swa_d1_fastidious_shard), graft_cand is combined with swa_rccl().AllReduce(min) (src/algod1.cc:244-258 keeps
 // the smallest heavy id), the two heavy-side counters add up.
 //
 // The same code runs with several contexts on ONE device (SWARM_AMD_DEVICES=0,0: what a one-GPU box can
@@ -18,7 +18,7 @@
 // (tests/test_multi_gpu.py).
 #include "swa_internal.h"
 
-#include <rccl/rccl.h>
+#include "rccl_late.h"
 
 #include <algorithm>
 #include <functional>
@@ -102,7 +102,7 @@ int fail(swa_multi * m, int code, const std::string & msg) { m->err = msg; retur
 #define NCCL_OK(m, expr)                                                                               \
   do {                                                                                                 \
     ncclResult_t r_ = (expr);                                                                          \
-    if (r_ != ncclSuccess) { return fail((m), SWA_E_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)); } \
+    if (r_ != ncclSuccess) { return fail((m), SWA_E_DEVICE, std::string(#expr) + ": " + swa_rccl().GetErrorString(r_)); } \
   } while (0)
 
 // every rank's buffer src[r] (count[r] elements of `bytes_per` bytes) into dst[k] + prefix(r) on every rank k
@@ -112,17 +112,17 @@ int all_gather_v(swa_multi * m, const std::vector<const void *> & src, const std
   std::vector<uint64_t> at((size_t)world + 1, 0);
   for (int r = 0; r < world; ++r) { at[(size_t)r + 1] = at[(size_t)r] + count[(size_t)r]; }
   if (!m->comms.empty()) {
-    NCCL_OK(m, ncclGroupStart());
+    NCCL_OK(m, swa_rccl().GroupStart());
     for (int k = 0; k < world; ++k) {
       for (int r = 0; r < world; ++r) {
         if (count[(size_t)r] == 0) { continue; }
         char * recv = static_cast<char *>(dst[(size_t)k]) + at[(size_t)r] * bytes_per;
         // (the send buffer only matters on the root)
-        NCCL_OK(m, ncclBroadcast(k == r ? src[(size_t)r] : recv, recv, count[(size_t)r] * bytes_per, ncclUint8, r, m->comms[(size_t)k],
+        NCCL_OK(m, swa_rccl().Broadcast(k == r ? src[(size_t)r] : recv, recv, count[(size_t)r] * bytes_per, ncclUint8, r, m->comms[(size_t)k],
                                  m->ctx[(size_t)k]->stream));
       }
     }
-    NCCL_OK(m, ncclGroupEnd());
+    NCCL_OK(m, swa_rccl().GroupEnd());
   } else {
     for (int k = 0; k < world; ++k) {
       if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
@@ -152,13 +152,13 @@ int gather_to_root_v(swa_multi * m, const std::vector<const void *> & src, void 
   swa_ctx * c0 = m->ctx[0];
   std::vector<uint64_t> at((size_t)world + 1, 0);
   for (int r = 0; r < world; ++r) { at[(size_t)r + 1] = at[(size_t)r] + count[(size_t)r]; }
-  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupStart()); }
+  if (!m->comms.empty()) { NCCL_OK(m, swa_rccl().GroupStart()); }
   for (int r = 0; r < world; ++r) {
     if (count[(size_t)r] == 0) { continue; }
     char * recv = static_cast<char *>(dst) + at[(size_t)r] * bytes_per;
     if (!m->comms.empty() && r != 0) {
-      NCCL_OK(m, ncclSend(src[(size_t)r], count[(size_t)r] * bytes_per, ncclUint8, 0, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
-      NCCL_OK(m, ncclRecv(recv, count[(size_t)r] * bytes_per, ncclUint8, r, m->comms[0], c0->stream));
+      NCCL_OK(m, swa_rccl().Send(src[(size_t)r], count[(size_t)r] * bytes_per, ncclUint8, 0, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
+      NCCL_OK(m, swa_rccl().Recv(recv, count[(size_t)r] * bytes_per, ncclUint8, r, m->comms[0], c0->stream));
     } else {
       if (hipSetDevice(c0->device) != hipSuccess ||
           hipMemcpyAsync(recv, src[(size_t)r], count[(size_t)r] * bytes_per, hipMemcpyDefault, c0->stream) != hipSuccess) {
@@ -166,7 +166,7 @@ int gather_to_root_v(swa_multi * m, const std::vector<const void *> & src, void 
       }
     }
   }
-  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupEnd()); }
+  if (!m->comms.empty()) { NCCL_OK(m, swa_rccl().GroupEnd()); }
   for (int k = 0; k < world; ++k) {
     if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
       return fail(m, SWA_E_DEVICE, "synchronising the exchange failed");
@@ -198,9 +198,10 @@ extern "C" int swa_multi_create(const int * devices, int ndevices, swa_multi ** 
   const std::set<int> distinct(m->devices.begin(), m->devices.end());
   const char * force = getenv("SWARM_AMD_FORCE_RCCL");       // test hook: RCCL even for a single rank
   if ((int)distinct.size() == ndevices && (ndevices > 1 || (force != nullptr && force[0] == '1'))) {
+    if (!swa_rccl().error.empty()) { m->err = swa_rccl().error; return SWA_E_DEVICE; }
     m->comms.resize((size_t)ndevices);
-    const ncclResult_t r = ncclCommInitAll(m->comms.data(), ndevices, m->devices.data());
-    if (r != ncclSuccess) { m->comms.clear(); m->err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return SWA_E_DEVICE; }
+    const ncclResult_t r = swa_rccl().CommInitAll(m->comms.data(), ndevices, m->devices.data());
+    if (r != ncclSuccess) { m->comms.clear(); m->err = std::string("ncclCommInitAll: ") + swa_rccl().GetErrorString(r); return SWA_E_DEVICE; }
   }
   return SWA_OK;
 }
@@ -215,7 +216,7 @@ extern "C" void swa_multi_destroy(swa_multi * m) {
     swa_release(m->routed_counts[r]);
     swa_release(m->inbox[r]);
   }
-  for (auto & c : m->comms) { (void)ncclCommDestroy(c); }
+  for (auto & c : m->comms) { (void)swa_rccl().CommDestroy(c); }
   for (auto * c : m->ctx) { swa_ctx_destroy(c); }
   delete m;
 }
@@ -267,7 +268,7 @@ static int routed_index_build(swa_multi * m, std::vector<int> & dup, bool * rout
     rc = swa_reserve(c, m->inbox[(size_t)r], ((uint64_t)m0[(size_t)r] + m1[(size_t)r] + 1) * sizeof(uint32_t));
     if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
   }
-  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupStart()); }
+  if (!m->comms.empty()) { NCCL_OK(m, swa_rccl().GroupStart()); }
   for (int r = 0; r < world; ++r) {
     uint64_t at[2] = {0, m0[(size_t)r]};
     for (int s2 = 0; s2 < world; ++s2) {
@@ -279,8 +280,8 @@ static int routed_index_build(swa_multi * m, std::vector<int> & dup, bool * rout
         uint32_t * dst = static_cast<uint32_t *>(m->inbox[(size_t)r].ptr) + at[index];
         at[index] += count;
         if (!m->comms.empty()) {
-          NCCL_OK(m, ncclSend(src, count, ncclUint32, r, m->comms[(size_t)s2], m->ctx[(size_t)s2]->stream));
-          NCCL_OK(m, ncclRecv(dst, count, ncclUint32, s2, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
+          NCCL_OK(m, swa_rccl().Send(src, count, ncclUint32, r, m->comms[(size_t)s2], m->ctx[(size_t)s2]->stream));
+          NCCL_OK(m, swa_rccl().Recv(dst, count, ncclUint32, s2, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
         } else {
           if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess ||
               hipMemcpyAsync(dst, src, (size_t)count * sizeof(uint32_t), hipMemcpyDefault, m->ctx[(size_t)r]->stream) != hipSuccess) {
@@ -290,7 +291,7 @@ static int routed_index_build(swa_multi * m, std::vector<int> & dup, bool * rout
       }
     }
   }
-  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupEnd()); }
+  if (!m->comms.empty()) { NCCL_OK(m, swa_rccl().GroupEnd()); }
   for (int k = 0; k < world; ++k) {
     if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
       return fail(m, SWA_E_DEVICE, "synchronising the exchange of the routed id lists failed");
@@ -419,12 +420,12 @@ extern "C" int swa_multi_d1_fastidious(swa_multi * m, const uint8_t * is_light, 
   if (world == 1 && m->comms.empty()) { return SWA_OK; }
   // element-wise minimum of the ranks' graft_cand arrays, which are still in HBM (d_graft)
   if (!m->comms.empty()) {
-    NCCL_OK(m, ncclGroupStart());
+    NCCL_OK(m, swa_rccl().GroupStart());
     for (int r = 0; r < world; ++r) {
-      NCCL_OK(m, ncclAllReduce(m->ctx[(size_t)r]->d_graft.ptr, m->ctx[(size_t)r]->d_graft.ptr, n, ncclUint32, ncclMin, m->comms[(size_t)r],
+      NCCL_OK(m, swa_rccl().AllReduce(m->ctx[(size_t)r]->d_graft.ptr, m->ctx[(size_t)r]->d_graft.ptr, n, ncclUint32, ncclMin, m->comms[(size_t)r],
                                m->ctx[(size_t)r]->stream));
     }
-    NCCL_OK(m, ncclGroupEnd());
+    NCCL_OK(m, swa_rccl().GroupEnd());
   } else {
     swa_ctx * c0 = m->ctx[0];
     if (hipSetDevice(c0->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
@@ -495,7 +496,7 @@ extern "C" int swa_multi_dn_graph(swa_multi * m, int no_cluster_breaking, uint64
   if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c0)); }
   auto * keys = static_cast<unsigned long long *>(m->gathered[0].ptr);
   auto * vals = static_cast<uint32_t *>(m->links[0].ptr);
-  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupStart()); }
+  if (!m->comms.empty()) { NCCL_OK(m, swa_rccl().GroupStart()); }
   for (int r = 0; r < world; ++r) {
     swa_ctx * c = m->ctx[(size_t)r];
     const uint64_t cnt = c->dn_edges;
@@ -503,10 +504,10 @@ extern "C" int swa_multi_dn_graph(swa_multi * m, int no_cluster_breaking, uint64
     const auto * k_src = static_cast<const unsigned long long *>(c->d_dn_keys.ptr) + c->dn_work;
     const auto * v_src = static_cast<const uint32_t *>(c->d_dn_vals.ptr) + c->dn_work;
     if (!m->comms.empty() && r != 0) {
-      NCCL_OK(m, ncclSend(k_src, cnt, ncclUint64, 0, m->comms[(size_t)r], c->stream));
-      NCCL_OK(m, ncclRecv(keys + at[(size_t)r], cnt, ncclUint64, r, m->comms[0], c0->stream));
-      NCCL_OK(m, ncclSend(v_src, cnt, ncclUint32, 0, m->comms[(size_t)r], c->stream));
-      NCCL_OK(m, ncclRecv(vals + at[(size_t)r], cnt, ncclUint32, r, m->comms[0], c0->stream));
+      NCCL_OK(m, swa_rccl().Send(k_src, cnt, ncclUint64, 0, m->comms[(size_t)r], c->stream));
+      NCCL_OK(m, swa_rccl().Recv(keys + at[(size_t)r], cnt, ncclUint64, r, m->comms[0], c0->stream));
+      NCCL_OK(m, swa_rccl().Send(v_src, cnt, ncclUint32, 0, m->comms[(size_t)r], c->stream));
+      NCCL_OK(m, swa_rccl().Recv(vals + at[(size_t)r], cnt, ncclUint32, r, m->comms[0], c0->stream));
     } else {
       if (hipSetDevice(c0->device) != hipSuccess ||
           hipMemcpyAsync(keys + at[(size_t)r], k_src, cnt * sizeof(uint64_t), hipMemcpyDefault, c0->stream) != hipSuccess ||
@@ -515,7 +516,7 @@ extern "C" int swa_multi_dn_graph(swa_multi * m, int no_cluster_breaking, uint64
       }
     }
   }
-  if (!m->comms.empty()) { NCCL_OK(m, ncclGroupEnd()); }
+  if (!m->comms.empty()) { NCCL_OK(m, swa_rccl().GroupEnd()); }
   for (int k = 0; k < world; ++k) {
     if (hipSetDevice(m->devices[(size_t)k]) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)k]->stream) != hipSuccess) {
       return fail(m, SWA_E_DEVICE, "synchronising the exchange of the graph failed");

@@ -83,6 +83,32 @@ def test_hostdb_line_shapes_fuzz(tmp_path, seed):
     assert [hdb.header(i) for i in range(db.n)] == db.headers
 
 
+def test_hostdb_db_order_of_a_large_file_sorted_on_several_threads(tmp_path):
+    """Above 100 000 entries and 4 MB of text the reader parses on several threads and orders the entries with its
+    sample sort (fasta_db.cpp) on 16-byte records whose abundance saturates at 32 bits: abundance descending, then
+    header bytes ascending (src/db.cc:388-413).  Many ties on the abundance, headers that agree in their first
+    8 bytes (decided by strcmp), and abundances beyond 32 bits (decided through the entries)."""
+    rng = np.random.default_rng(11)
+    n = 150_000
+    abund = np.maximum(1, (1.0 / rng.random(n) ** 1.5).astype(np.int64) % 50)
+    abund[rng.integers(0, n, 6)] = [2 ** 32 - 1, 2 ** 32, 2 ** 32 + 5, 2 ** 40, 2 ** 32 + 5, 2 ** 33]
+    names = [f"amplicon{int(x):07d}" if i % 3 else f"a{int(x)}" for i, x in enumerate(rng.permutation(n))]
+    seqs = rng.integers(0, 4, size=(n, 40), dtype=np.uint8)
+    text = "".join(f">{names[i]}_{int(abund[i])}\n{''.join('ACGT'[c] for c in seqs[i])}\n" for i in range(n))
+    assert len(text) > 8 << 20
+    fa = tmp_path / "large.fa"
+    fa.write_text(text)
+    hdb = HostDb(fa)
+    want = sorted(range(n), key=lambda i: (-int(abund[i]), f"{names[i]}_{int(abund[i])}".encode()))
+    assert hdb.n == n
+    assert [hdb.header(k) for k in range(0, n, 997)] == [f"{names[i]}_{int(abund[i])}".encode() for i in want[::997]]
+    assert np.array_equal(hdb.abundance, np.array([int(abund[i]) for i in want], dtype=np.uint64))
+    got_names = [hdb.header(k) for k in range(n)]
+    assert got_names == [f"{names[i]}_{int(abund[i])}".encode() for i in want]
+    first_word = np.array([sum(int(c) << (2 * j) for j, c in enumerate(seqs[i][:32])) for i in want[:2000]], dtype=np.uint64)
+    assert np.array_equal(hdb.seqs[hdb.seq_off[:2000].astype(np.int64)], first_word)
+
+
 def test_hostdb_usearch_and_append_abundance():
     hdb = HostDb(G / "d1_usearch.fasta", usearch_abundance=True, append_abundance=2)
     db = S.build_db([(h, s) for h, s in S.read_fasta(G / "d1_short.fasta")])
