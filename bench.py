@@ -18,17 +18,25 @@ At N = 1 the same run also measures, after the timed region (none of it enters `
   config.configs1 / configs2 / configs3   BASELINE configs[1..3]
   config.skewed / config.heavy_tail        the headline step on conserved flanks / on Zipf-sized families
   config.d1_x400                           the d=1 step on 1 M amplicons of 400 bp
-  config.whole_run                         FASTA -> -o through the drop-in command line, 1 M (md5 vs the reference) and 10 M
-  config.host_seam_ms                      swa_db_upload + index + swa_d1_network from / to host buffers (PCIe inclusive)
+  whole_run (top level)                    FASTA -> -o through the drop-in command line, 1 M (md5 vs the reference) and 10 M
+  host_seam_ms (top level)                 swa_db_upload + index + swa_d1_network from / to host buffers (PCIe inclusive)
+  first_step_ms (top level)                the first index build + network of a fresh context on a resident database (what a real
+                                           run pays once: lines, lengths, ranks, the guard's second opinion) beside the repeated step
+  configs2 / configs3 (top level)          the rates of config.configs2 / config.configs3 the metric names (q-gram comparisons/s, aligned pairs/s)
   roofline.traffic / roofline.kernels      HBM bytes and VALU instructions per kernel from nested rocprofv3 --pmc passes,
                                            corrected per access pattern as calibrated (profiles/r03/ubench_ceilings_and_pmc_calibration.json)
   roofline.ceilings                        tools/ubench_lines on this box: streaming copy, random lines/s, atomics/s, VALU issue
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     — for the dominant kernel (by time) of the step: its algorithmic bytes / its duration (HIP events on
-                   the launch stream) against the 8 TB/s HBM peak, and — since that kernel is bound by VALU issue, not by
-                   HBM — its instruction rate against the measured VALU ceiling; the same per kernel group; the step as
-                   a whole; SURVEY.md 8(d)'s figure kept as reference_equivalent_rate.
+  "roofline"     — for the dominant kernel (by time) of the step, by the resource that BINDS it.  A pair kernel is bound by
+                   VALU issue: bound "valu", achieved = its VALU wave-instructions (SQ_INSTS_VALU of a nested rocprofv3
+                   --pmc pass) / its duration (HIP events on the launch stream), peak = the guide's issue rate
+                   (256 CUs x 4 SIMDs x 1/2 a cycle x 2.4 GHz = 1.23e12 wave-instr/s), the ceiling tools/ubench_lines measures on
+                   this box beside it (peak_measured); roofline.hbm = the HBM view of the same kernel on COUNTER bytes
+                   (and on its algorithmic bytes).  Without the counter passes (--no-extras) the object falls back to the
+                   HBM view on algorithmic bytes.  The same per kernel group (kernels), the step as a whole (step,
+                   step_traffic_over_minimum = measured bytes / (64 n + 12 e + 8 n)); SURVEY.md 8(d)'s figure — the
+                   reference's probing loop, which this route never performs — kept as reference_equivalent_rate.
   "cpu_baseline" — the unmodified reference (oracle/_ref/swarm, kind "reference") timed on this box's host cores on a
                    bounded sample (1 M); cpu_baseline_10M: the same on the metric's own 10 M set, once.
 """
@@ -51,6 +59,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU issue peak of the chip, same guide ("Wave scheduling": 4 SIMD-32 per CU, a 64-lane wave issues each VALU instruction
+# over 2 cycles): 256 CUs x 4 SIMDs x 0.5 wave-instructions a cycle x 2.4 GHz
+VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 0.5 * 2.4e9
 
 
 def algorithmic_bytes(seqlen: np.ndarray, hits: int) -> float:
@@ -238,6 +249,43 @@ def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, f
                                 "plain_kernel_and_table": t8[0] + t8[1], "plain_kernel_in_network": max(0.0, k - st[3] - st[4])},
             # (SURVEY 8(d) bytes — the reference's probing loop — over the step's wall time: an equivalent rate, see roofline)
             "reference_equivalent_GBs": abytes / (elapsed / steps) / 1e9}
+
+
+def first_step(torch, dev, device_index: int, args, n: int) -> dict:
+    """What a real run pays ONCE: the first index build + network on a database that has just
+    arrived in HBM — k_lines_build, the lengths / anchor sample / abundance ranks, the guard's second opinion
+    (k_guard_db, k_guard_records) and the step itself — next to the same step repeated.  Code objects are loaded (this
+    process has run the step before), buffers are NOT: a fresh context allocates everything inside the timed call."""
+    from swarm_amd import Context, HostDb
+    hdb = HostDb(gen_fasta(n, args.length, args.seed))
+
+    def to_dev(a: np.ndarray, as_dtype):
+        return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
+
+    t_seqs = to_dev(np.concatenate([hdb.seqs, np.zeros(2, dtype=np.uint64)]), np.int64)
+    t_off, t_len, t_ab = to_dev(hdb.seq_off, np.int64), to_dev(hdb.seqlen, np.int32), to_dev(hdb.abundance, np.int64)
+    cap = 8 * hdb.n
+    d_offsets = torch.zeros(hdb.n + 1, dtype=torch.int64, device=dev)
+    d_nb = torch.zeros(cap, dtype=torch.int32, device=dev)
+    firsts, repeats = [], []
+    for _ in range(3):
+        ctx = Context(device_index, torch.cuda.current_stream(dev).cuda_stream)
+        ctx.attach_db(t_seqs, t_off, t_len, t_ab, hdb.longest)
+        ms = []
+        for it in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            assert not ctx.d1_index_build()
+            ctx.d1_network_device(d_offsets, d_nb, cap, False, 0, hdb.n)
+            torch.cuda.synchronize(dev)
+            ms.append(1e3 * (time.perf_counter() - t0))
+        firsts.append(ms[0])
+        repeats.append(min(ms[1:]))
+        ctx.close()
+    return {"first_step_ms": round(min(firsts), 3), "repeated_step_ms": round(min(repeats), 3), "first_step_ms_all": [round(x, 3) for x in firsts],
+            "what": f"{hdb.n} x {args.length} bp resident in HBM, fresh context: first swa_d1_index_build + swa_d1_network_device "
+                    "(buffer allocation, k_lines_build, lengths, anchor sample, abundance ranks, guard second opinion, one step) "
+                    "against the same two calls repeated; best of 3 contexts, wall clock around synchronised calls"}
 
 
 def md5_of(path) -> str:
@@ -779,6 +827,7 @@ def main() -> None:
         # 0.08 ms at 10 M — profiles/r04/*kernel_stats*.csv; both partitions stay in `kernels` and in `step`)
         single = [g for g in ("keys", "groups", "pairs0", "pairs1", "csr_rows") if g in kernels]
         dominant = max(single, key=lambda g: kernels[g]["ms"]) if single else None
+        largest_group = max(kernels, key=lambda g: kernels[g]["ms"]) if kernels else None
         names = {"keys": "k_keys", "partition_keys": "k_part_hist / k_flat_* / k_part_scatter over the key records", "groups": "k_group1",
                  "partition_links": "k_part_hist / k_flat_* / k_part_scatter over the links",
                  "pairs0": "k_d1_group_pairs<0> (prefix groups)", "pairs1": "k_d1_group_pairs<1> (suffix groups)", "csr_rows": "k_csr_bucket"}
@@ -787,6 +836,9 @@ def main() -> None:
             roof = {"bound": "hbm", "kernel": names[dominant] + ": the kernel with the largest share of the step's time",
                     "achieved": dk["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dk["frac_of_hbm_peak"], "traffic": None,
                     "algorithmic_bytes_per_launch": dk["algorithmic_bytes"], "avg_kernel_ms": dk["ms"],
+                    "dominant_group": dominant, "largest_group_including_multi_launch": largest_group,
+                    "largest_group_note": "partition_keys / partition_links are 6 / 12 short launches each (their largest single launch is shorter "
+                                          "than the dominant kernel); they are graded in `kernels` and in `step`",
                     "kernels": kernels,
                     "step": {"ms": step_kernel_ms, "algorithmic_bytes": sum(model.values()),
                              "GB/s": sum(model.values()) / (step_kernel_ms * 1e-3) / 1e9,
@@ -872,6 +924,7 @@ def main() -> None:
                              ("d1_x460", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 460}), 1_000_000, 5)),
                              ("mixed_lengths", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 0, 0.0, True)),
                              ("host_seam_ms", lambda: host_seam(args, n_total)),
+                             ("first_step_ms", lambda: first_step(torch, dev, device_index, args, n_total)),
                              ("whole_run", lambda: whole_run(args, n_total, ref_md5, sample_n)),
                              ("configs2", lambda: config2_fastidious(args, args.per_gpu)),
                              ("configs3", lambda: config3_dn(args, 1_000_000, 400, 3))):
@@ -888,7 +941,7 @@ def main() -> None:
             if t is not None and "kernels" in out["roofline"]:
                 per = t["per_kernel_group"]
                 out["roofline"]["traffic_detail"] = t
-                dom = max((g for g in out["roofline"]["kernels"] if not g.startswith("partition")), key=lambda g: out["roofline"]["kernels"][g]["ms"])
+                dom = out["roofline"].get("dominant_group") or max(out["roofline"]["kernels"], key=lambda g: out["roofline"]["kernels"][g]["ms"], default=None)
                 if "partition" in per:                          # (split over the two partitions by their algorithmic bytes)
                     kk = out["roofline"]["kernels"]
                     both = sum(kk[g]["algorithmic_bytes"] for g in ("partition_keys", "partition_links") if g in kk)
@@ -928,6 +981,49 @@ def main() -> None:
                                                                "(tools/ubench_lines): VALU wave-instructions/s for the pair kernels, float4 copy rate for the streaming kernels")
                 out["roofline"]["step"]["hbm_bytes_measured"] = t["hbm_bytes_per_step"]
                 out["roofline"]["step"]["traffic_over_algorithmic"] = t["hbm_bytes_per_step"] / out["roofline"]["step"]["algorithmic_bytes"]
+                # what the PROBLEM needs: every line read once, the CSR written once
+                minimum = 64.0 * count + 12.0 * hits_seen[0] + 8.0 * count
+                out["roofline"]["step"]["minimum_bytes"] = minimum
+                out["roofline"]["step_traffic_over_minimum"] = t["hbm_bytes_per_step"] / minimum
+                out["roofline"]["step_traffic_over_minimum_note"] = "measured HBM bytes of one step / (64 n lines + 12 e CSR targets and link reads + 8 n offsets)"
+                # The headline object says what BINDS the dominant kernel.  A pair kernel is bound by VALU
+                # issue: achieved = its VALU wave-instructions a second (SQ_INSTS_VALU / its HIP-event duration), peak = the
+                # guide's issue rate; the HBM view of the same kernel — on COUNTER bytes — stays beside it under `hbm`.
+                rec = out["roofline"]["kernels"].get(dom) if dom else None
+                if rec is not None and "hbm_bytes_measured" in rec:
+                    counter_gbs = rec["hbm_bytes_measured"] / (rec["ms"] * 1e-3) / 1e9
+                    hbm_view = {"bound": "hbm", "achieved": counter_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": counter_gbs / HBM_PEAK_GBS,
+                                "traffic": rec["hbm_bytes_measured"], "bytes": "FETCH_SIZE + WRITE_SIZE of this kernel, corrected as the guide prescribes",
+                                "algorithmic_bytes": rec["algorithmic_bytes"], "algorithmic_GB/s": rec["GB/s"], "algorithmic_frac": rec["frac_of_hbm_peak"]}
+                    if dom.startswith("pairs") and rec.get("valu_wave_instructions_per_s"):
+                        rate = rec["valu_wave_instructions_per_s"]
+                        out["roofline"].update({"bound": "valu", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_S, "unit": "wave-instr/s",
+                                                "frac": rate / VALU_PEAK_WAVE_INSTR_S,
+                                                "valu_wave_instructions_per_launch": rec["valu_wave_instructions"],
+                                                "bound_note": "integer VALU issue: the pair test is v_xor / v_ffbl / v_ffbh / v_min chains over packed words in "
+                                                              "registers; its line fetches (hbm.frac) leave the memory system mostly idle"})
+                        if ceil is not None:
+                            meas = max((ceil.get(k, {}).get("rate") or 0.0) for k in ("valu_3op", "valu_simple")) or None
+                            if meas:
+                                out["roofline"]["peak_measured"] = meas
+                                out["roofline"]["frac_of_measured_ceiling"] = rate / meas
+                        out["roofline"]["hbm"] = hbm_view
+                    else:
+                        out["roofline"].update({"achieved": counter_gbs, "frac": counter_gbs / HBM_PEAK_GBS,
+                                                "achieved_note": "counter bytes of the dominant kernel / its duration"})
+                        out["roofline"]["hbm"] = hbm_view
+            # what the driver's record keeps is the top level of this line: the numbers a reader of BENCH_rNN.json needs
+            # beside `value` live there, not under config
+            for name in ("whole_run", "host_seam_ms", "first_step_ms"):
+                if name in out["config"]:
+                    out[name] = out["config"].pop(name)
+            c3 = out["config"].get("configs3")
+            if isinstance(c3, dict) and "qgram_comparisons_per_s" in c3:
+                out["configs3"] = {k: c3[k] for k in ("workload", "qgram_comparisons_per_s", "aligned_pairs_per_s", "clustering_seconds",
+                                                      "full_matrix_equivalent_cells_per_s", "banded_cells_per_s") if k in c3}
+            c2 = out["config"].get("configs2")
+            if isinstance(c2, dict) and "pipeline_total_s" in c2:
+                out["configs2"] = {k: c2[k] for k in ("workload", "pipeline_total_s", "value", "unit", "counters_equal_reference_log") if k in c2}
         elif world == 1 and not sim_world and not args.no_cpu_baseline:
             sample_n = min(n_total, 1_000_000)
             out["cpu_baseline"] = cpu_baseline(gen_fasta(sample_n, args.length, args.seed), sample_n, args.length, args.seed)

@@ -918,9 +918,10 @@ static int ensure_db_lengths(swa_ctx * ctx) {
 // Where the work lists of an index lie in its item buffer.  A group of width class c has a member of that class, and all
 // its members are of classes <= c; a group on size list k has at least least[k] members: so list (c, k) holds at most
 // min(pop[c], pop[<= c] / least[k]) groups, and the row tiles of class c (64 members each, of groups of more than 256)
-// number at most pop[<= c] / 64 + pop[<= c] / 257.  A database of one class — the usual one — pays for one class.
+// number at most pop[<= c] / 64 + pop[<= c] / (pair_big + 1), pair_big = the largest group a workgroup takes by pairs
+// (256 unless SWA_D1_PAIR_BIG lowers it).  A database of one class — the usual one — pays for one class.
 static ListRegions list_regions(const swa_ctx * ctx, uint64_t * total_items) {
-  static const uint32_t least[kListKinds] = {2, 5, 9, 17, 33, 65, 257};
+  const uint32_t least[kListKinds] = {2, 5, 9, 17, 33, 65, pair_big_limit() + 1u};
   ListRegions r{};
   uint64_t at = 0, upto = 0;
   for (uint32_t c = 0; c < kWidthClasses; ++c) {
@@ -928,7 +929,7 @@ static ListRegions list_regions(const swa_ctx * ctx, uint64_t * total_items) {
     for (uint32_t k = 0; k < kListKinds; ++k) {
       r.at[c][k] = at;
       uint64_t room = 64;
-      if (ctx->class_pop[c] != 0) { room += k + 1 < kListKinds ? std::min<uint64_t>(ctx->class_pop[c], upto / least[k]) : upto / 64 + upto / 257; }
+      if (ctx->class_pop[c] != 0) { room += k + 1 < kListKinds ? std::min<uint64_t>(ctx->class_pop[c], upto / least[k]) : upto / 64 + upto / least[k]; }
       at += room;
     }
     r.at[c][kListKinds] = at;
@@ -1471,9 +1472,8 @@ static int launch_pairs_tiled(swa_ctx * ctx, int pass, int width, int nwin, int 
 }
 
 // workgroups of k_d1_group_pairs<*, W, *> that one CU holds at a time (registers and LDS: the occupancy API; 1..8)
-static int pair_blocks_per_cu(uint32_t cls) {
-  static int cached[kWidthClasses] = {};
-  int & c = cached[cls];
+static int pair_blocks_per_cu(swa_ctx * ctx, uint32_t cls) {
+  int & c = ctx->pair_blocks[cls];                        // (per context: swa_multi runs one context per GPU on its own host thread)
   if (c == 0) {
     int nb = 0;
     const hipError_t e = cls == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_d1_group_pairs<0, 5, 1>, kThreads, 0)
@@ -1566,7 +1566,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
       // Bundles per visit of a work counter: 4 where every wave has dozens of bundles to go through (10 M amplicons: the counters
       // are what limits then — 0.78 / 1.21 / 2.2 ms with 4 / 2 / 1), fewer where the waves' shares are what limits (1 M: 2.4
       // bundles a wave — 0.072 / 0.049 / 0.037 ms a pass with 4 / 2 / 1)
-      const int pgrid = ctx->num_cus * pair_blocks_per_cu(cls);
+      const int pgrid = ctx->num_cus * pair_blocks_per_cu(ctx, cls);
       a.batch = pair_batch;
       if (pair_batch == 0) {
         uint64_t bundles = 0;
@@ -2094,7 +2094,9 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
         // (the streaming index serves any query range; it is rebuilt when the owner changed)
         swa_t0(ctx, 7);
         SWA_TRY(launch_abundance_rank(ctx));
-        SWA_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, 0, sizeof(uint32_t), ctx->stream));
+        // ([2] duplicates [3] seeds left to the plain kernel [4] oversized groups [5] their members: the previous owner's
+        // values must not survive into this owner's build — [3] is only ever set, [4] / [5] accumulate)
+        SWA_HIP(ctx, hipMemsetAsync(static_cast<uint32_t *>(ctx->d_flags.ptr) + 2, 0, 5 * sizeof(uint32_t), ctx->stream));
         SWA_TRY(build_stream_index(ctx, 0, 0));
         swa_t1(ctx, 7);
         // The index of another owner (swa_d1_set_ownership after the build): the member table and its Bloom filter hold the

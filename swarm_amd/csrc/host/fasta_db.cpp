@@ -307,9 +307,20 @@ void run_parallel(unsigned threads, F && fn) {
   for (auto & th : pool) { th.join(); }
 }
 
+struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the phase times to stderr
+  bool on = std::getenv("SWARM_AMD_DB_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char * what) {
+    if (!on) { return; }
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[hostdb] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 // sorts a[0, n) by `less` (a strict weak order) on `threads` threads; tmp[0, n) is scratch; the result is in a
 template <class Rec, class Less>
-void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less less) {
+void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less less, PhaseTimer * timer = nullptr) {
   if (threads <= 1 || n < 100000) { std::sort(a, a + n, less); return; }
   const unsigned buckets = std::min<unsigned>(threads * 8u, 1024u);
   constexpr uint64_t kOver = 64;                            // sampled records per bucket
@@ -321,6 +332,7 @@ void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less
   for (unsigned b = 1; b < buckets; ++b) { split[b - 1] = sample[(uint64_t)b * kOver]; }
   std::vector<uint64_t> place((size_t)threads * buckets, 0);
   swa_vec<uint16_t> where(n);
+  if (timer != nullptr) { timer->lap("  sort: sample + splitters"); }
   run_parallel(threads, [&](unsigned t) {
     uint64_t * c = &place[(size_t)t * buckets];
     for (uint64_t i = n * t / threads; i < n * (t + 1) / threads; ++i) {
@@ -340,10 +352,12 @@ void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less
     for (unsigned t = 0; t < threads; ++t) { const uint64_t c = place[(size_t)t * buckets + b]; place[(size_t)t * buckets + b] = at; at += c; }
   }
   start[buckets] = at;
+  if (timer != nullptr) { timer->lap("  sort: buckets found"); }
   run_parallel(threads, [&](unsigned t) {
     uint64_t * c = &place[(size_t)t * buckets];
     for (uint64_t i = n * t / threads; i < n * (t + 1) / threads; ++i) { tmp[c[where[i]]++] = a[i]; }
   });
+  if (timer != nullptr) { timer->lap("  sort: records filed"); }
   std::atomic<unsigned> next{0};
   run_parallel(threads, [&](unsigned) {
     for (;;) {
@@ -353,22 +367,11 @@ void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less
       std::copy(tmp + start[b], tmp + start[b + 1], a + start[b]);
     }
   });
+  if (timer != nullptr) { timer->lap("  sort: buckets sorted"); }
 }
 
 }  // namespace
 
-namespace {
-struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the phase times to stderr
-  bool on = std::getenv("SWARM_AMD_DB_TIMING") != nullptr;
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  void lap(const char * what) {
-    if (!on) { return; }
-    const auto now = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[hostdb] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-    t = now;
-  }
-};
-}  // namespace
 
 extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t append_abundance, int check_dup_seqs,
                                      swa_hostdb ** out) {
@@ -644,18 +647,22 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     // order is a strict total order (identifiers are unique), so the result equals std::sort's.  (r04 used libstdc++'s
     // parallel multiway merge sort on 32-byte records: 151 ms at 10 M amplicons on 64 threads, the largest phase of the
     // reader.)
+    timer.lap("  sort: records made, order checked");
     swa_vec<SortRec> other(n);
-    parallel_sample_sort(recs.data(), other.data(), n64, threads, less);
+    timer.lap("  sort: second buffer");
+    parallel_sample_sort(recs.data(), other.data(), n64, threads, less, &timer);
   }
   auto order = [&](uint64_t k) { return recs[k].entry; };
   timer.lap("sort");
   // ---- contiguous SoA in sorted order (offsets by prefix sum, copies in parallel)
+  timer.lap("  (sort ends)");
   db->seq_off.resize((size_t)n + 1);
   db->seqlen.resize(n);
   db->abundance.resize(n);
   db->hdr_off.resize((size_t)n + 1);
   db->ab_start.resize(n);
   db->ab_end.resize(n);
+  timer.lap("  gather: index arrays sized");
   uint64_t woff = 0, hoff = 0;
   {
     // offsets by a two-level prefix sum: per-thread block totals, then each thread fills its block
@@ -688,8 +695,10 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   }
   db->seq_off[n] = woff;
   db->hdr_off[n] = hoff;
+  timer.lap("  gather: offsets");
   db->seqs.resize(woff + 1);
   db->headers.resize(hoff + 1);
+  timer.lap("  gather: arrays sized");
   run_parallel(threads, [&](unsigned t) {
     // the entries, their words and their headers are three random reads per amplicon: keep a
     // few of them in flight

@@ -343,6 +343,7 @@ int main(int argc, char ** argv) {
     });
   }
 
+  if (std::getenv("SWARM_AMD_SERIAL_INIT") != nullptr && early.joinable()) { early.join(); stamp("(experiment) GPU start-up waited for before the read"); }
   // ---- read the database (seam L2, host side)
   swa_hostdb * db = nullptr;
   int rc = swa_hostdb_read_fasta(o.input.c_str(), o.usearch ? 1 : 0, o.append_abundance, o.differences > 1 ? 1 : 0, &db);

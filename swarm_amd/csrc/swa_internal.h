@@ -149,6 +149,7 @@ struct swa_ctx {
 
   // the d = 1 network kept in d_offsets_tmp / d_nb_tmp (swa_d1_network_resident) and its clustering (cluster_gpu.hip)
   bool csr_ready = false;
+  int pair_blocks[4] = {};                      // workgroups of k_d1_group_pairs a CU holds, per width class (0: not asked yet)
   bool g1_lds_opt_in = false;                  // k_group1's dynamic-LDS attribute has been set on this context's device
   uint32_t part_lds_opt_in = 0;    // ... and the wide-tile forms of k_part_scatter (one bit each)
   bool csr_has_diffs = false;                 // the resident network is a d >= 2 graph: one byte of differences per link behind the neighbours
