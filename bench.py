@@ -458,21 +458,18 @@ def whole_run(args, n: int, ref_out_md5: str | None, sample_n: int) -> dict:
         for size in (sample_n, n):
             fa = gen_fasta(size, args.length, args.seed)
             best = None
-            for _ in range(2):
+            runs = []
+            for _ in range(3):
+                time.sleep(1.0)                              # (the previous process's GPU-side teardown is the kernel's, and asynchronous)
                 t0 = time.perf_counter()
                 subprocess.run([str(exe), "-d", "1", "-o", f"{tmp}/o", "-l", "/dev/null", str(fa)], check=True)
-                dt = time.perf_counter() - t0
-                best = dt if best is None or dt < best else best
-            res[f"n{size}"] = {"seconds": round(best, 3), "amplicons_per_s": size / best}
-            # opt-in: the front process returns when the outputs are closed, the worker's teardown is nobody's wait
-            t0 = time.perf_counter()
-            subprocess.run([str(exe), "-d", "1", "-o", f"{tmp}/o2", "-l", "/dev/null", str(fa)], check=True, env=dict(os.environ, SWARM_AMD_DETACHED_EXIT="1"))
-            res[f"n{size}"]["seconds_detached_exit"] = round(time.perf_counter() - t0, 3)
-            time.sleep(0.5)                                  # (let that worker finish before the next timing)
+                runs.append(time.perf_counter() - t0)
+            best = min(runs)
+            res[f"n{size}"] = {"seconds": round(best, 3), "amplicons_per_s": size / best, "all_runs_seconds": [round(x, 3) for x in runs]}
             if size == sample_n and ref_out_md5 is not None:
                 res[f"n{size}"]["output_md5_equals_reference"] = md5_of(f"{tmp}/o") == ref_out_md5
-    res["what"] = ("swarm_amd/bin/swarm -d 1 -o as ONE process (the default): process start, FASTA read + sort + pack, upload, index, network, "
-                   "agglomeration on the GPU, write, process exit; seconds_detached_exit: with SWARM_AMD_DETACHED_EXIT=1")
+    res["what"] = ("swarm_amd/bin/swarm -d 1 -o, one process: process start, FASTA read + sort + pack, upload, index, network, "
+                   "agglomeration on the GPU, write, process exit; best of 3 runs started one second apart")
     return res
 
 

@@ -178,6 +178,12 @@ int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first
    size.  cap = capacity in entries; SWA_E_CAPACITY / *total as above. */
 int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
                                 uint64_t * d_edge_list, uint64_t cap, uint64_t * total);
+/* The guard (SWA_E_INTERNAL).  The reference's network thread cannot return a partial network
+   (src/algod1.cc:630-670); the three calls above compare the counts their kernels hand to one another and,
+   should they not balance, make everything derived from the uploaded database again and repeat the step ONCE
+   (one line on stderr names the count) before they give up with SWA_E_INTERNAL.  This returns how many steps
+   of this context were repeated that way (0 on every run seen so far). */
+int swa_d1_guard_retries(const swa_ctx * ctx);
 
 /* Introspection used by the parity tests (bit-exact against the oracle): copies to host.
    what: 0 seqhash u64[n] · 1 Bloom bitmap u64[table_size/8] · 2 Zobrist table
@@ -199,6 +205,12 @@ int swa_d1_network_resident(swa_ctx * ctx, int no_cluster_breaking, uint64_t * t
 int swa_d1_network_fetch(swa_ctx * ctx, uint64_t * offsets, uint32_t * neighbours, uint64_t cap);
 int swa_d1_cluster_device(swa_ctx * ctx, uint32_t * swarmid, uint32_t * generation, uint32_t * parent, uint32_t * order,
                           uint32_t * swarm_begin, uint32_t swarm_cap, uint32_t * nswarms);
+/* swarmid / generation / parent may be null in swa_d1_cluster_device: they stay in HBM, and a caller that wants them
+   after all (the reference's -i, -s, -u, -w outputs and --fastidious read ampinfo[].generation / parent,
+   src/algod1.cc:994-1037) fetches them here (any of the three may be null again); valid until the next upload, index
+   build, network or clustering call of the context.  swa_d1_cluster_maxgen: the deepest generation ("Max generations"). */
+int swa_d1_cluster_fetch(swa_ctx * ctx, uint32_t * swarmid, uint32_t * generation, uint32_t * parent);
+uint32_t swa_d1_cluster_maxgen(const swa_ctx * ctx);
 
 /* ---- B2: fastidious second pass ------------------------------------------------- */
 /* is_light[n]: != 0 when the amplicon's swarm has mass < boundary.  light_nt: total

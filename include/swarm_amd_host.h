@@ -112,6 +112,12 @@ int swa_d0_write_structure(const swa_d0_result * res, const swa_hostdb * db, con
 int swa_d0_write_uclust(const swa_d0_result * res, const swa_hostdb * db, const char * path, int usearch_abundance,
                         int64_t append_abundance);
 
+/* ---- the command line (src/swarm.cc:96-124, 269-463, 486-630) ---------------------------
+   `swarm` itself: options, log lines, FASTA in, output files out, exit status; everything above driven the way the
+   reference's main() drives its own functions.  The executable swarm_amd/bin/swarm is a launcher that sets the OpenMP
+   wait policy and calls this (host/launcher.cpp). */
+int swa_cli_main(int argc, char ** argv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,8 +42,8 @@ class DbView(C.Structure):
 
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_d1_anchor_windows", "swa_d1_anchor_width",
-    "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_resident",
-    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device",
+    "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident",
+    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
@@ -447,6 +447,11 @@ class Context:
         self._check(self.lib.swa_d1_network_device(self.h, int(no_cluster_breaking), first, count,
                                                    _ptr(d_offsets), _ptr(d_neighbours), cap, C.byref(total)))
         return int(total.value)
+
+    def d1_guard_retries(self) -> int:
+        """Steps this context repeated because the guard's counts did not balance (swa_d1_guard_retries)."""
+        self.lib.swa_d1_guard_retries.argtypes = [C.c_void_p]
+        return int(self.lib.swa_d1_guard_retries(self.h))
 
     def d1_network_edges_device(self, d_edge_list, cap: int, no_cluster_breaking: bool = False,
                                 first: int = 0, count: int | None = None) -> int:

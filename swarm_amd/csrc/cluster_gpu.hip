@@ -108,6 +108,7 @@ extern "C" int swa_d1_network_resident(swa_ctx * ctx, int no_cluster_breaking, u
   if (!ctx->d1_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network_resident: call swa_d1_index_build first"); }
   const uint32_t n = ctx->db.n;
   ctx->csr_ready = false;
+  ctx->cluster_ready = false;
   SWA_TRY(swa_reserve(ctx, ctx->d_offsets_tmp, ((uint64_t)n + 1) * sizeof(uint64_t)));
   uint64_t cap = std::max<uint64_t>(ctx->d_nb_tmp.bytes / sizeof(uint32_t), 4ull * n + 1024);
   for (;;) {
@@ -143,9 +144,10 @@ extern "C" int swa_d1_network_fetch(swa_ctx * ctx, uint64_t * offsets, uint32_t 
 // swarm_cap + 1 entries: SWA_E_CAPACITY with *nswarms = the number needed when it is too small.
 extern "C" int swa_d1_cluster_device(swa_ctx * ctx, uint32_t * swarmid, uint32_t * generation, uint32_t * parent, uint32_t * order,
                                      uint32_t * swarm_begin, uint32_t swarm_cap, uint32_t * nswarms) {
-  if (ctx == nullptr || swarmid == nullptr || generation == nullptr || parent == nullptr || order == nullptr || nswarms == nullptr) {
-    return SWA_E_ARG;
-  }
+  // (swarmid / generation / parent may be null: they stay in HBM for swa_d1_cluster_fetch — a run that only writes the
+  // swarms, the usual one, never looks at them)
+  if (ctx == nullptr || order == nullptr || nswarms == nullptr) { return SWA_E_ARG; }
+  ctx->cluster_ready = false;
   if (!ctx->csr_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_cluster_device: no resident network (swa_d1_network_resident)"); }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n = ctx->db.n;
@@ -179,7 +181,7 @@ extern "C" int swa_d1_cluster_device(swa_ctx * ctx, uint32_t * swarmid, uint32_t
     uint32_t grew = 0;
     SWA_HIP(ctx, hipMemcpyAsync(&grew, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (grew == 0) { break; }
+    if (grew == 0) { ctx->cluster_maxgen = level - 1; break; }     // (the last level that took somebody in)
   }
   // swarm numbers = rank of the seed among the seeds
   size_t tmp_bytes = 0, need = 0;
@@ -204,9 +206,9 @@ extern "C" int swa_d1_cluster_device(swa_ctx * ctx, uint32_t * swarmid, uint32_t
   uint8_t last_seed = 0;
   SWA_HIP(ctx, hipMemcpyAsync(&last_rank, seed_rank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipMemcpyAsync(&last_seed, is_seed + (n - 1), 1, hipMemcpyDeviceToHost, ctx->stream));
-  SWA_HIP(ctx, hipMemcpyAsync(swarmid, sid, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  SWA_HIP(ctx, hipMemcpyAsync(generation, gen, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  SWA_HIP(ctx, hipMemcpyAsync(parent, par, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (swarmid != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(swarmid, sid, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+  if (generation != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(generation, gen, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+  if (parent != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(parent, par, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
   SWA_HIP(ctx, hipMemcpyAsync(order, ids_out, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipGetLastError());
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -214,5 +216,26 @@ extern "C" int swa_d1_cluster_device(swa_ctx * ctx, uint32_t * swarmid, uint32_t
   if (*nswarms > swarm_cap || swarm_begin == nullptr) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_cluster_device: swarm table too small"); }
   SWA_HIP(ctx, hipMemcpyAsync(swarm_begin, begins, ((uint64_t)*nswarms + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->cluster_ready = true;
   return SWA_OK;
 }
+
+// what swa_d1_cluster_device left in HBM, for the callers that want it after all (-i, -s, -u, -w, --fastidious): swarm,
+// generation and parent of every amplicon; any of the three may be null.  Valid until the next upload, index build,
+// network or clustering call of this context.
+extern "C" int swa_d1_cluster_fetch(swa_ctx * ctx, uint32_t * swarmid, uint32_t * generation, uint32_t * parent) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (!ctx->cluster_ready || !ctx->csr_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_cluster_fetch: no clustering in place (swa_d1_cluster_device)"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = ctx->db.n;
+  const auto * label = static_cast<const uint32_t *>(ctx->d_cluster.ptr);
+  const uint32_t * gen = label + n, * par = gen + n, * sid = par + n;
+  if (swarmid != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(swarmid, sid, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+  if (generation != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(generation, gen, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+  if (parent != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(parent, par, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWA_OK;
+}
+
+// the deepest generation of the clustering in place (what the log calls "Max generations")
+extern "C" uint32_t swa_d1_cluster_maxgen(const swa_ctx * ctx) { return ctx != nullptr && ctx->cluster_ready ? ctx->cluster_maxgen : 0u; }

@@ -194,6 +194,7 @@ static void invalidate(swa_ctx * ctx) {
   ctx->dn_graph_ready = false;
   ctx->dn_shortest = 0;
   ctx->csr_ready = false;
+  ctx->cluster_ready = false;
 }
 
 extern "C" int swa_db_upload(swa_ctx * ctx, const swa_db_view * h) {

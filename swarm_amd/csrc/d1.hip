@@ -1243,7 +1243,11 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   k.nwin = ctx->anchor_w / 32u;
   k.flags = dflags;
   k.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
-  if (const char * e = getenv("SWA_D1_GUARD_TEST")) { k.fault = e[0] == 'm' ? 1u : (e[0] == 'd' ? 2u : 0u); }   // (test hook: a wrong index, on purpose)
+  if (const char * e = getenv("SWA_D1_GUARD_TEST")) {         // (test hook: a wrong index, on purpose; "...-once": only the first build)
+    static int builds = 0;
+    const bool once = strstr(e, "-once") != nullptr;
+    if (!once || builds++ == 0) { k.fault = e[0] == 'm' ? 1u : (e[0] == 'd' ? 2u : 0u); }
+  }
   if (routed) {
     hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(1), 0, ctx->stream, dflags,
                        ctx->db_shortest < minlen ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
@@ -1841,6 +1845,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   if (first > ctx->db.n || count > ctx->db.n - first) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_range: bad range"); }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n = ctx->db.n;
+  ctx->index_first = first; ctx->index_count = count; ctx->index_routed = ctx->route_ids[0] != nullptr;   // (network_run_guarded repeats it)
   ctx->d1_ready = false;
   ctx->csr_ready = false;                                   // (a resident network belongs to the index it was made from)
   ctx->anchor_ready = false;
@@ -2205,6 +2210,31 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
   return SWA_OK;
 }
 
+// The reference cannot fail here (src/algod1.cc:630-670), so a drop-in must not exit where the reference would not: when
+// the guard finds counts that do not balance, everything derived from the uploaded database (lines, lengths, ranks,
+// windows, indexes) is made again and the step repeated — once; which count disagreed goes to stderr.  Only a second
+// disagreement is SWA_E_INTERNAL.  (A routed build's id lists belong to the caller: multi.hip repeats its own exchange.)
+static int network_run_guarded(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count, uint64_t * d_offsets,
+                               uint32_t * d_neighbours, uint64_t * d_edge_list, uint64_t cap, uint64_t * total) {
+  const int rc = network_run(ctx, no_cluster_breaking, first, count, d_offsets, d_neighbours, d_edge_list, cap, total);
+  if (rc != SWA_E_INTERNAL || ctx->index_routed) { return rc; }
+  const std::string first_msg = ctx->err;
+  fprintf(stderr, "swarm-amd: %s; rebuilding the index from the packed database and repeating the step\n", first_msg.c_str());
+  ++ctx->guard_retries;
+  ctx->lines_ready = ctx->props_ready = ctx->windows_ready = ctx->rank_ready = false;
+  ctx->anchor_ready = ctx->stream_index = ctx->member_index = ctx->full_index = false;
+  ctx->guard_index = ctx->guard_keys_done = ctx->guard_keys_pending = false;
+  ctx->stream_extra_bits = 0;
+  int dup = 0;
+  const int rb = swa_d1_index_build_range(ctx, ctx->index_first, ctx->index_count, &dup);
+  if (rb != SWA_OK && rb != SWA_E_DUPLICATES) { return rb; }
+  const int again = network_run(ctx, no_cluster_breaking, first, count, d_offsets, d_neighbours, d_edge_list, cap, total);
+  if (again == SWA_E_INTERNAL) { ctx->err = first_msg + "; after a rebuild: " + ctx->err; }
+  return again;
+}
+
+extern "C" int swa_d1_guard_retries(const swa_ctx * ctx) { return ctx != nullptr ? (int)ctx->guard_retries : 0; }
+
 extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
                                      uint64_t * d_offsets, uint32_t * d_neighbours, uint64_t cap, uint64_t * total) {
   if (ctx == nullptr) { return SWA_E_ARG; }
@@ -2213,7 +2243,7 @@ extern "C" int swa_d1_network_device(swa_ctx * ctx, int no_cluster_breaking, uin
       (d_neighbours == nullptr && cap != 0)) {
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network: bad range or null buffer");
   }
-  return network_run(ctx, no_cluster_breaking, first, count, d_offsets, d_neighbours, nullptr, cap, total);
+  return network_run_guarded(ctx, no_cluster_breaking, first, count, d_offsets, d_neighbours, nullptr, cap, total);
 }
 
 extern "C" int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
@@ -2223,7 +2253,7 @@ extern "C" int swa_d1_network_edges_device(swa_ctx * ctx, int no_cluster_breakin
   if (count == 0 || (uint64_t)first + count > ctx->db.n || d_edge_list == nullptr || total == nullptr) {
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network_edges: bad range or null buffer");
   }
-  return network_run(ctx, no_cluster_breaking, first, count, nullptr, nullptr, d_edge_list, cap, total);
+  return network_run_guarded(ctx, no_cluster_breaking, first, count, nullptr, nullptr, d_edge_list, cap, total);
 }
 
 // multi.hip: the CSR of the whole database from the ranks' link lists as they lie gathered on this device — `lists` runs of

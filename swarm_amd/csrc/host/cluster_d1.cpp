@@ -43,6 +43,17 @@ struct swa_d1_result {
   uint64_t swarmcount_adjusted = 0;
   uint32_t largest = 0, maxgen = 0;
   std::string error;
+  // The clustering made on the GPU (swa_d1_cluster_resident) brings home only what the swarms file needs — the member
+  // order and the swarms' bounds.  swarmid / parent / generation / graft_cand and the per-swarm sums (mass, length,
+  // singletons, deepest generation) are fetched and computed when somebody asks: -i, -s, -u, -w, --fastidious and the
+  // accessors (need_details).  A plain `swarm -d 1 -o` never does.
+  swa_ctx * lazy_ctx = nullptr;
+  const swa_hostdb * lazy_db = nullptr;
+  bool details = true;
+  ~swa_d1_result() {                          // (the big arrays' pages go back on all threads, see hostdb.h)
+    for (auto * v : {&swarmid, &parent, &generation, &order, &graft_cand}) { swa_release_pages(v->data(), v->size() * sizeof(uint32_t)); }
+    swa_release_pages(swarms.data(), swarms.size() * sizeof(Swarm));
+  }
 };
 
 namespace {
@@ -75,6 +86,35 @@ std::vector<uint32_t> output_numbers(const swa_d1_result * r) {
   uint32_t next = 0;
   for (size_t k = 0; k < r->swarms.size(); ++k) { number[k] = next; if (r->swarms[k].attached == 0) { ++next; } }
   return number;
+}
+
+// swarmid / parent / generation from HBM and the sums of every swarm (see swa_d1_result); false when the context that holds
+// them has moved on
+bool need_details(const swa_d1_result * cr) {
+  if (cr->details) { return true; }
+  auto * r = const_cast<swa_d1_result *>(cr);
+  const uint32_t n = r->n;
+  const swa_hostdb * db = r->lazy_db;
+  r->swarmid.resize(n); r->parent.resize(n); r->generation.resize(n);
+  fill_parallel(r->graft_cand, n, (uint32_t)SWA_NO_AMPLICON);
+  if (swa_d1_cluster_fetch(r->lazy_ctx, r->swarmid.data(), r->generation.data(), r->parent.data()) != SWA_OK) {
+    r->error = swa_last_error(r->lazy_ctx);
+    return false;
+  }
+  const auto & gen = r->generation;
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t s = 0; s < (int64_t)r->swarms.size(); ++s) {
+    auto & sw = r->swarms[(size_t)s];
+    for (uint32_t k = sw.begin; k < sw.end; ++k) {
+      const uint32_t a = r->order[k];
+      sw.mass += db->abundance[a];
+      sw.sumlen += db->seqlen[a];
+      if (db->abundance[a] == 1) { ++sw.singletons; }
+      sw.maxgen = std::max(sw.maxgen, gen[a]);
+    }
+  }
+  r->details = true;
+  return true;
 }
 
 }  // namespace
@@ -281,44 +321,33 @@ extern "C" int swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa
     std::fprintf(stderr, "[cluster] %-24s %8.3f ms\n", what, 1000.0 * (now - t_last));
     t_last = now;
   };
-  fill_parallel(r->swarmid, n, (uint32_t)SWA_NO_AMPLICON);
-  fill_parallel(r->parent, n, (uint32_t)SWA_NO_AMPLICON);
-  fill_parallel(r->generation, n, 0u);
-  fill_parallel(r->graft_cand, n, (uint32_t)SWA_NO_AMPLICON);
-  fill_parallel(r->order, n, 0u);
   if (n == 0) { return SWA_OK; }
-  swa_vec<uint32_t> begin;
-  fill_parallel(begin, (size_t)n + 1, 0u);
+  r->order.resize(n);                                       // (every entry is written by the download below)
+  swa_vec<uint32_t> begin((size_t)n + 1);
   lap("result arrays");
   uint32_t nswarms = 0;
-  const int rc = swa_d1_cluster_device(ctx, r->swarmid.data(), r->generation.data(), r->parent.data(), r->order.data(), begin.data(), n,
-                                       &nswarms);
+  const int rc = swa_d1_cluster_device(ctx, nullptr, nullptr, nullptr, r->order.data(), begin.data(), n, &nswarms);
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
   lap("device + download");
-  fill_parallel(r->swarms, nswarms, swa_d1_result::empty_swarm());
-  uint32_t largest = 0, maxgen = 0;
-  const auto & gen = r->generation;
-#pragma omp parallel for schedule(dynamic, 1024) reduction(max : largest) reduction(max : maxgen)
+  r->lazy_ctx = ctx;
+  r->lazy_db = db;
+  r->details = false;
+  r->swarms.resize(nswarms);
+  uint32_t largest = 0;
+#pragma omp parallel for schedule(static) reduction(max : largest)
   for (int64_t s = 0; s < (int64_t)nswarms; ++s) {
     auto & sw = r->swarms[(size_t)s];
+    sw = swa_d1_result::empty_swarm();
     sw.begin = begin[(size_t)s];
     sw.end = begin[(size_t)s + 1];
     sw.seed = r->order[sw.begin];
     sw.size = sw.end - sw.begin;
-    for (uint32_t k = sw.begin; k < sw.end; ++k) {
-      const uint32_t a = r->order[k];
-      sw.mass += db->abundance[a];
-      sw.sumlen += db->seqlen[a];
-      if (db->abundance[a] == 1) { ++sw.singletons; }
-      sw.maxgen = std::max(sw.maxgen, gen[a]);
-    }
     largest = std::max(largest, sw.size);
-    maxgen = std::max(maxgen, sw.maxgen);
   }
   r->largest = largest;
-  r->maxgen = maxgen;
+  r->maxgen = swa_d1_cluster_maxgen(ctx);
   r->swarmcount_adjusted = r->swarms.size();
-  lap("swarm table + sums");
+  lap("swarm table");
   return SWA_OK;
 }
 
@@ -429,12 +458,13 @@ extern "C" void swa_d1_result_summary(const swa_d1_result * r, uint64_t * out4) 
   out4[3] = r->swarms.size();
 }
 
-extern "C" const uint32_t * swa_d1_result_swarmid(const swa_d1_result * r) { return r->swarmid.data(); }
-extern "C" const uint32_t * swa_d1_result_parent(const swa_d1_result * r) { return r->parent.data(); }
-extern "C" const uint32_t * swa_d1_result_generation(const swa_d1_result * r) { return r->generation.data(); }
+extern "C" const uint32_t * swa_d1_result_swarmid(const swa_d1_result * r) { return need_details(r) ? r->swarmid.data() : nullptr; }
+extern "C" const uint32_t * swa_d1_result_parent(const swa_d1_result * r) { return need_details(r) ? r->parent.data() : nullptr; }
+extern "C" const uint32_t * swa_d1_result_generation(const swa_d1_result * r) { return need_details(r) ? r->generation.data() : nullptr; }
 
 // ---- fastidious bookkeeping (src/algod1.cc:1291-1328) -----------------------------------
 extern "C" void swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, uint8_t * is_light, uint64_t * stats5) {
+  (void)need_details(r);
   uint64_t light_swarms = 0, light_amps = 0, light_nt = 0;
   for (const auto & s : r->swarms) {
     const bool light = s.mass < (uint64_t)boundary;
@@ -450,6 +480,7 @@ extern "C" void swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, ui
 
 // ---- grafting (src/algod1.cc:214-241 attach, 274-336 attach_candidates) -----------------
 extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand) {
+  if (!need_details(r)) { return 0; }
   // (parent << 32 | child): sorting the packed pairs is the (parent, child) order of
   // src/algod1.cc:263-271, and a plain integer sort runs on all cores
   const int64_t n64 = (int64_t)r->n;
@@ -527,6 +558,7 @@ extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * d
 
 // -s  (src/algod1.cc:1040-1062): maxgen is printed twice for d = 1
 extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  if (!need_details(r)) { return SWA_E_ARG; }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   for (const auto & s : r->swarms) {
@@ -541,6 +573,7 @@ extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db
 
 // -i  (src/algod1.cc:985-1037)
 extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  if (!need_details(r)) { return SWA_E_ARG; }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   const std::vector<uint32_t> number = output_numbers(r);
@@ -575,6 +608,7 @@ extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb 
 
 // -w  (src/algod1.cc:935-982 + db_fprintseq src/db.cc:925-943)
 extern "C" int swa_d1_write_seeds(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
+  if (!need_details(r)) { return SWA_E_ARG; }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   std::vector<uint32_t> idx(r->swarms.size());
@@ -621,6 +655,7 @@ extern "C" int swa_d1_write_network(const swa_hostdb * db, const uint64_t * offs
 // -u  (src/algod1.cc:849-932): members in swarm order, each aligned against the seed
 extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch,
                                    int64_t append_abundance, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend) {
+  if (!need_details(r)) { return SWA_E_ARG; }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   const std::vector<uint32_t> number = output_numbers(r);

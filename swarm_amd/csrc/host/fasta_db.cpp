@@ -10,6 +10,7 @@
 // 8-byte aligned sequence words (what the GPU wants to stream), instead of the
 // reference's single-threaded getline loop over an interleaved header/sequence blob.
 #include "hostdb.h"
+#include "pool.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -65,6 +66,7 @@ struct Piece {            // what one thread parsed
   uint64_t missing = 0;   // entries without abundance annotation
   uint32_t missing_line = 0;
   std::string missing_hdr;
+  void swap_buffers(Piece & other) { entries.swap(other.entries); hdr_pool.swap(other.hdr_pool); words.swap(other.words); }
 };
 
 struct Input {
@@ -72,6 +74,14 @@ struct Input {
   size_t size = 0;
   bool mapped = false;
   std::vector<char> owned;
+  // what is still mapped of [data, data + size): the whole file until the pieces are parsed; then every thread unmaps
+  // the whole pages of its own piece as soon as it has parsed it (the kernel takes the pages of 1.6 GB of text apart on
+  // 64 threads instead of one, at 10 M amplicons) and only the pages that straddle two pieces are left for the end
+  std::vector<std::pair<size_t, size_t>> still_mapped;
+  void unmap_rest() {
+    for (const auto & r : still_mapped) { ::munmap(const_cast<char *>(data) + r.first, r.second - r.first); }
+    still_mapped.clear();
+  }
 };
 
 bool load_input(const char * path, Input & in, std::string & err) {
@@ -90,6 +100,7 @@ bool load_input(const char * path, Input & in, std::string & err) {
         in.data = static_cast<const char *>(p);
         in.size = (size_t)st.st_size;
         in.mapped = true;
+        in.still_mapped.assign(1, {0, (size_t)st.st_size});
         ::close(fd);
         return true;
       }
@@ -298,14 +309,23 @@ unsigned worker_count(size_t bytes) {
   return (unsigned)std::min<size_t>(t, by_size);
 }
 
+// threads of its own for a caller that runs BESIDE the pool's phases (the identifier / sequence checks)
 template <typename F>
-void run_parallel(unsigned threads, F && fn) {
+void run_transient(unsigned threads, F && fn) {
   if (threads <= 1) { fn(0u); return; }
   std::vector<std::thread> pool;
   pool.reserve(threads);
   for (unsigned t = 0; t < threads; ++t) { pool.emplace_back([&fn, t] { fn(t); }); }
   for (auto & th : pool) { th.join(); }
 }
+
+// fn(t) for t in [0, tasks) on the process's worker threads (pool.h)
+template <typename F>
+void run_parallel(unsigned tasks, F && fn) { swa_pool::get().run(tasks, fn); }
+
+// the pages of a big block handed back in slices by all threads (the block stays mapped: its owner frees it as usual,
+// which then has nothing left to take apart)
+void release_pages_parallel(void * p, size_t bytes) { swa_release_pages(p, bytes); }
 
 struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the phase times to stderr
   bool on = std::getenv("SWARM_AMD_DB_TIMING") != nullptr;
@@ -381,7 +401,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   *out = db;
   Input in;
   if (!load_input(path, in, db->error)) { return SWA_E_ARG; }
-  struct Unmap { Input & i; ~Unmap() { if (i.mapped) { ::munmap(const_cast<char *>(i.data), i.size); } } } unmap{in};
+  struct Unmap { Input & i; ~Unmap() { i.unmap_rest(); } } unmap{in};
 
   int8_t map[256];
   std::memset(map, -1, sizeof(map));
@@ -404,11 +424,32 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     cuts[t] = pos;
   }
   std::vector<Piece> pieces(threads);
+  // (pieces of a mapped file of at least 1 MB each: their whole pages are unmapped by their own threads; what is left —
+  // the pages around the cuts — is listed now, before anybody unmaps anything)
+  constexpr size_t kPage = 4096;
+  const bool unmap_by_piece = in.mapped && threads > 1 && in.size / threads >= (1u << 20);
+  std::vector<std::pair<size_t, size_t>> interior(threads, {0, 0});
+  if (unmap_by_piece) {
+    in.still_mapped.clear();
+    size_t covered = 0;                                       // everything below is unmapped by a piece or listed
+    for (unsigned t = 0; t < threads; ++t) {
+      const size_t lo = std::max(covered, (cuts[t] + kPage - 1) & ~(kPage - 1));
+      const size_t hi = t + 1 == threads ? in.size : (cuts[t + 1] & ~(kPage - 1));
+      if (lo < hi) {
+        if (covered < lo) { in.still_mapped.push_back({covered, lo}); }
+        interior[t] = {lo, hi};
+        covered = t + 1 == threads ? in.size : hi;
+      }
+    }
+    if (covered < in.size) { in.still_mapped.push_back({covered, in.size}); }
+  }
   run_parallel(threads, [&](unsigned t) {
     if (cuts[t] < cuts[t + 1]) {
       parse_piece(in.data + cuts[t], in.data + cuts[t + 1], map, usearch != 0, append_abundance, t, pieces[t]);
     }
+    if (interior[t].first < interior[t].second) { ::munmap(const_cast<char *>(in.data) + interior[t].first, interior[t].second - interior[t].first); }
   });
+  in.unmap_rest();
 
   timer.lap("map + parallel parse");
   // ---- first error in file order, with absolute line numbers
@@ -452,6 +493,22 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   if (n64 > 0xFFFFFFFEull) { db->error = "\nError: too many sequences.\n"; return SWA_E_ARG; }
   const uint32_t n = (uint32_t)n64;
   db->n = n;
+  // The arrays of the database (0.9 GB at 10 M amplicons) are sized — mapped and populated — by a helper thread while
+  // the entries are sorted: every size is known now, and populating fresh memory is what the sizing costs (57 ms on the
+  // critical path before, profiles/r05/NOTES.md).
+  uint64_t all_words = 0, all_hdr_bytes = 0;
+  for (const auto & pc : pieces) { all_words += pc.words.size(); all_hdr_bytes += pc.hdr_pool.size(); }
+  std::thread sizing([db, n, all_words, all_hdr_bytes]() {
+    db->seqs.resize(all_words + 1);
+    db->headers.resize(all_hdr_bytes + 1);
+    db->seq_off.resize((size_t)n + 1);
+    db->hdr_off.resize((size_t)n + 1);
+    db->seqlen.resize(n);
+    db->abundance.resize(n);
+    db->ab_start.resize(n);
+    db->ab_end.resize(n);
+  });
+  struct JoinSizing { std::thread & t; ~JoinSizing() { if (t.joinable()) { t.join(); } } } join_sizing{sizing};
   swa_vec<const RawEntry *> ent(n);
   run_parallel(threads, [&](unsigned t) {
     uint64_t k = piece_first[t];
@@ -477,7 +534,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   {
     const uint64_t tsize = n ? 2ull * n : 1;
     std::unique_ptr<std::atomic<uint32_t>[]> idtab(new std::atomic<uint32_t>[tsize]);   // filled in parallel below
-    run_parallel(check_threads, [&](unsigned t) {
+    run_transient(check_threads, [&](unsigned t) {
       for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
     });
     auto id_span = [&](const RawEntry * e, const char *& s, uint32_t & l) {
@@ -486,7 +543,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
       else { s = hdr + e->ab_end; l = e->hdr_len - (uint32_t)e->ab_end; }
     };
     std::atomic<uint32_t> dup_entry{0xFFFFFFFFu};
-    run_parallel(check_threads, [&](unsigned t) {
+    run_transient(check_threads, [&](unsigned t) {
       // entries and headers stream in file order; the table slot is the one random access per
       // amplicon, so the slots of the next few identifiers are requested ahead of their turn
       constexpr uint64_t kAhead = 8;
@@ -536,11 +593,11 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   if (check_dup_seqs && n > 1) {
     const uint64_t tsize = 2ull * n;
     std::unique_ptr<std::atomic<uint32_t>[]> tab(new std::atomic<uint32_t>[tsize]);
-    run_parallel(check_threads, [&](unsigned t) {
+    run_transient(check_threads, [&](unsigned t) {
       for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
     });
     std::atomic<uint32_t> dup{0xFFFFFFFFu};                  // the earliest entry that repeats an earlier one's sequence
-    run_parallel(check_threads, [&](unsigned t) {
+    run_transient(check_threads, [&](unsigned t) {
       for (uint64_t i = n64 * t / check_threads; i < n64 * (t + 1) / check_threads; ++i) {
         const RawEntry * e = ent[i];
         const uint64_t * w = words_of(e);
@@ -650,19 +707,18 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     timer.lap("  sort: records made, order checked");
     swa_vec<SortRec> other(n);
     timer.lap("  sort: second buffer");
-    parallel_sample_sort(recs.data(), other.data(), n64, threads, less, &timer);
+    // (32 threads, not 64: the bucket sorts took 17-20 ms on 32 and 56-93 ms on 64 threads of the 2 x 64-core host, on one
+    // socket as well as on two — lease r5b; SWARM_AMD_SORT_THREADS overrides)
+    const char * env_sort = std::getenv("SWARM_AMD_SORT_THREADS");
+    const unsigned sort_threads = std::max(1u, std::min(threads, env_sort != nullptr ? (unsigned)std::atoi(env_sort) : 32u));
+    parallel_sample_sort(recs.data(), other.data(), n64, sort_threads, less, &timer);
   }
   auto order = [&](uint64_t k) { return recs[k].entry; };
   timer.lap("sort");
   // ---- contiguous SoA in sorted order (offsets by prefix sum, copies in parallel)
   timer.lap("  (sort ends)");
-  db->seq_off.resize((size_t)n + 1);
-  db->seqlen.resize(n);
-  db->abundance.resize(n);
-  db->hdr_off.resize((size_t)n + 1);
-  db->ab_start.resize(n);
-  db->ab_end.resize(n);
-  timer.lap("  gather: index arrays sized");
+  sizing.join();
+  timer.lap("  gather: arrays sized (waited for)");
   uint64_t woff = 0, hoff = 0;
   {
     // offsets by a two-level prefix sum: per-thread block totals, then each thread fills its block
@@ -696,9 +752,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   db->seq_off[n] = woff;
   db->hdr_off[n] = hoff;
   timer.lap("  gather: offsets");
-  db->seqs.resize(woff + 1);
-  db->headers.resize(hoff + 1);
-  timer.lap("  gather: arrays sized");
+  if (woff != all_words || hoff != all_hdr_bytes) { db->error = "\nError: internal: the pieces' sizes do not add up.\n"; return SWA_E_ARG; }
   run_parallel(threads, [&](unsigned t) {
     // the entries, their words and their headers are three random reads per amplicon: keep a
     // few of them in flight
@@ -724,24 +778,27 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   timer.lap("gather into db order");
   if (const int rc_checks = checks_verdict()) { return rc_checks; }
   timer.lap("identifier / sequence checks (waited for)");
-  // The parse buffers, the sort records and the input mapping (≈ 3 GB at 10 M amplicons) are NOT returned to the
-  // kernel now: that takes as long as the sort, and done by a detached thread (as it was) it holds the process's
-  // memory-map lock just when the caller starts allocating and copying on the GPU (measured: the first upload
-  // stalled for ~0.25 s behind it).  They go when the handle is freed — or with the process.
-  // SWARM_AMD_EAGER_FREE=1: release them right away on a helper thread (small-memory hosts).
-  struct Leftovers {
-    std::vector<Piece> pieces; swa_vec<const RawEntry *> ent; swa_vec<SortRec> recs; const char * data; size_t size; bool mapped;
-  };
-  auto * rest = new Leftovers{std::move(pieces), std::move(ent), std::move(recs), in.data, in.size, in.mapped};
-  in.mapped = false;                                         // (unmapped with the leftovers)
-  auto release = [rest] {
-    if (rest->mapped) { ::munmap(const_cast<char *>(rest->data), rest->size); }
-    delete rest;
-  };
-  if (std::getenv("SWARM_AMD_EAGER_FREE") != nullptr) { std::thread(release).detach(); }
-  else { db->release_leftovers = release; }
+  // The parse buffers and the sort records (1.6 GB at 10 M amplicons) go back to the kernel now, every piece by the
+  // thread that made it and the two big arrays in slices: taking their pages apart is 75 ms a GB for ONE thread — at
+  // process exit, where round 4 left it (0.09-0.4 s of exit), or on a detached thread, which held up the first upload —
+  // and a few ms on all of them.
+  run_parallel(threads, [&](unsigned t) { Piece().swap_buffers(pieces[t]); });
+  release_pages_parallel(ent.data(), ent.size() * sizeof(ent[0]));
+  release_pages_parallel(recs.data(), recs.size() * sizeof(recs[0]));
   timer.lap("hand-off of parse buffers");
   return SWA_OK;
+}
+
+void swa_release_pages(void * p, size_t bytes) {
+  constexpr size_t kPage = 4096, kSlice = size_t(16) << 20;
+  if (p == nullptr || bytes < (size_t(8) << 20)) { return; }
+  const uintptr_t lo = ((uintptr_t)p + kPage - 1) & ~(uintptr_t)(kPage - 1), hi = ((uintptr_t)p + bytes) & ~(uintptr_t)(kPage - 1);
+  if (hi <= lo) { return; }
+  const unsigned slices = (unsigned)((hi - lo + kSlice - 1) / kSlice);
+  swa_pool::get().run(slices, [&](unsigned k) {
+    const uintptr_t a = lo + (uintptr_t)k * kSlice, b = std::min<uintptr_t>(hi, a + kSlice);
+    (void)::madvise(reinterpret_cast<void *>(a), b - a, MADV_DONTNEED);
+  });
 }
 
 extern "C" void swa_hostdb_free(swa_hostdb * db) { delete db; }

@@ -64,6 +64,11 @@ struct swa_default_init_allocator {
 };
 template <class T> using swa_vec = std::vector<T, swa_default_init_allocator<T>>;
 
+// The pages of a big block given back to the kernel in slices by the worker threads (MADV_DONTNEED works under the
+// shared memory-map lock, so the slices go in parallel); the block itself stays mapped for its owner to free.  Freeing
+// a gigabyte costs one thread ~75 ms on the bench host — at exit, inside the caller's wall time.
+void swa_release_pages(void * p, size_t bytes);
+
 struct swa_hostdb {
   uint32_t n = 0;
   uint32_t longest = 0;
@@ -78,8 +83,11 @@ struct swa_hostdb {
   swa_vec<int32_t> ab_start;     // abundance annotation span inside each header
   swa_vec<int32_t> ab_end;
   std::string error;
-  // what the reader no longer needs (parse buffers, sort records, the input mapping: ~3 GB at 10 M amplicons), kept
-  // until the handle is freed — see swa_hostdb_read_fasta
-  std::function<void()> release_leftovers;
-  ~swa_hostdb() { if (release_leftovers) { release_leftovers(); } }
+  ~swa_hostdb() {
+    swa_release_pages(seqs.data(), seqs.size() * sizeof(uint64_t));
+    swa_release_pages(headers.data(), headers.size());
+    swa_release_pages(seq_off.data(), seq_off.size() * sizeof(uint64_t));
+    swa_release_pages(hdr_off.data(), hdr_off.size() * sizeof(uint64_t));
+    swa_release_pages(abundance.data(), abundance.size() * sizeof(uint64_t));
+  }
 };

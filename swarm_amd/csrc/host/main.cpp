@@ -1,4 +1,4 @@
-// main.cpp — `swarm` command-line front end over the C ABI (drop-in for the reference CLI:
+// main.cpp — `swarm` command-line front end over the C ABI (swa_cli_main; the executable is host/launcher.cpp) (drop-in for the reference CLI:
 // same options, same FASTA input, same output files, same log lines; src/swarm.cc:96-124,
 // 269-463, 486-630).  Everything compute-heavy goes through libswarm_amd.so to the GPU; the
 // greedy clustering and the writers are the host code in cluster_d1.cpp / cluster_dn.cpp.
@@ -15,13 +15,8 @@
 #include "../../../include/swarm_amd_host.h"
 
 #include <getopt.h>
-#include <sys/prctl.h>
-#include <sys/resource.h>
-#include <sys/wait.h>
+#include <omp.h>
 #include <unistd.h>
-
-#include <cerrno>
-#include <csignal>
 
 #include <algorithm>
 #include <cinttypes>
@@ -226,71 +221,17 @@ void check_writer(int rc, const char * what) {
   if (rc != SWA_OK) { die(std::string("Unable to open ") + what + " file for writing."); }
 }
 
-// Process exit is not free here: after the last output file is closed the kernel still has ~5 GB of page tables and the
-// amdgpu / KFD side of the process to take apart, and on the same box that takes anything from 30 ms to 400 ms (measured,
-// 10 M amplicons; freeing host or device memory first changes nothing).  By default the program is ONE process, like the
-// reference: whoever waits for it waits for that too, a kill reaches the GPU work, resource accounting sees everything.
-// SWARM_AMD_DETACHED_EXIT=1 (opt-in, for an interactive caller who only wants the files): the program runs as a WORKER
-// child (killed with the front: PR_SET_PDEATHSIG) and the FRONT process — the one the caller started — returns as soon
-// as the worker reports that every output file is complete and closed, with the worker's status, and otherwise with
-// whatever the worker ended with (error exit, signal).
-int g_done_fd = -1;
-pid_t g_worker = -1;
-
-void forward_signal(int sig) { if (g_worker > 0) { (void)kill(g_worker, sig); } }
-
-void front_and_worker() {
-  const char * detached = std::getenv("SWARM_AMD_DETACHED_EXIT");
-  if (detached == nullptr || detached[0] != '1') { return; }
-  int fds[2];
-  if (pipe(fds) != 0) { return; }
-  const pid_t pid = fork();                    // (no threads, no HIP runtime yet)
-  if (pid < 0) { close(fds[0]); close(fds[1]); return; }
-  if (pid == 0) {
-    (void)prctl(PR_SET_PDEATHSIG, SIGKILL);    // (a front that is killed outright cannot forward anything)
-    close(fds[0]); g_done_fd = fds[1]; return;
-  }
-  g_worker = pid;
-  close(fds[1]);
-  for (int sig : {SIGINT, SIGTERM, SIGHUP, SIGQUIT}) { (void)std::signal(sig, forward_signal); }
-  unsigned char code = 0;
-  ssize_t got;
-  do { got = read(fds[0], &code, 1); } while (got < 0 && errno == EINTR);
-  if (got == 1) { _exit(code); }               // results complete: the worker finishes on its own
-  int status = 0;
-  while (waitpid(pid, &status, 0) < 0 && errno == EINTR) { }
-  if (WIFEXITED(status)) { _exit(WEXITSTATUS(status)); }
-  if (WIFSIGNALED(status)) { (void)std::signal(WTERMSIG(status), SIG_DFL); (void)raise(WTERMSIG(status)); }
-  _exit(EXIT_FAILURE);
-}
-
-// the worker's last act before it leaves the rest to the kernel: every output is flushed and closed
-void report_complete() {
-  if (g_done_fd < 0) { return; }
-  std::fflush(nullptr);
-  (void)close(STDOUT_FILENO);                  // (a caller reading our stdout / stderr through pipes gets its end-of-file
-  (void)close(STDERR_FILENO);                  //  from the front process, not from this one's slow end)
-  const unsigned char ok = EXIT_SUCCESS;
-  ssize_t put;
-  do { put = write(g_done_fd, &ok, 1); } while (put < 0 && errno == EINTR);
-  (void)close(g_done_fd);
-  g_done_fd = -1;
-}
-
 }  // namespace
 
-int main(int argc, char ** argv) {
-  // OpenMP workers that SPIN between parallel regions (libgomp's default) fight the HIP runtime's helper threads
-  // and each other for the cores: measured at 10 M amplicons on a 256-thread host, the same run takes 1.9 s with
-  // the default and 0.5 s with OMP_WAIT_POLICY=passive (a 40 MB array fill went from 18 ms to 660 ms).  libgomp reads
-  // the variable when it is loaded, i.e. before main: set it and start over, once.
-  if (std::getenv("OMP_WAIT_POLICY") == nullptr && std::getenv("SWARM_AMD_NO_REEXEC") == nullptr) {
-    setenv("OMP_WAIT_POLICY", "passive", 1);
-    setenv("SWARM_AMD_NO_REEXEC", "1", 1);
-    execv("/proc/self/exe", argv);             // (falls through if it cannot)
-  }
-  front_and_worker();
+// The command line proper.  The executable (host/launcher.cpp) is a few lines that set the OpenMP wait policy and load this
+// library: libgomp reads OMP_WAIT_POLICY when it is loaded, and workers that SPIN between parallel regions (its default)
+// fight the HIP runtime's helper threads for the cores — measured at 10 M amplicons on a 256-thread host, the same run
+// takes 1.9 s with the default and 0.5 s with `passive`.
+extern "C" int swa_cli_main(int argc, char ** argv) {
   stamp("start");
+  // (OpenMP teams of the host phases: 32 threads at most — on the 256-thread bench host a team of 256 spends more time
+  // gathering than working: result arrays 25 -> 12 ms, swarm table 14 -> 10, writing 89 -> 55 at 10 M amplicons, lease r5b)
+  if (std::getenv("OMP_NUM_THREADS") == nullptr) { omp_set_num_threads(std::max(1, std::min(omp_get_max_threads(), 32))); }
   Options o = parse(argc, argv);
   validate(o);
   if (!o.log.empty()) {
@@ -561,18 +502,16 @@ int main(int argc, char ** argv) {
                  sum[1], sum[2]);
   }
   stamp("results written");
-  // Every output file is closed at this point.  Tearing down gigabytes of host vectors, the device buffers and the
-  // HIP runtime costs ~0.25 s at 10 M amplicons and serves nobody: leave it to the kernel (SWARM_AMD_FULL_TEARDOWN=1
-  // keeps the orderly path, e.g. under a leak checker).
+  // Every output file is closed at this point.  What is left costs at exit by what the kernel has to take apart on ONE
+  // thread: ~75 ms per GB of host pages on the bench host, nothing measurable for device memory (lease r5a,
+  // tools/experiments/init_cost.hip).  So the host database's pages go back now, on all worker threads
+  // (swa_hostdb_free -> swa_release_pages: a few ms), and the device side and the HIP runtime are left to the kernel
+  // (SWARM_AMD_FULL_TEARDOWN=1 keeps the orderly path, e.g. under a leak checker).
   if (std::getenv("SWARM_AMD_FULL_TEARDOWN") == nullptr) {
     if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
     std::fflush(nullptr);
-    if (const char * mode = std::getenv("SWARM_AMD_EXIT_MODE")) {       // experiment: what the kernel is left with
-      const int m = std::atoi(mode);
-      if ((m & 1) != 0) { if (multi != nullptr) { swa_multi_destroy(multi); } else if (ctx != nullptr) { swa_ctx_destroy(ctx); } stamp("device released"); }
-      if ((m & 2) != 0) { swa_hostdb_free(db); stamp("host database released"); }
-    }
-    report_complete();
+    swa_hostdb_free(db);
+    stamp("host database released");
     std::_Exit(EXIT_SUCCESS);
   }
   if (multi != nullptr) { swa_multi_destroy(multi); }

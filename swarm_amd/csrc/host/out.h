@@ -4,6 +4,8 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
@@ -67,23 +69,41 @@ class BufOut {
   std::string buf_;
 };
 
-// Big outputs are formatted by several threads — `format(sink, begin, end)` writes items
-// [begin, end) into a memory sink — and the pieces are emitted in order, so the bytes are those of
-// the single-threaded loop.  More pieces than threads (dynamic schedule): items differ in cost
-// (swarm sizes; an alignment per member for -u).
+// Big outputs are formatted by several threads — `format(sink, begin, end)` writes items [begin, end) into a memory
+// sink — while the calling thread emits the finished pieces in order, so the bytes are those of the single-threaded
+// loop and the copy into the page cache (one thread's work: writes to one file serialise in the kernel) runs beside
+// the formatting instead of after it.  More pieces than threads, claimed from a counter: items differ in cost (swarm
+// sizes; an alignment per member for -u).
+inline int swa_host_team() { return std::max(1, std::min(omp_get_max_threads(), 32)); }
+
 template <class F>
 void swa_format_in_pieces(BufOut & o, size_t items, bool parallel, F && format) {
-  const int threads = std::min(omp_get_max_threads(), 64);
-  if (!parallel || threads < 2 || items < 2) { format(o, (size_t)0, items); return; }
+  const int threads = swa_host_team();
+  if (!parallel || threads < 3 || items < 2) { format(o, (size_t)0, items); return; }
   const size_t npieces = std::min<size_t>(items, (size_t)threads * 8);
   std::vector<std::string> pieces(npieces);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-  for (size_t p = 0; p < npieces; ++p) {
-    BufOut sink;
-    format(sink, items * p / npieces, items * (p + 1) / npieces);
-    pieces[p] = sink.take();
+  std::vector<std::atomic<int>> ready(npieces);
+  for (auto & r : ready) { r.store(0, std::memory_order_relaxed); }
+  std::atomic<size_t> next{0};
+#pragma omp parallel num_threads(threads)
+  {
+    if (omp_get_thread_num() == 0) {
+      for (size_t p = 0; p < npieces; ++p) {
+        while (ready[p].load(std::memory_order_acquire) == 0) { std::this_thread::yield(); }
+        o.write(pieces[p].data(), pieces[p].size());
+        std::string().swap(pieces[p]);
+      }
+    } else {
+      for (;;) {
+        const size_t p = next.fetch_add(1, std::memory_order_relaxed);
+        if (p >= npieces) { break; }
+        BufOut sink;
+        format(sink, items * p / npieces, items * (p + 1) / npieces);
+        pieces[p] = sink.take();
+        ready[p].store(1, std::memory_order_release);
+      }
+    }
   }
-  for (const auto & piece : pieces) { o.write(piece.data(), piece.size()); }
 }
 
 namespace swa_out {

@@ -1,0 +1,106 @@
+// pool.h — the host side's worker threads, started once.
+// The reader (fasta_db.cpp) runs a dozen short parallel phases; a std::thread per phase and worker costs a stack mapping
+// each (the process's memory-map lock, which the HIP runtime starting up beside the reader wants all the time) and showed
+// as stalls of 50-80 ms in single phases at 10 M amplicons (profiles/r05/NOTES.md).  Workers here are created on first
+// use, wait on a condition variable between phases and claim task numbers from a shared counter, so a phase may have
+// more tasks than there are workers.  One phase at a time (a second caller waits); the calling thread works too.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+class swa_pool {
+ public:
+  static swa_pool & get() {
+    static swa_pool pool;
+    return pool;
+  }
+  unsigned size() const { return (unsigned)workers_.size() + 1u; }     // workers + the caller
+
+  // fn(t) for every t in [0, tasks), on up to size() threads; returns when all are done
+  template <class F>
+  void run(unsigned tasks, F && fn) {
+    if (tasks == 0) { return; }
+    if (tasks == 1 || workers_.empty()) { for (unsigned t = 0; t < tasks; ++t) { fn(t); } return; }
+    std::lock_guard<std::mutex> one_phase(phase_);
+    std::function<void(unsigned)> job = std::ref(fn);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &job;
+      tasks_ = tasks;
+      next_.store(0, std::memory_order_relaxed);
+      pending_ = tasks;
+      ++generation_;
+    }
+    wake_.notify_all();
+    work(job, tasks);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0 && busy_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  swa_pool() {
+    const char * env = std::getenv("SWARM_AMD_HOST_THREADS");
+    unsigned n = env != nullptr ? (unsigned)std::atoi(env) : std::thread::hardware_concurrency();
+    if (n < 1) { n = 1; }
+    if (n > 64) { n = 64; }
+    for (unsigned i = 1; i < n; ++i) { workers_.emplace_back([this] { loop(); }); }
+  }
+  ~swa_pool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++generation_; }
+    wake_.notify_all();
+    for (auto & w : workers_) { w.join(); }
+  }
+  void work(const std::function<void(unsigned)> & job, unsigned tasks) {
+    unsigned finished = 0;
+    for (;;) {
+      const unsigned t = next_.fetch_add(1, std::memory_order_relaxed);
+      if (t >= tasks) { break; }
+      job(t);
+      ++finished;
+    }
+    if (finished != 0) {
+      std::lock_guard<std::mutex> lk(m_);
+      pending_ -= finished;
+      if (pending_ == 0) { done_.notify_all(); }
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)> * job = nullptr;
+      unsigned tasks = 0;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        wake_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) { return; }
+        job = job_;
+        tasks = tasks_;
+        if (job == nullptr) { continue; }
+        ++busy_;                                // (the phase's owner waits for every worker that picked the job up)
+      }
+      work(*job, tasks);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        --busy_;
+        if (pending_ == 0 && busy_ == 0) { done_.notify_all(); }
+      }
+    }
+  }
+
+  std::vector<std::thread> workers_;
+  std::mutex phase_, m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(unsigned)> * job_ = nullptr;
+  unsigned tasks_ = 0, pending_ = 0, busy_ = 0;
+  std::atomic<unsigned> next_{0};
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};

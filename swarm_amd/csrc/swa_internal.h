@@ -149,6 +149,11 @@ struct swa_ctx {
 
   // the d = 1 network kept in d_offsets_tmp / d_nb_tmp (swa_d1_network_resident) and its clustering (cluster_gpu.hip)
   bool csr_ready = false;
+  uint32_t index_first = 0, index_count = 0;   // the range of the last index build (network_run_guarded repeats it)
+  bool index_routed = false;
+  uint32_t guard_retries = 0;                  // steps repeated after the guard found counts that did not balance
+  bool cluster_ready = false;                  // swa_d1_cluster_device's arrays lie in d_cluster (swa_d1_cluster_fetch)
+  uint32_t cluster_maxgen = 0;
   int pair_blocks[4] = {};                      // workgroups of k_d1_group_pairs a CU holds, per width class (0: not asked yet)
   bool g1_lds_opt_in = false;                  // k_group1's dynamic-LDS attribute has been set on this context's device
   uint32_t part_lds_opt_in = 0;    // ... and the wide-tile forms of k_part_scatter (one bit each)

@@ -32,6 +32,7 @@ WORKER = textwrap.dedent('''
     wnb = wnb.copy()
     for i in range(db.n):
         wnb[int(woff[i]):int(woff[i + 1])].sort()
+    print("RETRIES", ctx.d1_guard_retries())
     print("NETWORK", "equal" if (np.array_equal(off, woff) and np.array_equal(nb, wnb)) else "DIFFERENT", len(nb), len(wnb), "width", ctx.d1_anchor_width())
 ''')
 
@@ -66,3 +67,16 @@ def test_lost_records_are_caught(tmp_path):
     """records made by k_keys that never reach a group: the counts do not balance and the call fails"""
     out = _run(tmp_path, "drop")
     assert "ERROR 6" in out and "key records" in out, out
+
+
+@pytest.mark.parametrize("fault", ["misfile-once", "drop-once"])
+def test_a_transient_fault_costs_one_repeated_step_not_the_run(tmp_path, fault):
+    """the reference cannot fail here (src/algod1.cc:630-670): when the guard trips, the library rebuilds everything
+    derived from the packed database and repeats the step once — a fault that does not recur (injected into the first
+    build only) ends in the right network, one retry counted, one line on stderr"""
+    out = _run(tmp_path, fault)
+    assert "NETWORK equal" in out and "RETRIES 1" in out, out
+
+
+def test_a_sound_run_repeats_nothing(tmp_path):
+    assert "RETRIES 0" in _run(tmp_path, None)
