@@ -16,7 +16,8 @@ rank r serves the anchor groups whose key maps to r (routed index build), the li
 
 At N = 1 the same run also measures, after the timed region (none of it enters `value`; --no-extras skips it):
   config.configs1 / configs2 / configs3   BASELINE configs[1..3]
-  config.skewed / config.heavy_tail        the headline step on conserved flanks / on Zipf-sized families
+  config.skewed / skewed_70 / v4_like / heavy_tail   the headline step on conserved flanks (40 nt; 70 nt: wider than a window) /
+                                           on 250-nt reads with 60 % conserved positions / on Zipf-sized families
   config.d1_x400                           the d=1 step on 1 M amplicons of 400 bp
   whole_run (top level)                    FASTA -> -o through the drop-in command line, 1 M (md5 vs the reference) and 10 M
   host_seam_ms (top level)                 swa_db_upload + index + swa_d1_network from / to host buffers (PCIe inclusive)
@@ -80,7 +81,7 @@ def gen_tool() -> Path:
     return out
 
 
-def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0, flank: int = 0, zipf: float = 0.0) -> Path:
+def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0, flank: int = 0, zipf: float = 0.0, conserved: int = 0) -> Path:
     """The synthetic amplicon set (SURVEY.md section 8d shapes; tools/gen_amplicons.c), cached in
     the temp dir.  Sets above 2 M are generated as independent blocks of <= 2 M amplicons by
     parallel processes (disjoint header numbers, seeds derived from `seed`) and concatenated.
@@ -96,11 +97,13 @@ def gen_fasta(n: int, length: int, seed: int, edits: int = 1, light: float = 0.0
     # flank > 0: all centroids share their first and last `flank` nucleotides (GEN_FLANK of the generator): the skewed
     # case for anchors at the ends of the sequences
     # zipf > 0: family sizes follow Zipf's law (GEN_ZIPF): the largest family of every 2 M block is that share of the block
-    tag = (f"_f{flank}" if flank else "") + (f"_z{zipf}" if zipf else "")
+    # conserved > 0: that per cent of the positions, in stretches of 8..40 nt, is the same in every centroid (GEN_CONSERVED)
+    tag = (f"_f{flank}" if flank else "") + (f"_z{zipf}" if zipf else "") + (f"_c{conserved}" if conserved else "")
     fasta = Path(tempfile.gettempdir()) / f"swa_bench_{n}x{length}_s{seed}{tag}.fa"
     if fasta.exists():
         return fasta
-    genv = dict(os.environ, **({"GEN_FLANK": str(flank)} if flank else {}), **({"GEN_ZIPF": str(zipf)} if zipf else {})) if (flank or zipf) else None
+    genv = dict(os.environ, **({"GEN_FLANK": str(flank)} if flank else {}), **({"GEN_ZIPF": str(zipf)} if zipf else {}),
+                **({"GEN_CONSERVED": str(conserved)} if conserved else {})) if (flank or zipf or conserved) else None
     tool = str(gen_tool())
     tmp = fasta.with_suffix(f".tmp{os.getpid()}")
     block = 2_000_000
@@ -202,10 +205,10 @@ def gen_mixed_fasta(n: int, length: int, seed: int) -> Path:
     return fasta
 
 
-def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, flank: int = 0, zipf: float = 0.0, mixed: bool = False) -> dict:
+def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, flank: int = 0, zipf: float = 0.0, mixed: bool = False, conserved: int = 0) -> dict:
     """The bench step (index build + network, db and CSR resident) on n x length amplicons."""
     from swarm_amd import Context, HostDb
-    hdb = HostDb(gen_mixed_fasta(n, args.length, args.seed) if mixed else gen_fasta(n, args.length, args.seed, 1, 0.0, flank, zipf))
+    hdb = HostDb(gen_mixed_fasta(n, args.length, args.seed) if mixed else gen_fasta(n, args.length, args.seed, 1, 0.0, flank, zipf, conserved))
 
     def to_dev(a: np.ndarray, as_dtype):
         return torch.from_numpy(np.ascontiguousarray(a).view(as_dtype)).to(dev)
@@ -238,6 +241,7 @@ def extra_measurement(torch, dev, device_index: int, args, n: int, steps: int, f
     nucleotides = float(hdb.seqlen.astype(np.int64).sum())
     return {"workload": f"{hdb.n} synthetic amplicons x {args.length} bp, d=1" + (f", all centroids share their first / last {flank} nt" if flank else "")
             + (", of them one per cent 420-480 nt long" if mixed else "")
+            + (f", {conserved} % of the positions (stretches of 8-40 nt) the same in every centroid" if conserved else "")
             + (f", Zipf family sizes (GEN_ZIPF={zipf}: the largest family of every 2 M block holds that share of it)" if zipf else ""),
             "anchor_windows_nt_from_the_ends": list(windows), "anchor_width_nt": width, "value": hdb.n * steps / elapsed,
             "ns_per_nucleotide": 1e9 * (elapsed / steps) / nucleotides,
@@ -915,6 +919,10 @@ def main() -> None:
                 out["cpu_baseline_10M"] = {"value": n_total / dt, "unit": "amplicons/s", "cores": 16, "kind": "reference", "seconds": round(dt, 2),
                                            "sample": f"unmodified reference swarm 3.1.6 -d 1 -t 16, whole run on the {n_total} x {args.length} bp set of the headline"}
             for name, fn in (("skewed", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 40)),
+                             # the conserved-flank cliff: flanks that swallow a 64-nt window whole, and a
+                             # V4-like set — 250 nt, 60 % of the positions conserved across centroids
+                             ("skewed_70", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 70)),
+                             ("v4_like", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 250}), n_total, 5, 0, 0.0, False, 60)),
                              ("heavy_tail", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 0, 0.1)),
                              # 400-bp amplicons: the pair route with 13-word records (128-byte lines), 1 M x 400, d = 1
                              ("d1_x400", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 400}), 1_000_000, 5)),

@@ -102,6 +102,25 @@ int swa_db_upload(swa_ctx * ctx, const swa_db_view * host_db);
 /* adopt a database whose arrays are ALREADY device memory on this GPU (not copied,
    not freed; must outlive the context's use of it) */
 int swa_db_attach(swa_ctx * ctx, const swa_db_view * device_db);
+/* The same database handed over as the FASTA reader leaves it (src/db.cc:432-628 packs while it reads; :388-413 sorts
+   afterwards): the packed words in FILE order, in `pieces` pools, and per amplicon k of the db order where its words
+   begin in the concatenation of the pools.  The GPU puts the words in db order (one gather kernel) — the host never
+   copies them.  swa_db_stage_words starts the copy of the pools as soon as they exist (asynchronous, on the context's
+   stream; the pools must stay as they are until swa_db_upload_unordered has returned); swa_db_upload_unordered stages
+   them itself if that was not done (same pool pointers), copies the three per-amplicon arrays and leaves the context
+   exactly as swa_db_upload does. */
+typedef struct swa_db_unordered_view {
+  uint32_t n;                          /* amplicons */
+  uint32_t longest;                    /* longest sequence (nt) */
+  uint32_t pieces;                     /* word pools */
+  const uint64_t * const * piece_words; /* pools[pieces]: packed words, every sequence from a word boundary */
+  const uint64_t * piece_word_count;   /* words per pool */
+  const uint64_t * src_off;            /* [n] db order: first word of amplicon k, counted through the pools in order */
+  const uint32_t * seqlen;             /* [n] db order */
+  const uint64_t * abundance;          /* [n] db order */
+} swa_db_unordered_view;
+int swa_db_stage_words(swa_ctx * ctx, const uint64_t * const * piece_words, const uint64_t * piece_word_count, uint32_t pieces);
+int swa_db_upload_unordered(swa_ctx * ctx, const swa_db_unordered_view * host_db);
 
 /* ---- B1: d = 1 network --------------------------------------------------------- */
 /* The index the network calls work on — what the reference's hash_insert loop builds (src/algod1.cc:188-208,

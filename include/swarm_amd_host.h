@@ -26,10 +26,20 @@ typedef struct swa_hostdb swa_hostdb;
    fatal() text (the caller prints it and exits 1). */
 int swa_hostdb_read_fasta(const char * path, int usearch_abundance, int64_t append_abundance,
                           int check_duplicate_sequences, swa_hostdb ** out);
+/* The same with a notice as soon as the packed words are final (right after the parse, before the sort): on_words(user,
+   pools, words per pool, pools) runs on the calling thread; the pools stay where they are for the life of the handle
+   (they are the database's storage), so a GPU context coming up on another thread can start swa_db_stage_words on
+   them while this call sorts.  on_words may be NULL. */
+typedef void (*swa_words_ready_fn)(void * user, const uint64_t * const * piece_words, const uint64_t * piece_word_count, uint32_t pieces);
+int swa_hostdb_read_fasta_staged(const char * path, int usearch_abundance, int64_t append_abundance, int check_duplicate_sequences,
+                                 swa_words_ready_fn on_words, void * user, swa_hostdb ** out);
 void swa_hostdb_free(swa_hostdb * db);
 const char * swa_hostdb_error(const swa_hostdb * db);
-/* host pointers into the handle (valid until swa_hostdb_free) */
+/* host pointers into the handle (valid until swa_hostdb_free).  swa_hostdb_view: the packed sequences contiguous in db
+   order — gathered on the host the first time it is asked for; swa_hostdb_unordered_view: the database as the reader
+   keeps it (words in file order + where each amplicon's begin), what swa_db_upload_unordered takes — no host copy. */
 void swa_hostdb_view(const swa_hostdb * db, swa_db_view * view);
+void swa_hostdb_unordered_view(const swa_hostdb * db, swa_db_unordered_view * view);
 uint64_t swa_hostdb_nucleotides(const swa_hostdb * db);
 /* header of amplicon i (db order), NUL terminated; replaces db_getheader (src/db.h:47) */
 const char * swa_hostdb_header(const swa_hostdb * db, uint32_t i, uint32_t * len);

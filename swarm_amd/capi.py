@@ -40,10 +40,16 @@ class DbView(C.Structure):
                 ("seqlen", C.c_void_p), ("abundance", C.c_void_p)]
 
 
+class DbUnorderedView(C.Structure):
+    """swa_db_unordered_view: the reader's word pools in file order + where every amplicon's words begin"""
+    _fields_ = [("n", C.c_uint32), ("longest", C.c_uint32), ("pieces", C.c_uint32), ("piece_words", C.c_void_p),
+                ("piece_word_count", C.c_void_p), ("src_off", C.c_void_p), ("seqlen", C.c_void_p), ("abundance", C.c_void_p)]
+
+
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_d1_anchor_windows", "swa_d1_anchor_width",
     "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident",
-    "swa_db_upload", "swa_db_attach", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
+    "swa_db_upload", "swa_db_attach", "swa_db_stage_words", "swa_db_upload_unordered", "swa_hostdb_unordered_view", "swa_hostdb_read_fasta_staged", "swa_cli_main", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
@@ -165,22 +171,35 @@ class HostDb:
             msg = self.lib.swa_hostdb_error(h).decode() if h else "allocation failed"
             self.close()
             raise SwaError(rc, msg)
-        v = DbView()
-        self.lib.swa_hostdb_view(h, C.byref(v))
-        self.n = int(v.n)
-        self.longest = int(v.longest)
+        u = DbUnorderedView()
+        self.lib.swa_hostdb_unordered_view(h, C.byref(u))
+        self.n = int(u.n)
+        self.longest = int(u.longest)
         self.nucleotides = int(self.lib.swa_hostdb_nucleotides(h))
+        self._ordered = None
 
-        def view(ptr, count, dtype):
-            if count == 0:
-                return np.zeros(0, dtype=dtype)
-            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dtype, count=count)
+    @staticmethod
+    def _array(ptr, count, dtype):
+        if count == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=count)
 
-        self.seq_off = view(v.seq_off, self.n + 1, np.uint64)
-        self.seqlen = view(v.seqlen, self.n, np.uint32)
-        self.abundance = view(v.abundance, self.n, np.uint64)
-        self.seqs = view(v.seqs, int(self.seq_off[self.n]) if self.n else 0, np.uint64)
+    def _view(self):
+        """The packed sequences contiguous in db order (swa_hostdb_view): gathered by the library on first use."""
+        if self._ordered is None:
+            v = DbView()
+            self.lib.swa_hostdb_view(self.h, C.byref(v))
+            seq_off = self._array(v.seq_off, self.n + 1, np.uint64)
+            self._ordered = {"seq_off": seq_off, "seqlen": self._array(v.seqlen, self.n, np.uint32),
+                             "abundance": self._array(v.abundance, self.n, np.uint64),
+                             "seqs": self._array(v.seqs, int(seq_off[self.n]) if self.n else 0, np.uint64)}
+        return self._ordered
+
+    seq_off = property(lambda self: self._view()["seq_off"])
+    seqlen = property(lambda self: self._view()["seqlen"])
+    abundance = property(lambda self: self._view()["abundance"])
+    seqs = property(lambda self: self._view()["seqs"])
 
     def header(self, i: int) -> bytes:
         return self.lib.swa_hostdb_header(self.h, i, None)
@@ -343,7 +362,12 @@ class Context:
         return [float(x) for x in ms]
 
     def upload_hostdb(self, hdb: "HostDb") -> None:
-        self.upload_db(hdb.seqs, hdb.seq_off, hdb.seqlen, hdb.abundance, hdb.longest)
+        """The database as the reader keeps it — words in file order — put in db order on the GPU (swa_db_upload_unordered:
+        what the command line does)."""
+        u = DbUnorderedView()
+        self.lib.swa_hostdb_unordered_view(hdb.h, C.byref(u))
+        self._check(self.lib.swa_db_upload_unordered(self.h, C.byref(u)))
+        self.n = hdb.n
 
     # ---- L2
     def upload_db(self, seqs, seq_off, seqlen, abundance, longest: int) -> None:

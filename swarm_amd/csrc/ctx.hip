@@ -1,6 +1,8 @@
 // ctx.hip — context, error reporting, database residency (seam L2 of include/swarm_amd.h).
 #include "swa_internal.h"
 
+#include <rocprim/rocprim.hpp>
+
 int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e) {
   if (ctx != nullptr) {
     ctx->err = std::string(what) + ": " + hipGetErrorString(e);
@@ -117,7 +119,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_afallback, &ctx->d_arank, &ctx->d_rank_tmp, &ctx->d_wfa, &ctx->d_long_rows, &ctx->d_seg_fill, &ctx->d_seg_base, &ctx->d_akeys[0], &ctx->d_acounts[0],
                        &ctx->d_aitems[0], &ctx->d_aitems[1],
                        &ctx->d_frole, &ctx->d_fkeys, &ctx->d_fcnt, &ctx->d_foff, &ctx->d_fslot, &ctx->d_fmembers, &ctx->d_fitems,
-                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster}) {
+                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster, &ctx->d_words_stage}) {
     swa_release(*b);
   }
   for (auto & b : ctx->d_stream) { swa_release(b); }
@@ -213,6 +215,102 @@ extern "C" int swa_db_upload(swa_ctx * ctx, const swa_db_view * h) {
   SWA_HIP(ctx, hipMemcpyAsync(ctx->d_abund.ptr, h->abundance, uint64_t(h->n) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->db.n = h->n;
+  ctx->db.longest = h->longest;
+  ctx->db.seqs = static_cast<const uint64_t *>(ctx->d_seqs.ptr);
+  ctx->db.seq_off = static_cast<const uint64_t *>(ctx->d_seq_off.ptr);
+  ctx->db.seqlen = static_cast<const uint32_t *>(ctx->d_seqlen.ptr);
+  ctx->db.abundance = static_cast<const uint64_t *>(ctx->d_abund.ptr);
+  ctx->db_owned = true;
+  invalidate(ctx);
+  return SWA_OK;
+}
+
+// ---- the database in file order, put in db order on the device -------------------------------------------------------
+// words[k] = words of amplicon k; word offsets by an exclusive scan; one lane per amplicon copies its words (5 at 150 nt)
+__global__ __launch_bounds__(256) void k_db_word_counts(const uint32_t * __restrict__ seqlen, uint32_t n, uint64_t * __restrict__ counts) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += gridDim.x * blockDim.x) { counts[k] = k < n ? (uint64_t)((seqlen[k] + 31u) >> 5) : 0ull; }
+}
+__global__ __launch_bounds__(256) void k_db_gather_words(const uint64_t * __restrict__ file_words, const uint64_t * __restrict__ src_off,
+                                                         const uint64_t * __restrict__ seq_off, uint32_t n, uint64_t * __restrict__ seqs) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const uint64_t from = src_off[k], to = seq_off[k], nw = seq_off[k + 1] - to;
+    for (uint64_t j = 0; j < nw; ++j) { seqs[to + j] = file_words[from + j]; }
+  }
+}
+
+extern "C" int swa_db_stage_words(swa_ctx * ctx, const uint64_t * const * piece_words, const uint64_t * piece_word_count, uint32_t pieces) {
+  if (ctx == nullptr || piece_words == nullptr || piece_word_count == nullptr || pieces == 0) { return SWA_E_ARG; }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  uint64_t total = 0;
+  for (uint32_t p = 0; p < pieces; ++p) { total += piece_word_count[p]; }
+  SWA_TRY(swa_reserve(ctx, ctx->d_words_stage, (total + 2) * sizeof(uint64_t)));
+  uint64_t at = 0;
+  for (uint32_t p = 0; p < pieces; ++p) {
+    if (piece_word_count[p] != 0) {
+      SWA_HIP(ctx, hipMemcpyAsync(static_cast<uint64_t *>(ctx->d_words_stage.ptr) + at, piece_words[p], piece_word_count[p] * sizeof(uint64_t),
+                                  hipMemcpyHostToDevice, ctx->stream));
+    }
+    at += piece_word_count[p];
+  }
+  ctx->staged_first = piece_words[0];
+  ctx->staged_words = total;
+  return SWA_OK;
+}
+
+extern "C" int swa_db_upload_unordered(swa_ctx * ctx, const swa_db_unordered_view * h) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (h == nullptr || h->piece_words == nullptr || h->piece_word_count == nullptr || h->src_off == nullptr || h->seqlen == nullptr ||
+      h->abundance == nullptr) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_db: null array in db view");
+  }
+  if (h->n == 0 || h->longest == 0 || h->pieces == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_db: empty database"); }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  uint64_t total = 0;
+  for (uint32_t p = 0; p < h->pieces; ++p) { total += h->piece_word_count[p]; }
+  if (ctx->staged_first != h->piece_words[0] || ctx->staged_words != total || ctx->d_words_stage.ptr == nullptr) {
+    SWA_TRY(swa_db_stage_words(ctx, h->piece_words, h->piece_word_count, h->pieces));
+  }
+  const uint32_t n = h->n;
+  SWA_TRY(swa_reserve(ctx, ctx->d_seqs, (total + 2) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_seq_off, (uint64_t(n) + 1) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_seqlen, uint64_t(n) * sizeof(uint32_t)));
+  SWA_TRY(swa_reserve(ctx, ctx->d_abund, uint64_t(n) * sizeof(uint64_t)));
+  // src_off travels through the buffer that will hold the offsets' scan input afterwards
+  swa_dbuf d_src, d_counts;
+  SWA_TRY(swa_reserve(ctx, d_src, uint64_t(n) * sizeof(uint64_t)));
+  SWA_TRY(swa_reserve(ctx, d_counts, (uint64_t(n) + 1) * sizeof(uint64_t)));
+  auto release_tmp = [&]() { swa_release(d_src); swa_release(d_counts); };
+  auto fail_hip = [&](hipError_t e, const char * what) { release_tmp(); return swa_fail(ctx, SWA_E_DEVICE, what, e); };
+  hipError_t e;
+  if ((e = hipMemcpyAsync(d_src.ptr, h->src_off, uint64_t(n) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { return fail_hip(e, "hipMemcpyAsync"); }
+  if ((e = hipMemcpyAsync(ctx->d_seqlen.ptr, h->seqlen, uint64_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { return fail_hip(e, "hipMemcpyAsync"); }
+  if ((e = hipMemcpyAsync(ctx->d_abund.ptr, h->abundance, uint64_t(n) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { return fail_hip(e, "hipMemcpyAsync"); }
+  const int grid = std::max(1, std::min<int>(ctx->num_cus * 8, (int)((uint64_t(n) + 256) / 256)));
+  hipLaunchKernelGGL(k_db_word_counts, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(ctx->d_seqlen.ptr), n,
+                     static_cast<uint64_t *>(d_counts.ptr));
+  size_t need = 0;
+  (void)rocprim::exclusive_scan(nullptr, need, static_cast<uint64_t *>(d_counts.ptr), static_cast<uint64_t *>(ctx->d_seq_off.ptr), 0ull,
+                                (size_t)n + 1, rocprim::plus<uint64_t>(), ctx->stream);
+  swa_dbuf d_tmp;
+  if (swa_reserve(ctx, d_tmp, need + 16) != SWA_OK) { release_tmp(); return SWA_E_NOMEM; }
+  e = rocprim::exclusive_scan(d_tmp.ptr, need, static_cast<uint64_t *>(d_counts.ptr), static_cast<uint64_t *>(ctx->d_seq_off.ptr), 0ull,
+                              (size_t)n + 1, rocprim::plus<uint64_t>(), ctx->stream);
+  if (e != hipSuccess) { swa_release(d_tmp); return fail_hip(e, "rocprim::exclusive_scan"); }
+  hipLaunchKernelGGL(k_db_gather_words, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t *>(ctx->d_words_stage.ptr),
+                     static_cast<const uint64_t *>(d_src.ptr), static_cast<const uint64_t *>(ctx->d_seq_off.ptr), n,
+                     static_cast<uint64_t *>(ctx->d_seqs.ptr));
+  uint64_t placed = 0;                                        // = seq_off[n]: the words the amplicons take, <= the pools' words
+  if ((e = hipMemcpyAsync(&placed, static_cast<uint64_t *>(ctx->d_seq_off.ptr) + n, sizeof(placed), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) { swa_release(d_tmp); return fail_hip(e, "hipMemcpyAsync"); }
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { swa_release(d_tmp); return fail_hip(e, "hipStreamSynchronize"); }
+  swa_release(d_tmp);
+  release_tmp();
+  if (placed > total) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_db_upload_unordered: the amplicons' words exceed the pools'"); }
+  SWA_HIP(ctx, hipMemsetAsync(static_cast<uint64_t *>(ctx->d_seqs.ptr) + placed, 0, 2 * sizeof(uint64_t), ctx->stream));
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  swa_release(ctx->d_words_stage);
+  ctx->staged_first = nullptr;
+  ctx->staged_words = 0;
+  ctx->db.n = n;
   ctx->db.longest = h->longest;
   ctx->db.seqs = static_cast<const uint64_t *>(ctx->d_seqs.ptr);
   ctx->db.seq_off = static_cast<const uint64_t *>(ctx->d_seq_off.ptr);

@@ -50,10 +50,6 @@ struct swa_d1_result {
   swa_ctx * lazy_ctx = nullptr;
   const swa_hostdb * lazy_db = nullptr;
   bool details = true;
-  ~swa_d1_result() {                          // (the big arrays' pages go back on all threads, see hostdb.h)
-    for (auto * v : {&swarmid, &parent, &generation, &order, &graft_cand}) { swa_release_pages(v->data(), v->size() * sizeof(uint32_t)); }
-    swa_release_pages(swarms.data(), swarms.size() * sizeof(Swarm));
-  }
 };
 
 namespace {
@@ -674,8 +670,8 @@ extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * d
       sink.str("\t*\n");
       for_each_member(r, s, [&](uint32_t a) {
         if (a == s.seed) { return; }
-        const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[a], db->seqlen[a],
-                                             db->seqs.data() + db->seq_off[s.seed], db->seqlen[s.seed], mismatch, gapopen,
+        const uint64_t nwdiff = swa_nw_align(db->words(a), db->seqlen[a],
+                                             db->words(s.seed), db->seqlen[s.seed], mismatch, gapopen,
                                              gapextend, scratch);
         const double columns = (double)scratch.ops.size();
         const double percentid = 100.0 * (columns - (double)nwdiff) / columns;

@@ -423,8 +423,8 @@ extern "C" int swa_dn_write_uclust(const swa_dn_result * r, const swa_hostdb * d
       sink.str("\t*\n");
       for (uint32_t k = s.link_begin; k < s.link_end; ++k) {
         const uint32_t hit = r->links[k].child;
-        const uint64_t nwdiff = swa_nw_align(db->seqs.data() + db->seq_off[hit], db->seqlen[hit],
-                                             db->seqs.data() + db->seq_off[seed], db->seqlen[seed], r->pen_mismatch,
+        const uint64_t nwdiff = swa_nw_align(db->words(hit), db->seqlen[hit],
+                                             db->words(seed), db->seqlen[seed], r->pen_mismatch,
                                              r->pen_gapopen, r->pen_gapextend, scratch);
         const double columns = (double)scratch.ops.size();
         const double percentid = 100.0 * (columns - (double)nwdiff) / columns;

@@ -6,9 +6,10 @@
 // all host cores in parallel into per-thread SoA pieces; abundance parsing and the
 // identifier-uniqueness check run in the same parallel pass (lock-free open addressing);
 // the sort is a parallel merge sort on (abundance, 8-byte header prefix) keys that falls
-// back to strcmp only on ties; and the result is written contiguously in SORTED order with
-// 8-byte aligned sequence words (what the GPU wants to stream), instead of the
-// reference's single-threaded getline loop over an interleaved header/sequence blob.
+// back to strcmp only on ties; and what the parser wrote STAYS where it is, in file order —
+// db order is an array of pointers into it, and the packed words are put in db order by the
+// GPU as they arrive (swa_db_upload_unordered) —, instead of the reference's single-threaded
+// getline loop over an interleaved header/sequence blob.
 #include "hostdb.h"
 #include "pool.h"
 
@@ -34,23 +35,8 @@
 
 namespace {
 
-struct RawEntry {
-  uint64_t hdr_off;      // into the piece's header pool
-  uint64_t word_off;     // into the piece's word pool
-  uint64_t abundance;
-  uint64_t key8;         // first 8 header bytes, big endian (sort accelerator)
-  uint32_t hdr_len;
-  uint32_t lineno;       // line of the '>' header, counted from the start of the piece
-  uint32_t seqlen;
-  int32_t ab_start;      // abundance annotation [start, end) inside the header
-  int32_t ab_end;
-  uint32_t piece;
-};
-
-struct Piece {            // what one thread parsed
-  std::vector<RawEntry> entries;
-  std::vector<char> hdr_pool;
-  std::vector<uint64_t> words;
+struct Piece {            // what one thread parsed: the data (it becomes the database's storage) and the parse's own notes
+  swa_piece data;
   uint64_t lines = 0;     // newline-terminated lines consumed
   uint64_t nucleotides = 0;
   uint32_t longest = 0, longest_header = 0;
@@ -66,7 +52,6 @@ struct Piece {            // what one thread parsed
   uint64_t missing = 0;   // entries without abundance annotation
   uint32_t missing_line = 0;
   std::string missing_hdr;
-  void swap_buffers(Piece & other) { entries.swap(other.entries); hdr_pool.swap(other.hdr_pool); words.swap(other.words); }
 };
 
 struct Input {
@@ -74,14 +59,6 @@ struct Input {
   size_t size = 0;
   bool mapped = false;
   std::vector<char> owned;
-  // what is still mapped of [data, data + size): the whole file until the pieces are parsed; then every thread unmaps
-  // the whole pages of its own piece as soon as it has parsed it (the kernel takes the pages of 1.6 GB of text apart on
-  // 64 threads instead of one, at 10 M amplicons) and only the pages that straddle two pieces are left for the end
-  std::vector<std::pair<size_t, size_t>> still_mapped;
-  void unmap_rest() {
-    for (const auto & r : still_mapped) { ::munmap(const_cast<char *>(data) + r.first, r.second - r.first); }
-    still_mapped.clear();
-  }
 };
 
 bool load_input(const char * path, Input & in, std::string & err) {
@@ -100,7 +77,6 @@ bool load_input(const char * path, Input & in, std::string & err) {
         in.data = static_cast<const char *>(p);
         in.size = (size_t)st.st_size;
         in.mapped = true;
-        in.still_mapped.assign(1, {0, (size_t)st.st_size});
         ::close(fd);
         return true;
       }
@@ -186,9 +162,12 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
   uint32_t lineno = 1;
   auto line_end = [&](const char * q) { const void * nl = std::memchr(q, '\n', (size_t)(end - q)); return nl ? (const char *)nl : end; };
   const size_t span = (size_t)(end - begin);
-  out.entries.reserve(span / 160 + 16);
-  out.words.reserve(span / 28 + 16);
-  out.hdr_pool.reserve(span / 12 + 16);
+  auto & entries = out.data.entries;
+  auto & words = out.data.words;
+  auto & hdr_pool = out.data.hdr_pool;
+  entries.reserve(span / 160 + 16);
+  words.reserve(span / 28 + 16);
+  hdr_pool.reserve(span / 12 + 16);
   auto fail = [&](const std::string & msg, uint32_t line, int kind) { out.error = msg; out.error_line = line; out.error_kind = kind; };
   while (p < end) {
     if (*p != '>') { fail("\nError: Illegal header line in fasta file.\n", lineno, 2); break; }   // db.cc:492-494
@@ -197,20 +176,16 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
     uint32_t hlen = 0;
     while (h + hlen < le && h[hlen] != ' ' && h[hlen] != '\r' && h[hlen] != 0) { ++hlen; }      // db.cc:498-499
     if (hlen > 16777215u) { fail("\nError: Headers longer than 16,777,215 symbols are not supported.\n", lineno, 2); break; }
-    RawEntry e{};
-    e.piece = piece_no;
-    e.hdr_off = out.hdr_pool.size();
-    e.hdr_len = hlen;
-    e.lineno = lineno;
-    out.hdr_pool.insert(out.hdr_pool.end(), h, h + hlen);
-    out.hdr_pool.push_back('\0');
-    uint64_t key = 0;
-    for (uint32_t i = 0; i < 8; ++i) { key = (key << 8) | (i < hlen ? (unsigned char)h[i] : 0u); }
-    e.key8 = key;
+    swa_entry e{};
+    e.hdr_off = hdr_pool.size();
+    e.hdr_len_piece = hlen | (piece_no << 24);
+    const uint32_t entry_line = lineno;
+    hdr_pool.insert(hdr_pool.end(), h, h + hlen);
+    hdr_pool.push_back('\0');
     p = (le < end) ? le + 1 : end;
     ++lineno;
 
-    e.word_off = out.words.size();
+    e.word_off = words.size();
     uint64_t acc = 0;
     uint32_t fill = 0, len = 0;
     bool bad = false;
@@ -227,7 +202,7 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
         const uint64_t bits = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6) | (c4 << 8) | (c5 << 10) | (c6 << 12) | (c7 << 14);
         acc |= bits << (2u * fill);
         if (fill + 8u >= 32u) {
-          out.words.push_back(acc);
+          words.push_back(acc);
           const uint32_t used = 32u - fill;                    // nucleotides of `bits` that went into the full word
           acc = used < 8u ? bits >> (2u * used) : 0;
           fill = fill + 8u - 32u;
@@ -243,7 +218,7 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
         if (code >= 0) {
           acc |= (uint64_t)code << (2u * fill);
           ++len;
-          if (++fill == 32u) { out.words.push_back(acc); acc = 0; fill = 0; }
+          if (++fill == 32u) { words.push_back(acc); acc = 0; fill = 0; }
         } else if (ch == 0) {
           break;                                 // the reference's line scan stops at a NUL
         } else if (ch != '\n' && ch != '\r') {
@@ -262,19 +237,19 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
     }
     if (bad) { break; }
     if (len == 0) { fail("\nError: Empty sequence found on line \x01.\n", lineno - 1, 1); break; }   // db.cc:608-611
-    if (fill > 0) { out.words.push_back(acc); }
+    if (fill > 0) { words.push_back(acc); }
     e.seqlen = len;
     out.nucleotides += len;
     out.longest = std::max(out.longest, len);
     out.longest_header = std::max(out.longest_header, hlen);
 
     // abundance annotation (db.cc:286-343)
-    const char * hdr = out.hdr_pool.data() + e.hdr_off;
+    const char * hdr = hdr_pool.data() + e.hdr_off;
     int32_t s = 0, t = 0;
     int64_t number = 0, abundance = 0;
     const bool found = usearch ? usearch_abundance(hdr, hlen, s, t, number) : swarm_abundance(hdr, hlen, s, t, number);
     auto fail_late = [&](const std::string & msg, int kind) {
-      if (out.late_kind == 0) { out.late_error = msg; out.late_line = e.lineno; out.late_kind = kind; out.late_entry = out.entries.size(); }
+      if (out.late_kind == 0) { out.late_error = msg; out.late_line = entry_line; out.late_kind = kind; out.late_entry = entries.size(); }
     };
     bool entry_failed = false;
     if (found) {
@@ -289,13 +264,13 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
       s = (int32_t)hlen;
       t = s;
       if (append_abundance != 0) { abundance = append_abundance; }
-      else if (++out.missing == 1) { out.missing_line = e.lineno; out.missing_hdr = hdr; }
+      else if (++out.missing == 1) { out.missing_line = entry_line; out.missing_hdr = hdr; }
     }
     e.abundance = (uint64_t)abundance;
     e.ab_start = s;
     e.ab_end = t;
     if (!entry_failed && e.ab_start == 0 && e.ab_end == (int32_t)hlen) { fail_late("\nError: Empty sequence identifier.\n", 2); }
-    out.entries.push_back(e);
+    entries.push_back(e);
   }
   out.lines = lineno - 1;
 }
@@ -323,9 +298,6 @@ void run_transient(unsigned threads, F && fn) {
 template <typename F>
 void run_parallel(unsigned tasks, F && fn) { swa_pool::get().run(tasks, fn); }
 
-// the pages of a big block handed back in slices by all threads (the block stays mapped: its owner frees it as usual,
-// which then has nothing left to take apart)
-void release_pages_parallel(void * p, size_t bytes) { swa_release_pages(p, bytes); }
 
 struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the phase times to stderr
   bool on = std::getenv("SWARM_AMD_DB_TIMING") != nullptr;
@@ -393,15 +365,15 @@ void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less
 }  // namespace
 
 
-extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t append_abundance, int check_dup_seqs,
-                                     swa_hostdb ** out) {
+extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int64_t append_abundance, int check_dup_seqs,
+                                            swa_words_ready_fn on_words, void * user, swa_hostdb ** out) {
   if (out == nullptr || path == nullptr) { return SWA_E_ARG; }
   PhaseTimer timer;
   auto * db = new swa_hostdb();
   *out = db;
   Input in;
   if (!load_input(path, in, db->error)) { return SWA_E_ARG; }
-  struct Unmap { Input & i; ~Unmap() { i.unmap_rest(); } } unmap{in};
+  struct Unmap { Input & i; ~Unmap() { if (i.mapped) { ::munmap(const_cast<char *>(i.data), i.size); i.mapped = false; } } } unmap{in};
 
   int8_t map[256];
   std::memset(map, -1, sizeof(map));
@@ -423,39 +395,18 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     }
     cuts[t] = pos;
   }
-  std::vector<Piece> pieces(threads);
-  // (pieces of a mapped file of at least 1 MB each: their whole pages are unmapped by their own threads; what is left —
-  // the pages around the cuts — is listed now, before anybody unmaps anything)
-  constexpr size_t kPage = 4096;
-  const bool unmap_by_piece = in.mapped && threads > 1 && in.size / threads >= (1u << 20);
-  std::vector<std::pair<size_t, size_t>> interior(threads, {0, 0});
-  if (unmap_by_piece) {
-    in.still_mapped.clear();
-    size_t covered = 0;                                       // everything below is unmapped by a piece or listed
-    for (unsigned t = 0; t < threads; ++t) {
-      const size_t lo = std::max(covered, (cuts[t] + kPage - 1) & ~(kPage - 1));
-      const size_t hi = t + 1 == threads ? in.size : (cuts[t + 1] & ~(kPage - 1));
-      if (lo < hi) {
-        if (covered < lo) { in.still_mapped.push_back({covered, lo}); }
-        interior[t] = {lo, hi};
-        covered = t + 1 == threads ? in.size : hi;
-      }
-    }
-    if (covered < in.size) { in.still_mapped.push_back({covered, in.size}); }
-  }
+  std::vector<Piece> parsed(threads);
   run_parallel(threads, [&](unsigned t) {
     if (cuts[t] < cuts[t + 1]) {
-      parse_piece(in.data + cuts[t], in.data + cuts[t + 1], map, usearch != 0, append_abundance, t, pieces[t]);
+      parse_piece(in.data + cuts[t], in.data + cuts[t + 1], map, usearch != 0, append_abundance, t, parsed[t]);
     }
-    if (interior[t].first < interior[t].second) { ::munmap(const_cast<char *>(in.data) + interior[t].first, interior[t].second - interior[t].first); }
   });
-  in.unmap_rest();
-
   timer.lap("map + parallel parse");
+
   // ---- first error in file order, with absolute line numbers
   uint64_t lines_before = 0;
   for (unsigned t = 0; t < threads; ++t) {
-    Piece & pc = pieces[t];
+    Piece & pc = parsed[t];
     if (pc.error_kind != 0) {
       if (pc.error_kind == 1) {                     // the first \x01 stands for the absolute line number
         const size_t at = pc.error.find('\x01');
@@ -470,16 +421,26 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     lines_before += pc.lines;
   }
 
-  // ---- global view of the entries
-  std::vector<uint64_t> piece_first(threads + 1, 0);
-  for (unsigned t = 0; t < threads; ++t) { piece_first[t + 1] = piece_first[t] + pieces[t].entries.size(); }
+  // ---- what the pieces hold becomes the database's storage, as it lies
+  db->pieces.resize(threads);
+  std::vector<uint64_t> piece_first(threads + 1, 0);        // entries before piece p
+  db->piece_word_first.assign(threads + 1, 0);
+  for (unsigned t = 0; t < threads; ++t) {
+    db->pieces[t] = std::move(parsed[t].data);
+    piece_first[t + 1] = piece_first[t] + db->pieces[t].entries.size();
+    db->piece_word_first[t + 1] = db->piece_word_first[t] + db->pieces[t].words.size();
+    db->nucleotides += parsed[t].nucleotides;
+    db->longest = std::max(db->longest, parsed[t].longest);
+    db->longest_header = std::max(db->longest_header, parsed[t].longest_header);
+  }
+  const auto & pieces = db->pieces;
   // the first second-phase error in file order (abundance value / empty identifier), as entry index + text
   uint64_t late_at = ~0ull;
   std::string late_error;
   {
     uint64_t lines = 0;
     for (unsigned t = 0; t < threads && late_at == ~0ull; ++t) {
-      const Piece & pc = pieces[t];
+      const Piece & pc = parsed[t];
       if (pc.late_kind != 0) {
         late_at = piece_first[t] + pc.late_entry;
         late_error = pc.late_error;
@@ -493,145 +454,133 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
   if (n64 > 0xFFFFFFFEull) { db->error = "\nError: too many sequences.\n"; return SWA_E_ARG; }
   const uint32_t n = (uint32_t)n64;
   db->n = n;
-  // The arrays of the database (0.9 GB at 10 M amplicons) are sized — mapped and populated — by a helper thread while
-  // the entries are sorted: every size is known now, and populating fresh memory is what the sizing costs (57 ms on the
-  // critical path before, profiles/r05/NOTES.md).
-  uint64_t all_words = 0, all_hdr_bytes = 0;
-  for (const auto & pc : pieces) { all_words += pc.words.size(); all_hdr_bytes += pc.hdr_pool.size(); }
-  std::thread sizing([db, n, all_words, all_hdr_bytes]() {
-    db->seqs.resize(all_words + 1);
-    db->headers.resize(all_hdr_bytes + 1);
-    db->seq_off.resize((size_t)n + 1);
-    db->hdr_off.resize((size_t)n + 1);
-    db->seqlen.resize(n);
-    db->abundance.resize(n);
-    db->ab_start.resize(n);
-    db->ab_end.resize(n);
-  });
-  struct JoinSizing { std::thread & t; ~JoinSizing() { if (t.joinable()) { t.join(); } } } join_sizing{sizing};
-  swa_vec<const RawEntry *> ent(n);
-  run_parallel(threads, [&](unsigned t) {
-    uint64_t k = piece_first[t];
-    for (const auto & e : pieces[t].entries) { ent[k++] = &e; }
-  });
-  auto hdr_of = [&](const RawEntry * e) { return pieces[e->piece].hdr_pool.data() + e->hdr_off; };
-  auto words_of = [&](const RawEntry * e) { return pieces[e->piece].words.data() + e->word_off; };
-  for (const auto & pc : pieces) {
-    db->nucleotides += pc.nucleotides;
-    db->longest = std::max(db->longest, pc.longest);
-    db->longest_header = std::max(db->longest_header, pc.longest_header);
+  // The packed words are final: a caller with a GPU coming up beside this thread can start copying them (they are
+  // put in db order on the device, once the order is known: swa_db_stage_words / swa_db_upload_unordered)
+  if (on_words != nullptr && n != 0 && late_at == ~0ull) {
+    std::vector<const uint64_t *> ptrs(threads);
+    std::vector<uint64_t> counts(threads);
+    for (unsigned t = 0; t < threads; ++t) { ptrs[t] = pieces[t].words.data(); counts[t] = pieces[t].words.size(); }
+    on_words(user, ptrs.data(), counts.data(), threads);
   }
+  // entry g of the file (pieces hold almost equal shares of the entries: a guess and a step or two)
+  auto entry_at = [&](uint64_t g) -> const swa_entry & {
+    unsigned p = (unsigned)std::min<uint64_t>(threads - 1, g * threads / std::max<uint64_t>(n64, 1));
+    while (g < piece_first[p]) { --p; }
+    while (g >= piece_first[p + 1]) { ++p; }
+    return pieces[p].entries[g - piece_first[p]];
+  };
+  auto hdr_of = [&](const swa_entry & e) { return pieces[e.piece()].hdr_pool.data() + e.hdr_off; };
+  auto words_of = [&](const swa_entry & e) { return pieces[e.piece()].words.data() + e.word_off; };
+  timer.lap("pieces taken over");
 
-  timer.lap("entry index");
   // The two table-based checks below only read the parsed entries and produce an error or nothing: they run on their
-  // own threads next to the sort and the gather (at 10 M amplicons 50-100 ms that used to sit on the critical path);
-  // their verdict is taken where the sequential order of the checks puts it.
+  // own threads next to the sort (at 10 M amplicons 50-100 ms that used to sit on the critical path); their verdict is
+  // taken where the sequential order of the checks puts it.
   std::string dup_id_error, dup_seq_error;
   uint64_t dup_id_at = ~0ull, dup_seq_at = ~0ull;           // entry indices (the later entry of the earliest repetition)
   const unsigned check_threads = std::max(1u, threads / 2);     // (the sort next to them is the critical path)
   std::thread checker([&]() {
-  // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
-  {
-    const uint64_t tsize = n ? 2ull * n : 1;
-    std::unique_ptr<std::atomic<uint32_t>[]> idtab(new std::atomic<uint32_t>[tsize]);   // filled in parallel below
-    run_transient(check_threads, [&](unsigned t) {
-      for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
-    });
-    auto id_span = [&](const RawEntry * e, const char *& s, uint32_t & l) {
-      const char * hdr = hdr_of(e);
-      if (e->ab_start > 0) { s = hdr; l = (uint32_t)e->ab_start; }
-      else { s = hdr + e->ab_end; l = e->hdr_len - (uint32_t)e->ab_end; }
-    };
-    std::atomic<uint32_t> dup_entry{0xFFFFFFFFu};
-    run_transient(check_threads, [&](unsigned t) {
-      // entries and headers stream in file order; the table slot is the one random access per
-      // amplicon, so the slots of the next few identifiers are requested ahead of their turn
-      constexpr uint64_t kAhead = 8;
-      const uint64_t lo = n64 * t / check_threads, hi = n64 * (t + 1) / check_threads;
-      uint64_t ring[kAhead];
-      auto slot_of = [&](uint64_t i) {
-        const char * ids; uint32_t idl;
-        id_span(ent[i], ids, idl);
-        const uint64_t slot = bytes_hash(ids, idl) % tsize;
-        __builtin_prefetch(&idtab[slot], 1);
-        return slot;
+    // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
+    {
+      const uint64_t tsize = n ? 2ull * n : 1;
+      std::unique_ptr<std::atomic<uint32_t>[]> idtab(new std::atomic<uint32_t>[tsize]);   // filled in parallel below
+      run_transient(check_threads, [&](unsigned t) {
+        for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
+      });
+      auto id_span = [&](const swa_entry & e, const char *& s, uint32_t & l) {
+        const char * hdr = hdr_of(e);
+        if (e.ab_start > 0) { s = hdr; l = (uint32_t)e.ab_start; }
+        else { s = hdr + e.ab_end; l = e.hdr_len() - (uint32_t)e.ab_end; }
       };
-      for (uint64_t i = lo; i < std::min(hi, lo + kAhead); ++i) { ring[i % kAhead] = slot_of(i); }
-      for (uint64_t i = lo; i < hi; ++i) {
+      std::atomic<uint32_t> dup_entry{0xFFFFFFFFu};
+      run_transient(check_threads, [&](unsigned t) {
+        // entries and headers stream in file order; the table slot is the one random access per
+        // amplicon, so the slots of the next few identifiers are requested ahead of their turn
+        constexpr uint64_t kAhead = 8;
+        const uint64_t lo = n64 * t / check_threads, hi = n64 * (t + 1) / check_threads;
+        uint64_t ring[kAhead];
+        auto slot_of = [&](uint64_t i) {
+          const char * ids; uint32_t idl;
+          id_span(entry_at(i), ids, idl);
+          const uint64_t slot = bytes_hash(ids, idl) % tsize;
+          __builtin_prefetch(&idtab[slot], 1);
+          return slot;
+        };
+        for (uint64_t i = lo; i < std::min(hi, lo + kAhead); ++i) { ring[i % kAhead] = slot_of(i); }
+        for (uint64_t i = lo; i < hi; ++i) {
+          const char * ids; uint32_t idl;
+          id_span(entry_at(i), ids, idl);
+          uint64_t slot = ring[i % kAhead];
+          if (i + kAhead < hi) { ring[i % kAhead] = slot_of(i + kAhead); }
+          for (;;) {
+            uint32_t cur = idtab[slot].load(std::memory_order_acquire);
+            if (cur == 0xFFFFFFFFu) {
+              if (idtab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
+            }
+            const char * os; uint32_t ol;
+            id_span(entry_at(cur), os, ol);
+            if (ol == idl && std::memcmp(os, ids, idl) == 0) {
+              // report the LATER of the two, like the sequential scan of the reference does
+              uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
+              uint32_t seen = dup_entry.load();
+              while (later < seen && !dup_entry.compare_exchange_weak(seen, later)) { }
+              break;
+            }
+            slot = (slot + 1) % tsize;
+          }
+        }
+      });
+      if (dup_entry.load() != 0xFFFFFFFFu) {
         const char * ids; uint32_t idl;
-        id_span(ent[i], ids, idl);
-        uint64_t slot = ring[i % kAhead];
-        if (i + kAhead < hi) { ring[i % kAhead] = slot_of(i + kAhead); }
-        for (;;) {
-          uint32_t cur = idtab[slot].load(std::memory_order_acquire);
-          if (cur == 0xFFFFFFFFu) {
-            if (idtab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
-          }
-          const char * os; uint32_t ol;
-          id_span(ent[cur], os, ol);
-          if (ol == idl && std::memcmp(os, ids, idl) == 0) {
-            // report the LATER of the two, like the sequential scan of the reference does
-            uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
-            uint32_t seen = dup_entry.load();
-            while (later < seen && !dup_entry.compare_exchange_weak(seen, later)) { }
-            break;
-          }
-          slot = (slot + 1) % tsize;
-        }
+        id_span(entry_at(dup_entry.load()), ids, idl);
+        dup_id_error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
+        dup_id_at = dup_entry.load();
       }
-    });
-    if (dup_entry.load() != 0xFFFFFFFFu) {
-      const char * ids; uint32_t idl;
-      id_span(ent[dup_entry.load()], ids, idl);
-      dup_id_error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
-      dup_id_at = dup_entry.load();
     }
-  }
 
-  // duplicated sequences are checked here only for d > 1 (db.cc:763-790); d = 1 finds
-  // them while building the amplicon table (algod1.cc:1131-1150 / swa_d1_index_build)
-  if (check_dup_seqs && n > 1) {
-    const uint64_t tsize = 2ull * n;
-    std::unique_ptr<std::atomic<uint32_t>[]> tab(new std::atomic<uint32_t>[tsize]);
-    run_transient(check_threads, [&](unsigned t) {
-      for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
-    });
-    std::atomic<uint32_t> dup{0xFFFFFFFFu};                  // the earliest entry that repeats an earlier one's sequence
-    run_transient(check_threads, [&](unsigned t) {
-      for (uint64_t i = n64 * t / check_threads; i < n64 * (t + 1) / check_threads; ++i) {
-        const RawEntry * e = ent[i];
-        const uint64_t * w = words_of(e);
-        const uint32_t nw = (e->seqlen + 31u) >> 5;
-        uint64_t hsh = e->seqlen * 0x9E3779B97F4A7C15ull;
-        for (uint32_t k = 0; k < nw; ++k) { hsh = (hsh ^ w[k]) * 0xff51afd7ed558ccdull; hsh ^= hsh >> 32; }
-        uint64_t slot = hsh % tsize;
-        for (;;) {
-          uint32_t cur = tab[slot].load(std::memory_order_acquire);
-          if (cur == 0xFFFFFFFFu) {
-            if (tab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
+    // duplicated sequences are checked here only for d > 1 (db.cc:763-790); d = 1 finds
+    // them while building the amplicon table (algod1.cc:1131-1150 / swa_d1_index_build)
+    if (check_dup_seqs && n > 1) {
+      const uint64_t tsize = 2ull * n;
+      std::unique_ptr<std::atomic<uint32_t>[]> tab(new std::atomic<uint32_t>[tsize]);
+      run_transient(check_threads, [&](unsigned t) {
+        for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
+      });
+      std::atomic<uint32_t> dup{0xFFFFFFFFu};                  // the earliest entry that repeats an earlier one's sequence
+      run_transient(check_threads, [&](unsigned t) {
+        for (uint64_t i = n64 * t / check_threads; i < n64 * (t + 1) / check_threads; ++i) {
+          const swa_entry & e = entry_at(i);
+          const uint64_t * w = words_of(e);
+          const uint32_t nw = (e.seqlen + 31u) >> 5;
+          uint64_t hsh = e.seqlen * 0x9E3779B97F4A7C15ull;
+          for (uint32_t k = 0; k < nw; ++k) { hsh = (hsh ^ w[k]) * 0xff51afd7ed558ccdull; hsh ^= hsh >> 32; }
+          uint64_t slot = hsh % tsize;
+          for (;;) {
+            uint32_t cur = tab[slot].load(std::memory_order_acquire);
+            if (cur == 0xFFFFFFFFu) {
+              if (tab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
+            }
+            const swa_entry & o = entry_at(cur);
+            if (o.seqlen == e.seqlen && std::memcmp(words_of(o), w, nw * 8ull) == 0) {
+              const uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
+              uint32_t seen = dup.load();
+              while (later < seen && !dup.compare_exchange_weak(seen, later)) { }
+              break;
+            }
+            slot = (slot + 1) % tsize;
           }
-          const RawEntry * o = ent[cur];
-          if (o->seqlen == e->seqlen && std::memcmp(words_of(o), w, nw * 8ull) == 0) {
-            const uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
-            uint32_t seen = dup.load();
-            while (later < seen && !dup.compare_exchange_weak(seen, later)) { }
-            break;
-          }
-          slot = (slot + 1) % tsize;
         }
+      });
+      if (dup.load() != 0xFFFFFFFFu) {
+        dup_seq_at = dup.load();
+        dup_seq_error = "\nError: some fasta entries have identical sequences.\n"
+                    "Swarm expects dereplicated fasta files.\n"
+                    "Such files can be produced with swarm or vsearch:\n"
+                    " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
+                    "or\n"
+                    " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
       }
-    });
-    if (dup.load() != 0xFFFFFFFFu) {
-      dup_seq_at = dup.load();
-      dup_seq_error = "\nError: some fasta entries have identical sequences.\n"
-                  "Swarm expects dereplicated fasta files.\n"
-                  "Such files can be produced with swarm or vsearch:\n"
-                  " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
-                  "or\n"
-                  " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
     }
-  }
-
   });
   struct JoinChecker { std::thread & t; ~JoinChecker() { if (t.joinable()) { t.join(); } } } join_checker{checker};
   // The reference walks the entries once (db.cc:676-795): abundance value, empty identifier, repeated identifier are
@@ -653,7 +602,7 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     uint64_t missing = 0;
     uint32_t missing_line = 0;
     std::string missing_hdr;
-    for (const auto & pc : pieces) {
+    for (const auto & pc : parsed) {
       if (pc.missing != 0 && missing == 0) { missing_line = pc.missing_line; missing_hdr = pc.missing_hdr; }
       missing += pc.missing;
     }
@@ -670,25 +619,33 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
     }
   }
 
-  timer.lap("duplicate / missing checks");
   // ---- db order: abundance descending, then header (strcmp) ascending — db.cc:388-413.
-  // Parallel merge sort; the 8-byte big-endian header prefix decides most ties without
-  // touching the header text (equal prefixes fall through to strcmp: same order).
-  // The sort moves compact records (the keys travel with the index, no pointer chasing);
-  // inputs that are already in db order (swarm's own -w output, vsearch output) skip it.
-  // 16-byte records: the abundance saturates at 32 bits (two saturated ones are told apart through their entries)
+  // The sort moves compact records: the abundance (saturating at 32 bits: two saturated ones are told apart through
+  // their entries), the first 8 header bytes big endian (they decide most ties without touching the header text; equal
+  // prefixes fall through to strcmp: same order) and the entry's number.  Inputs that are already in db order (swarm's
+  // own -w output, vsearch output) skip it.
   struct SortRec { uint64_t key8; uint32_t abundance, entry; };
   swa_vec<SortRec> recs(n);
   run_parallel(threads, [&](unsigned t) {
-    for (uint64_t i = n64 * t / threads; i < n64 * (t + 1) / threads; ++i) {
-      recs[i] = SortRec{ent[i]->key8, (uint32_t)std::min<uint64_t>(ent[i]->abundance, 0xFFFFFFFFull), (uint32_t)i};
+    uint64_t g = piece_first[t];
+    const char * pool = pieces[t].hdr_pool.data();
+    for (const swa_entry & e : pieces[t].entries) {
+      const unsigned char * h = reinterpret_cast<const unsigned char *>(pool + e.hdr_off);
+      const uint32_t hlen = e.hdr_len();
+      uint64_t key = 0;
+      for (uint32_t i = 0; i < 8; ++i) { key = (key << 8) | (i < hlen ? h[i] : 0u); }
+      recs[g] = SortRec{key, (uint32_t)std::min<uint64_t>(e.abundance, 0xFFFFFFFFull), (uint32_t)g};
+      ++g;
     }
   });
   auto less = [&](const SortRec & a, const SortRec & b) {
     if (a.abundance != b.abundance) { return a.abundance > b.abundance; }
-    if (a.abundance == 0xFFFFFFFFu && ent[a.entry]->abundance != ent[b.entry]->abundance) { return ent[a.entry]->abundance > ent[b.entry]->abundance; }
+    if (a.abundance == 0xFFFFFFFFu) {
+      const uint64_t x = entry_at(a.entry).abundance, y = entry_at(b.entry).abundance;
+      if (x != y) { return x > y; }
+    }
     if (a.key8 != b.key8) { return a.key8 < b.key8; }
-    return std::strcmp(hdr_of(ent[a.entry]), hdr_of(ent[b.entry])) < 0;
+    return std::strcmp(hdr_of(entry_at(a.entry)), hdr_of(entry_at(b.entry))) < 0;
   };
   std::atomic<bool> sorted{true};
   run_parallel(threads, [&](unsigned t) {
@@ -697,115 +654,85 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
       if (less(recs[i], recs[i - 1])) { sorted.store(false, std::memory_order_relaxed); }
     }
   });
+  timer.lap("sort records made, order checked");
   if (!sorted.load()) {
     // Sample sort over the host cores: splitters from a regular sample, every thread files its share of the records
-    // under them (a binary search per record, the counts per thread and bucket give every record its place without
+    // under them (a binary search per record; the counts per thread and bucket give every record its place without
     // atomics), the buckets — 8 per thread, so that an unlucky splitter costs little — are sorted independently.  The
     // order is a strict total order (identifiers are unique), so the result equals std::sort's.  (r04 used libstdc++'s
-    // parallel multiway merge sort on 32-byte records: 151 ms at 10 M amplicons on 64 threads, the largest phase of the
-    // reader.)
-    timer.lap("  sort: records made, order checked");
+    // parallel multiway merge sort on 32-byte records: 151 ms at 10 M amplicons on 64 threads.)  32 threads, not 64: the
+    // bucket sorts took 17-20 ms on 32 and 56-93 ms on 64 threads beside the checks' 32 (lease r5b).
     swa_vec<SortRec> other(n);
-    timer.lap("  sort: second buffer");
-    // (32 threads, not 64: the bucket sorts took 17-20 ms on 32 and 56-93 ms on 64 threads of the 2 x 64-core host, on one
-    // socket as well as on two — lease r5b; SWARM_AMD_SORT_THREADS overrides)
     const char * env_sort = std::getenv("SWARM_AMD_SORT_THREADS");
     const unsigned sort_threads = std::max(1u, std::min(threads, env_sort != nullptr ? (unsigned)std::atoi(env_sort) : 32u));
     parallel_sample_sort(recs.data(), other.data(), n64, sort_threads, less, &timer);
   }
-  auto order = [&](uint64_t k) { return recs[k].entry; };
   timer.lap("sort");
-  // ---- contiguous SoA in sorted order (offsets by prefix sum, copies in parallel)
-  timer.lap("  (sort ends)");
-  sizing.join();
-  timer.lap("  gather: arrays sized (waited for)");
-  uint64_t woff = 0, hoff = 0;
-  {
-    // offsets by a two-level prefix sum: per-thread block totals, then each thread fills its block
-    std::vector<uint64_t> wsum(threads + 1, 0), hsum(threads + 1, 0);
-    run_parallel(threads, [&](unsigned t) {
-      uint64_t w = 0, h = 0;
-      const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
-      for (uint64_t k = lo; k < hi; ++k) {
-        if (k + 16 < hi) { __builtin_prefetch(ent[recs[k + 16].entry]); }
-        const RawEntry * e = ent[recs[k].entry];
-        const uint32_t words = (e->seqlen + 31u) >> 5;
-        db->seqlen[k] = words;                               // (parked here for the second pass; the gather overwrites it)
-        db->ab_end[k] = (int32_t)e->hdr_len;
-        w += words; h += e->hdr_len + 1u;
-      }
-      wsum[t + 1] = w; hsum[t + 1] = h;
-    });
-    for (unsigned t = 0; t < threads; ++t) { wsum[t + 1] += wsum[t]; hsum[t + 1] += hsum[t]; }
-    run_parallel(threads, [&](unsigned t) {
-      uint64_t w = wsum[t], h = hsum[t];
-      for (uint64_t k = n64 * t / threads; k < n64 * (t + 1) / threads; ++k) {
-        db->seq_off[k] = w;
-        db->hdr_off[k] = h;
-        w += db->seqlen[k];
-        h += (uint64_t)db->ab_end[k] + 1u;
-      }
-    });
-    woff = wsum[threads];
-    hoff = hsum[threads];
-  }
-  db->seq_off[n] = woff;
-  db->hdr_off[n] = hoff;
-  timer.lap("  gather: offsets");
-  if (woff != all_words || hoff != all_hdr_bytes) { db->error = "\nError: internal: the pieces' sizes do not add up.\n"; return SWA_E_ARG; }
+
+  // ---- db order as pointers into the pieces; the plain arrays the GPU upload and the per-swarm sums read
+  db->ent.resize(n);
+  db->seqlen.resize(n);
+  db->abundance.resize(n);
+  db->src_off.resize(n);
+  timer.lap("db-order arrays sized");
   run_parallel(threads, [&](unsigned t) {
-    // the entries, their words and their headers are three random reads per amplicon: keep a
-    // few of them in flight
     const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
-    constexpr uint64_t kAheadEntry = 16, kAheadData = 8;
     for (uint64_t k = lo; k < hi; ++k) {
-      if (k + kAheadEntry < hi) { __builtin_prefetch(ent[order(k + kAheadEntry)]); }
-      if (k + kAheadData < hi) {
-        const RawEntry * f = ent[order(k + kAheadData)];
-        __builtin_prefetch(words_of(f));
-        __builtin_prefetch(hdr_of(f));
-      }
-      const RawEntry * e = ent[order(k)];
-      std::memcpy(&db->seqs[db->seq_off[k]], words_of(e), ((e->seqlen + 31u) >> 5) * 8ull);
-      std::memcpy(&db->headers[db->hdr_off[k]], hdr_of(e), (size_t)e->hdr_len + 1);
-      db->seqlen[k] = e->seqlen;
-      db->abundance[k] = e->abundance;
-      db->ab_start[k] = e->ab_start;
-      db->ab_end[k] = e->ab_end;
+      if (k + 16 < hi) { __builtin_prefetch(&entry_at(recs[k + 16].entry)); }
+      const swa_entry & e = entry_at(recs[k].entry);
+      db->ent[k] = &e;
+      db->seqlen[k] = e.seqlen;
+      db->abundance[k] = e.abundance;
+      db->src_off[k] = db->piece_word_first[e.piece()] + e.word_off;
     }
   });
-  db->seqs[woff] = 0;
-  timer.lap("gather into db order");
+  timer.lap("db order");
   if (const int rc_checks = checks_verdict()) { return rc_checks; }
   timer.lap("identifier / sequence checks (waited for)");
-  // The parse buffers and the sort records (1.6 GB at 10 M amplicons) go back to the kernel now, every piece by the
-  // thread that made it and the two big arrays in slices: taking their pages apart is 75 ms a GB for ONE thread — at
-  // process exit, where round 4 left it (0.09-0.4 s of exit), or on a detached thread, which held up the first upload —
-  // and a few ms on all of them.
-  run_parallel(threads, [&](unsigned t) { Piece().swap_buffers(pieces[t]); });
-  release_pages_parallel(ent.data(), ent.size() * sizeof(ent[0]));
-  release_pages_parallel(recs.data(), recs.size() * sizeof(recs[0]));
-  timer.lap("hand-off of parse buffers");
   return SWA_OK;
 }
 
-void swa_release_pages(void * p, size_t bytes) {
-  constexpr size_t kPage = 4096, kSlice = size_t(16) << 20;
-  if (p == nullptr || bytes < (size_t(8) << 20)) { return; }
-  const uintptr_t lo = ((uintptr_t)p + kPage - 1) & ~(uintptr_t)(kPage - 1), hi = ((uintptr_t)p + bytes) & ~(uintptr_t)(kPage - 1);
-  if (hi <= lo) { return; }
-  const unsigned slices = (unsigned)((hi - lo + kSlice - 1) / kSlice);
-  swa_pool::get().run(slices, [&](unsigned k) {
-    const uintptr_t a = lo + (uintptr_t)k * kSlice, b = std::min<uintptr_t>(hi, a + kSlice);
-    (void)::madvise(reinterpret_cast<void *>(a), b - a, MADV_DONTNEED);
-  });
+extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t append_abundance, int check_dup_seqs,
+                                     swa_hostdb ** out) {
+  return swa_hostdb_read_fasta_staged(path, usearch, append_abundance, check_dup_seqs, nullptr, nullptr, out);
 }
 
 extern "C" void swa_hostdb_free(swa_hostdb * db) { delete db; }
 
 extern "C" const char * swa_hostdb_error(const swa_hostdb * db) { return db != nullptr ? db->error.c_str() : ""; }
 
+// the packed sequences contiguous in db order (swa_db_view): gathered from the pieces the first time somebody asks
+static void order_on_host(swa_hostdb * db) {
+  if (db->ordered) { return; }
+  const uint64_t n = db->n;
+  db->seq_off.resize(n + 1);
+  const unsigned threads = swa_pool::get().size();
+  std::vector<uint64_t> sum(threads + 1, 0);
+  run_parallel(threads, [&](unsigned t) {
+    uint64_t w = 0;
+    for (uint64_t k = n * t / threads; k < n * (t + 1) / threads; ++k) { w += (db->seqlen[k] + 31u) >> 5; }
+    sum[t + 1] = w;
+  });
+  for (unsigned t = 0; t < threads; ++t) { sum[t + 1] += sum[t]; }
+  db->seqs.resize(sum[threads] + 1);
+  run_parallel(threads, [&](unsigned t) {
+    uint64_t w = sum[t];
+    const uint64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+    for (uint64_t k = lo; k < hi; ++k) {
+      if (k + 8 < hi) { __builtin_prefetch(db->words((uint32_t)(k + 8))); }
+      const uint64_t nw = (db->seqlen[k] + 31u) >> 5;
+      db->seq_off[k] = w;
+      std::memcpy(&db->seqs[w], db->words((uint32_t)k), nw * 8ull);
+      w += nw;
+    }
+  });
+  db->seq_off[n] = sum[threads];
+  db->seqs[sum[threads]] = 0;
+  db->ordered = true;
+}
+
 extern "C" void swa_hostdb_view(const swa_hostdb * db, swa_db_view * v) {
+  order_on_host(const_cast<swa_hostdb *>(db));
   v->n = db->n;
   v->longest = db->longest;
   v->seqs = db->seqs.data();
@@ -814,9 +741,24 @@ extern "C" void swa_hostdb_view(const swa_hostdb * db, swa_db_view * v) {
   v->abundance = db->abundance.data();
 }
 
+extern "C" void swa_hostdb_unordered_view(const swa_hostdb * db, swa_db_unordered_view * v) {
+  auto * mdb = const_cast<swa_hostdb *>(db);
+  mdb->piece_ptrs.resize(db->pieces.size());
+  mdb->piece_counts.resize(db->pieces.size());
+  for (size_t p = 0; p < db->pieces.size(); ++p) { mdb->piece_ptrs[p] = db->pieces[p].words.data(); mdb->piece_counts[p] = db->pieces[p].words.size(); }
+  v->n = db->n;
+  v->longest = db->longest;
+  v->pieces = (uint32_t)db->pieces.size();
+  v->piece_words = mdb->piece_ptrs.data();
+  v->piece_word_count = mdb->piece_counts.data();
+  v->src_off = db->src_off.data();
+  v->seqlen = db->seqlen.data();
+  v->abundance = db->abundance.data();
+}
+
 extern "C" uint64_t swa_hostdb_nucleotides(const swa_hostdb * db) { return db->nucleotides; }
 
 extern "C" const char * swa_hostdb_header(const swa_hostdb * db, uint32_t i, uint32_t * len) {
-  if (len != nullptr) { *len = (uint32_t)(db->hdr_off[i + 1] - db->hdr_off[i] - 1); }
-  return db->headers.data() + db->hdr_off[i];
+  if (len != nullptr) { *len = db->ent[i]->hdr_len(); }
+  return db->hdr(i);
 }

@@ -64,30 +64,47 @@ struct swa_default_init_allocator {
 };
 template <class T> using swa_vec = std::vector<T, swa_default_init_allocator<T>>;
 
-// The pages of a big block given back to the kernel in slices by the worker threads (MADV_DONTNEED works under the
-// shared memory-map lock, so the slices go in parallel); the block itself stays mapped for its owner to free.  Freeing
-// a gigabyte costs one thread ~75 ms on the bench host — at exit, inside the caller's wall time.
-void swa_release_pages(void * p, size_t bytes);
+
+// One FASTA record as parsed.  The parser works on pieces of the file (one per thread); what it produces — the entries,
+// their headers, their packed words — STAYS where the parser put it, in file order, and is the database's storage: db
+// order is the array `ent` of pointers into it (and, for the GPU, the offsets of the amplicons' words: the device gathers
+// them, swa_db_upload_unordered).  Round 4 copied everything into db-order arrays on the host: 0.9 GB more to fault in
+// and to take apart at exit, and the largest phase of the reader after the sort (profiles/r05/NOTES.md).
+struct swa_entry {
+  uint64_t hdr_off;          // into the header pool of its piece
+  uint64_t word_off;         // into the word pool of its piece
+  uint64_t abundance;
+  uint32_t hdr_len_piece;    // header length (24 bits) | piece number << 24
+  uint32_t seqlen;
+  int32_t ab_start, ab_end;  // abundance annotation [start, end) inside the header
+  uint32_t hdr_len() const { return hdr_len_piece & 0xFFFFFFu; }
+  uint32_t piece() const { return hdr_len_piece >> 24; }
+};
+struct swa_piece {
+  std::vector<swa_entry> entries;
+  std::vector<char> hdr_pool;          // NUL-terminated headers
+  std::vector<uint64_t> words;         // packed sequences, every one from a word boundary
+};
 
 struct swa_hostdb {
   uint32_t n = 0;
   uint32_t longest = 0;
   uint32_t longest_header = 0;
   uint64_t nucleotides = 0;
-  swa_vec<uint64_t> seqs;        // packed words, db order, contiguous
-  swa_vec<uint64_t> seq_off;     // n + 1
-  swa_vec<uint32_t> seqlen;
+  std::vector<swa_piece> pieces;            // the parsed file (at most 255 pieces)
+  std::vector<uint64_t> piece_word_first;   // words in the pools of the pieces before piece p (pieces + 1 entries)
+  // db order (abundance descending, then header ascending — src/db.cc:388-413)
+  swa_vec<const swa_entry *> ent;           // amplicon k
+  swa_vec<uint32_t> seqlen;                 // what the GPU upload and the per-swarm sums read as plain arrays
   swa_vec<uint64_t> abundance;
-  swa_vec<char> headers;         // NUL-terminated headers, db order
-  swa_vec<uint64_t> hdr_off;     // n + 1
-  swa_vec<int32_t> ab_start;     // abundance annotation span inside each header
-  swa_vec<int32_t> ab_end;
+  swa_vec<uint64_t> src_off;                // first word of amplicon k in the concatenation of the pieces' word pools
+  // the packed sequences in db order, contiguous (the layout of swa_db_view): made on demand, swa_hostdb_view
+  swa_vec<uint64_t> seqs, seq_off;
+  bool ordered = false;
+  std::vector<const uint64_t *> piece_ptrs;   // what swa_hostdb_unordered_view points at
+  std::vector<uint64_t> piece_counts;
   std::string error;
-  ~swa_hostdb() {
-    swa_release_pages(seqs.data(), seqs.size() * sizeof(uint64_t));
-    swa_release_pages(headers.data(), headers.size());
-    swa_release_pages(seq_off.data(), seq_off.size() * sizeof(uint64_t));
-    swa_release_pages(hdr_off.data(), hdr_off.size() * sizeof(uint64_t));
-    swa_release_pages(abundance.data(), abundance.size() * sizeof(uint64_t));
-  }
+
+  const char * hdr(uint32_t k) const { const swa_entry * e = ent[k]; return pieces[e->piece()].hdr_pool.data() + e->hdr_off; }
+  const uint64_t * words(uint32_t k) const { const swa_entry * e = ent[k]; return pieces[e->piece()].words.data() + e->word_off; }
 };

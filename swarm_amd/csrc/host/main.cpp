@@ -10,6 +10,7 @@
 // Environment (no new flags, to stay drop-in): SWARM_AMD_DEVICE = HIP device ordinal (default 0);
 // SWARM_AMD_DEVICES = 0,1,2,... : d >= 1 on several GPUs (swa_multi_*: one rank per entry, RCCL exchange).
 #include <chrono>
+#include <future>
 #include <thread>
 #include "../../../include/swarm_amd.h"
 #include "../../../include/swarm_amd_host.h"
@@ -273,32 +274,54 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
   swa_ctx * early_ctx = nullptr;
   int early_rc = SWA_OK;
   std::thread early;
+  // what the reader says as soon as the packed words are final (before it sorts): the helper thread copies them to the GPU
+  // while this thread sorts (swa_db_stage_words; the GPU puts them in db order later, swa_db_upload_unordered)
+  struct Words { std::vector<const uint64_t *> pools; std::vector<uint64_t> counts; };
+  std::promise<Words> words_promise;
+  std::future<Words> words_ready = words_promise.get_future();
+  bool words_told = false;
   if (!use_multi) {
     const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
     const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
-    early = std::thread([&early_ctx, &early_rc, device]() {
+    early = std::thread([&early_ctx, &early_rc, &words_ready, device]() {
       early_rc = swa_ctx_create(device, nullptr, &early_ctx);
       stamp("(helper thread) context created");
       if (early_rc == SWA_OK) { (void)swa_ctx_warmup(early_ctx); }
       stamp("(helper thread) code objects loaded, first copies done");
+      const Words w = words_ready.get();
+      if (early_rc == SWA_OK && !w.pools.empty()) {
+        (void)swa_db_stage_words(early_ctx, w.pools.data(), w.counts.data(), (uint32_t)w.pools.size());   // (a failure shows at the upload)
+        stamp("(helper thread) packed words on their way to the GPU");
+      }
     });
   }
 
-  if (std::getenv("SWARM_AMD_SERIAL_INIT") != nullptr && early.joinable()) { early.join(); stamp("(experiment) GPU start-up waited for before the read"); }
   // ---- read the database (seam L2, host side)
   swa_hostdb * db = nullptr;
-  int rc = swa_hostdb_read_fasta(o.input.c_str(), o.usearch ? 1 : 0, o.append_abundance, o.differences > 1 ? 1 : 0, &db);
+  struct Tell { std::promise<Words> * promise; bool * told; } tell{&words_promise, &words_told};
+  const swa_words_ready_fn on_words = [](void * user, const uint64_t * const * pools, const uint64_t * counts, uint32_t pieces) {
+    auto * t = static_cast<Tell *>(user);
+    Words w;
+    w.pools.assign(pools, pools + pieces);
+    w.counts.assign(counts, counts + pieces);
+    *t->told = true;
+    t->promise->set_value(std::move(w));
+  };
+  int rc = swa_hostdb_read_fasta_staged(o.input.c_str(), o.usearch ? 1 : 0, o.append_abundance, o.differences > 1 ? 1 : 0,
+                                        use_multi ? nullptr : on_words, &tell, &db);
+  if (!words_told) { words_promise.set_value(Words{}); }
+  stamp("database read and ordered");
   if (early.joinable()) { early.join(); }
   if (rc != SWA_OK) { die_raw(db != nullptr ? swa_hostdb_error(db) : "\nError: out of memory"); }
   phase(o, "Reading sequences:");
   phase(o, "Indexing database:");
   phase(o, "Abundance sorting:");
-  swa_db_view view{};
-  swa_hostdb_view(db, &view);
+  swa_db_unordered_view uview{};
+  swa_hostdb_unordered_view(db, &uview);
   std::fprintf(g_log, "Database info:     %" PRIu64 " nt in %u sequences, longest %u nt\n", swa_hostdb_nucleotides(db),
-               view.n, view.longest);
+               uview.n, uview.longest);
 
-  const uint32_t n = view.n;
+  const uint32_t n = uview.n;
   swa_ctx * ctx = nullptr;
   swa_multi * multi = nullptr;           // d = 1 on several GPUs: SWARM_AMD_DEVICES=0,1,2,... (one rank per entry)
   if (n > 0) {
@@ -309,6 +332,8 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       if (std::getenv("SWARM_AMD_MULTI_REPORT") != nullptr) {      // (tools/scale_check.sh asserts on this line)
         std::fprintf(stderr, "multi: %d ranks, exchange = %s\n", swa_multi_size(multi), swa_multi_uses_rccl(multi) ? "rccl" : "device-to-device copies");
       }
+      swa_db_view view{};                                    // (several GPUs: the db-order host arrays, gathered on the host)
+      swa_hostdb_view(db, &view);
       if (swa_multi_db_upload(multi, &view) != SWA_OK) { die(swa_multi_last_error(multi)); }
       stamp("database uploaded (all ranks)");
       ctx = swa_multi_ctx(multi, 0);
@@ -316,7 +341,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       if (early_rc != SWA_OK || early_ctx == nullptr) { die("no usable gfx950 GPU (this build has no CPU fallback)."); }
       ctx = early_ctx;
       stamp("context created");
-      if (swa_db_upload(ctx, &view) != SWA_OK) { die(swa_last_error(ctx)); }
+      if (swa_db_upload_unordered(ctx, &uview) != SWA_OK) { die(swa_last_error(ctx)); }
       stamp("database uploaded");
     }
   }

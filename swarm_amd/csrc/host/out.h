@@ -108,13 +108,13 @@ void swa_format_in_pieces(BufOut & o, size_t items, bool parallel, F && format) 
 
 namespace swa_out {
 
-inline const char * hdr(const swa_hostdb * db, uint32_t i) { return db->headers.data() + db->hdr_off[i]; }
-inline uint32_t hdrlen(const swa_hostdb * db, uint32_t i) { return (uint32_t)(db->hdr_off[i + 1] - db->hdr_off[i] - 1); }
+inline const char * hdr(const swa_hostdb * db, uint32_t i) { return db->hdr(i); }
+inline uint32_t hdrlen(const swa_hostdb * db, uint32_t i) { return db->ent[i]->hdr_len(); }
 
 // fprint_id (src/db.cc:946-968)
 inline void id(BufOut & o, const swa_hostdb * db, uint32_t i, bool usearch, int64_t append_abundance) {
   o.write(hdr(db, i), hdrlen(db, i));
-  if (append_abundance != 0 && db->ab_start[i] == db->ab_end[i]) {
+  if (append_abundance != 0 && db->ent[i]->ab_start == db->ent[i]->ab_end) {
     if (usearch) { o.str(";size="); o.u64(db->abundance[i]); o.put(';'); }
     else { o.put('_'); o.u64(db->abundance[i]); }
   }
@@ -122,7 +122,7 @@ inline void id(BufOut & o, const swa_hostdb * db, uint32_t i, bool usearch, int6
 
 // fprint_id_noabundance (src/db.cc:971-999)
 inline void id_noabundance(BufOut & o, const swa_hostdb * db, uint32_t i, bool usearch) {
-  const int s = db->ab_start[i], e = db->ab_end[i], len = (int)hdrlen(db, i);
+  const int s = db->ent[i]->ab_start, e = db->ent[i]->ab_end, len = (int)hdrlen(db, i);
   if (s < e) {
     o.write(hdr(db, i), (size_t)s);
     if (usearch) {
@@ -136,13 +136,13 @@ inline void id_noabundance(BufOut & o, const swa_hostdb * db, uint32_t i, bool u
 
 // fprint_id_with_new_abundance (src/db.cc:1002-1026)
 inline void id_new_abundance(BufOut & o, const swa_hostdb * db, uint32_t i, uint64_t abundance, bool usearch) {
-  o.write(hdr(db, i), (size_t)db->ab_start[i]);
+  o.write(hdr(db, i), (size_t)db->ent[i]->ab_start);
   if (usearch) {
-    if (db->ab_start[i] > 0) { o.put(';'); }
+    if (db->ent[i]->ab_start > 0) { o.put(';'); }
     o.str("size=");
     o.u64(abundance);
     o.put(';');
-    o.write(hdr(db, i) + db->ab_end[i], (size_t)((int)hdrlen(db, i) - db->ab_end[i]));
+    o.write(hdr(db, i) + db->ent[i]->ab_end, (size_t)((int)hdrlen(db, i) - db->ent[i]->ab_end));
   } else {
     o.put('_');
     o.u64(abundance);
@@ -151,7 +151,7 @@ inline void id_new_abundance(BufOut & o, const swa_hostdb * db, uint32_t i, uint
 
 // db_fprintseq (src/db.cc:925-943)
 inline void sequence(BufOut & o, const swa_hostdb * db, uint32_t i, std::string & scratch) {
-  const uint64_t * w = db->seqs.data() + db->seq_off[i];
+  const uint64_t * w = db->words(i);
   const uint32_t len = db->seqlen[i];
   scratch.resize(len);
   for (uint32_t p = 0; p < len; ++p) { scratch[p] = "ACGT"[(w[p >> 5] >> ((p & 31u) << 1)) & 3u]; }

@@ -152,6 +152,8 @@ struct swa_ctx {
   uint32_t index_first = 0, index_count = 0;   // the range of the last index build (network_run_guarded repeats it)
   bool index_routed = false;
   uint32_t guard_retries = 0;                  // steps repeated after the guard found counts that did not balance
+  swa_dbuf d_words_stage;                      // swa_db_stage_words: the reader's word pools, file order
+  const void * staged_first = nullptr; uint64_t staged_words = 0;
   bool cluster_ready = false;                  // swa_d1_cluster_device's arrays lie in d_cluster (swa_d1_cluster_fetch)
   uint32_t cluster_maxgen = 0;
   int pair_blocks[4] = {};                      // workgroups of k_d1_group_pairs a CU holds, per width class (0: not asked yet)

@@ -303,9 +303,10 @@ def gen_bin() -> Path:
     return out
 
 
-def gen_fasta(path, n: int, length: int, seed: int, max_edits: int = 1, light_frac: float = 0.0) -> None:
+def gen_fasta(path, n: int, length: int, seed: int, max_edits: int = 1, light_frac: float = 0.0, env: dict | None = None) -> None:
+    """tools/gen_amplicons; env: the generator's switches (GEN_FLANK, GEN_CORE, GEN_ZIPF, GEN_CONSERVED)"""
     subprocess.run([str(gen_bin()), str(n), str(length), str(seed), str(max_edits), str(light_frac), str(path)],
-                   check=True)
+                   check=True, env=dict(os.environ, **env) if env else None)
 
 
 # -------------------------------------------------------------------- device memory poison

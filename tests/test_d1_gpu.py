@@ -493,6 +493,40 @@ def test_conserved_flanks_move_the_anchor_windows(tmp_path, monkeypatch, n, seed
         ctx.close()
 
 
+@pytest.mark.parametrize("n,seed,flank", [(30000, 73, 70), (120000, 74, 70), (30000, 75, 64)])
+def test_flanks_wider_than_a_window_are_served_exactly(tmp_path, n, seed, flank):
+    """Conserved flanks that swallow a whole 64-nt window (primers left on): every amplicon shares its
+    first and last 64 / 70 nt, so both default indexes put everybody in one group — whatever the build chooses instead
+    (windows moved inwards, the tiled or the enumerating kernel), the network is the oracle's."""
+    from swarm_amd import Context
+    fa = tmp_path / "flanks70.fa"
+    _conserved_flank_set(fa, n, seed, flank)
+    db = S.db_from_fasta(fa)
+    ctx = Context(0)
+    try:
+        off, nb = _check_vs_oracle(ctx, db)
+        assert len(nb) > n // 2
+        _check_vs_oracle(ctx, db, ncb=True)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n,seed", [(40000, 81), (150000, 82)])
+def test_v4_like_reads_with_conserved_stretches(tmp_path, n, seed):
+    """250-nt reads whose centroids agree in 60 % of their positions (stretches of 8..40 nt, both ends conserved:
+    tools/gen_amplicons GEN_CONSERVED): windows at the ends are shared by far more than a family."""
+    from swarm_amd import Context
+    fa = tmp_path / "v4.fa"
+    S.gen_fasta(fa, n, 250, seed, env={"GEN_CONSERVED": "60"})
+    db = S.db_from_fasta(fa)
+    ctx = Context(0)
+    try:
+        off, nb = _check_vs_oracle(ctx, db)
+        assert len(nb) > n // 2
+    finally:
+        ctx.close()
+
+
 def test_tiled_pair_kernel_on_big_groups(tmp_path, monkeypatch):
     """k_d1_pairs_tiled (64 x 64 tiles) in place of the enumerating kernel for groups of 65..2048, default anchors."""
     from swarm_amd import Context

@@ -19,6 +19,9 @@
  *         GEN_FLANK=<k> in the environment: all centroids share their first and last k nucleotides
  *         GEN_CORE=<k>:  all centroids are identical except for a k-nt core in the middle (conserved everywhere but
  *                        a hypervariable region)
+ *         GEN_CONSERVED=<pct>: that share of the positions (in alternating conserved / variable stretches of 8..40 nt, both
+ *                        ends conserved, the same layout and the same nucleotides in every centroid) is identical in all
+ *                        centroids: what a 16S V4 read looks like to anything that groups sequences by windows
  *         GEN_ZIPF=<s>:  family sizes follow Zipf's law: the family of centroid r (r = 1, 2, ...) receives the share
  *                        s / r of all derived amplicons (until the shares add up to 1/2); the rest as usual.  s = 0.1
  *                        makes the largest family a tenth of the set: swarms of 10^5 members at n = 10^6
@@ -33,6 +36,7 @@ typedef struct { uint64_t s; } rng_t;
 static uint32_t g_flank = 0;        /* GEN_FLANK environment variable (see below) */
 static uint32_t g_core = 0;         /* GEN_CORE */
 static double g_zipf = 0.0;         /* GEN_ZIPF */
+static uint32_t g_conserved = 0;    /* GEN_CONSERVED (per cent) */
 #define ZIPF_FAMILIES 64
 
 static uint64_t rng_next(rng_t * r) {            /* splitmix64 */
@@ -153,6 +157,19 @@ int gen_amplicons_fasta(uint64_t n, uint32_t L, uint64_t seed, uint32_t max_edit
         const uint32_t lo = (len - g_core) / 2, hi = lo + g_core;
         for (uint32_t i = 0; i < len; ++i) { const uint8_t b = (uint8_t)(rng_next(&cr) >> 62); if (i < lo || i >= hi) tmp[i] = b; }
       }
+      if (g_conserved > 0 && g_conserved < 100) {
+        /* stretches alternate, conserved first; a variable stretch follows a conserved one of c nt with
+           c * (100 - pct) / pct nt, so the share holds along the sequence; the last 12 nt are conserved too */
+        rng_t lay; lay.s = 0xC0115E27ULL;
+        rng_t cons; cons.s = 0x0BA5E5ULL;
+        uint32_t at = 0;
+        while (at < len) {
+          const uint32_t c = 8u + (uint32_t)rng_below(&lay, 33);
+          for (uint32_t i = at; i < at + c && i < len; ++i) tmp[i] = (uint8_t)(rng_next(&cons) >> 62);
+          at += c + (c * (100u - g_conserved) + g_conserved / 2u) / g_conserved;
+        }
+        for (uint32_t i = len > 12 ? len - 12 : 0; i < len; ++i) tmp[i] = (uint8_t)(rng_next(&cons) >> 62);
+      }
       if (g_flank > 0 && 2u * g_flank < len) {
         rng_t fr; fr.s = 0x5EEDF1A2ULL;
         for (uint32_t i = 0; i < g_flank; ++i) tmp[i] = (uint8_t)(rng_next(&fr) >> 62);
@@ -240,6 +257,7 @@ int main(int argc, char ** argv) {
   if (getenv("GEN_FLANK") != NULL) g_flank = (uint32_t)atoi(getenv("GEN_FLANK"));
   if (getenv("GEN_CORE") != NULL) g_core = (uint32_t)atoi(getenv("GEN_CORE"));
   if (getenv("GEN_ZIPF") != NULL) g_zipf = atof(getenv("GEN_ZIPF"));
+  if (getenv("GEN_CONSERVED") != NULL) g_conserved = (uint32_t)atoi(getenv("GEN_CONSERVED"));
   const int rc = gen_amplicons_fasta(strtoull(argv[1], NULL, 10), (uint32_t)atoi(argv[2]),
                                      strtoull(argv[3], NULL, 10), (uint32_t)atoi(argv[4]),
                                      atof(argv[5]), argv[6]);
