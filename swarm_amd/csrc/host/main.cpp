@@ -16,6 +16,7 @@
 #include "../../../include/swarm_amd_host.h"
 
 #include <getopt.h>
+#include <sys/resource.h>
 #include <omp.h>
 #include <unistd.h>
 
@@ -212,6 +213,16 @@ void stamp(const char * what) {
   if (on) { std::fprintf(stderr, "[t %8.3f] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what); }
 }
 
+// SWARM_AMD_TIMING: what the process has cost so far (CPU seconds, page faults, context switches)
+void stamp_usage(const char * what) {
+  if (std::getenv("SWARM_AMD_TIMING") == nullptr) { return; }
+  struct rusage u{};
+  getrusage(RUSAGE_SELF, &u);
+  std::fprintf(stderr, "[usage] %-28s user %.3f s  sys %.3f s  minor faults %ld  major %ld  switches %ld voluntary, %ld involuntary\n", what,
+               (double)u.ru_utime.tv_sec + 1e-6 * (double)u.ru_utime.tv_usec, (double)u.ru_stime.tv_sec + 1e-6 * (double)u.ru_stime.tv_usec,
+               u.ru_minflt, u.ru_majflt, u.ru_nvcsw, u.ru_nivcsw);
+}
+
 void phase(const Options &, const char * prompt) {
   std::fprintf(g_log, "%s 100%%\n", prompt);
   std::fflush(g_log);
@@ -280,9 +291,10 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
   std::promise<Words> words_promise;
   std::future<Words> words_ready = words_promise.get_future();
   bool words_told = false;
-  if (!use_multi) {
-    const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
-    const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
+  const bool gpu_after_read = std::getenv("SWARM_AMD_GPU_AFTER_READ") != nullptr;     // (experiment: the reader alone, then the GPU)
+  const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
+  const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
+  auto start_helper = [&]() {
     early = std::thread([&early_ctx, &early_rc, &words_ready, device]() {
       early_rc = swa_ctx_create(device, nullptr, &early_ctx);
       stamp("(helper thread) context created");
@@ -294,7 +306,8 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
         stamp("(helper thread) packed words on their way to the GPU");
       }
     });
-  }
+  };
+  if (!use_multi && !gpu_after_read) { start_helper(); }
 
   // ---- read the database (seam L2, host side)
   swa_hostdb * db = nullptr;
@@ -311,6 +324,8 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
                                         use_multi ? nullptr : on_words, &tell, &db);
   if (!words_told) { words_promise.set_value(Words{}); }
   stamp("database read and ordered");
+  stamp_usage("after the read");
+  if (!use_multi && gpu_after_read) { start_helper(); }
   if (early.joinable()) { early.join(); }
   if (rc != SWA_OK) { die_raw(db != nullptr ? swa_hostdb_error(db) : "\nError: out of memory"); }
   phase(o, "Reading sequences:");
@@ -527,6 +542,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
                  sum[1], sum[2]);
   }
   stamp("results written");
+  stamp_usage("results written");
   // Every output file is closed at this point.  What is left costs at exit by what the kernel has to take apart on ONE
   // thread: ~75 ms per GB of host pages on the bench host, nothing measurable for device memory (lease r5a,
   // tools/experiments/init_cost.hip).  So the host database's pages go back now, on all worker threads
@@ -535,8 +551,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
   if (std::getenv("SWARM_AMD_FULL_TEARDOWN") == nullptr) {
     if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
     std::fflush(nullptr);
-    swa_hostdb_free(db);
-    stamp("host database released");
+    if (std::getenv("SWARM_AMD_FREE_AT_EXIT") != nullptr) { swa_hostdb_free(db); stamp("host database released"); }
     std::_Exit(EXIT_SUCCESS);
   }
   if (multi != nullptr) { swa_multi_destroy(multi); }
