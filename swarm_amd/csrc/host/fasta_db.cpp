@@ -15,6 +15,7 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -277,7 +278,7 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
 
 unsigned worker_count(size_t bytes) {
   const char * env = std::getenv("SWARM_AMD_HOST_THREADS");
-  unsigned t = env != nullptr ? (unsigned)std::atoi(env) : std::thread::hardware_concurrency();
+  unsigned t = env != nullptr ? (unsigned)std::atoi(env) : swa_host_cpus();
   if (t < 1) { t = 1; }
   if (t > 64) { t = 64; }
   const size_t by_size = bytes / (4u << 20) + 1;            // at least 4 MB of text per thread
@@ -299,14 +300,22 @@ template <typename F>
 void run_parallel(unsigned tasks, F && fn) { swa_pool::get().run(tasks, fn); }
 
 
-struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the phase times to stderr
+struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the phase times to stderr: wall, and CPU seconds of the whole process
   bool on = std::getenv("SWARM_AMD_DB_TIMING") != nullptr;
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  double cpu = cpu_now();
+  static double cpu_now() {
+    struct rusage u{};
+    getrusage(RUSAGE_SELF, &u);
+    return (double)u.ru_utime.tv_sec + (double)u.ru_stime.tv_sec + 1e-6 * ((double)u.ru_utime.tv_usec + (double)u.ru_stime.tv_usec);
+  }
   void lap(const char * what) {
     if (!on) { return; }
     const auto now = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[hostdb] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    const double c = cpu_now();
+    std::fprintf(stderr, "[hostdb] %-28s %8.3f ms   cpu %6.3f s\n", what, std::chrono::duration<double, std::milli>(now - t).count(), c - cpu);
     t = now;
+    cpu = c;
   }
 };
 
@@ -481,7 +490,7 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   const unsigned check_threads = std::max(1u, threads / 2);     // (the sort next to them is the critical path)
   std::thread checker([&]() {
     // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
-    {
+    if (std::getenv("SWARM_AMD_EXPERIMENT_NO_ID_CHECK") == nullptr) {
       const uint64_t tsize = n ? 2ull * n : 1;
       std::unique_ptr<std::atomic<uint32_t>[]> idtab(new std::atomic<uint32_t>[tsize]);   // filled in parallel below
       run_transient(check_threads, [&](unsigned t) {

@@ -14,6 +14,7 @@
 #include <thread>
 #include "../../../include/swarm_amd.h"
 #include "../../../include/swarm_amd_host.h"
+#include "pool.h"
 
 #include <getopt.h>
 #include <sys/resource.h>
@@ -241,9 +242,8 @@ void check_writer(int rc, const char * what) {
 // takes 1.9 s with the default and 0.5 s with `passive`.
 extern "C" int swa_cli_main(int argc, char ** argv) {
   stamp("start");
-  // (OpenMP teams of the host phases: 32 threads at most — on the 256-thread bench host a team of 256 spends more time
-  // gathering than working: result arrays 25 -> 12 ms, swarm table 14 -> 10, writing 89 -> 55 at 10 M amplicons, lease r5b)
-  if (std::getenv("OMP_NUM_THREADS") == nullptr) { omp_set_num_threads(std::max(1, std::min(omp_get_max_threads(), 32))); }
+  // (OpenMP teams of the host phases: the CPUs this process may really use — affinity, cgroup quota: pool.h — and 32 at most)
+  if (std::getenv("OMP_NUM_THREADS") == nullptr) { omp_set_num_threads(std::max(1, std::min<int>(omp_get_max_threads(), (int)std::min(swa_host_cpus(), 32u)))); }
   Options o = parse(argc, argv);
   validate(o);
   if (!o.log.empty()) {

@@ -15,6 +15,7 @@
 #include <omp.h>
 
 #include "hostdb.h"
+#include "pool.h"
 
 class BufOut {
  public:
@@ -74,7 +75,7 @@ class BufOut {
 // loop and the copy into the page cache (one thread's work: writes to one file serialise in the kernel) runs beside
 // the formatting instead of after it.  More pieces than threads, claimed from a counter: items differ in cost (swarm
 // sizes; an alignment per member for -u).
-inline int swa_host_team() { return std::max(1, std::min(omp_get_max_threads(), 32)); }
+inline int swa_host_team() { return std::max(1, std::min<int>(omp_get_max_threads(), (int)std::min(swa_host_cpus(), 32u))); }
 
 template <class F>
 void swa_format_in_pieces(BufOut & o, size_t items, bool parallel, F && format) {

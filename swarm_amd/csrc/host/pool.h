@@ -6,13 +6,48 @@
 // more tasks than there are workers.  One phase at a time (a second caller waits); the calling thread works too.
 #pragma once
 
+#include <sched.h>
+
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
+
+// CPUs this process may actually use: the hardware's, cut down to the scheduler affinity and to the cgroup's CPU quota
+// (cpu.max "quota period": quota / period CPUs' worth of time per period).  The quota matters more than it looks: the
+// bench host shows 256 CPUs to a container that may use 16 — 64 busy threads spend a period's quota in a quarter of the
+// period and are then ALL stopped for the rest of it (the GPU helper thread and the main thread included): phases of the
+// reader took 19 or 96 ms by where in the period they began, and HIP's start-up 0.12 or 0.3 s (lease r5e).
+inline unsigned swa_host_cpus() {
+  static const unsigned cpus = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n < 1) { n = 1; }
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (unsigned)c < n) { n = (unsigned)c; } }
+    auto quota_of = [](const char * path, const char * period_path) -> double {
+      double quota = -1.0, period = 100000.0;
+      if (FILE * f = std::fopen(path, "r")) {
+        char first[64] = {0};
+        if (period_path == nullptr) {                        // cgroup v2: "max 100000" or "1600000 100000"
+          if (std::fscanf(f, "%63s %lf", first, &period) >= 1 && std::strcmp(first, "max") != 0) { quota = std::atof(first); }
+        } else if (std::fscanf(f, "%lf", &quota) != 1) { quota = -1.0; }
+        std::fclose(f);
+      }
+      if (period_path != nullptr) { if (FILE * f = std::fopen(period_path, "r")) { if (std::fscanf(f, "%lf", &period) != 1) { period = 100000.0; } std::fclose(f); } }
+      return quota > 0.0 && period > 0.0 ? quota / period : -1.0;
+    };
+    double q = quota_of("/sys/fs/cgroup/cpu.max", nullptr);
+    if (q <= 0.0) { q = quota_of("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"); }
+    if (q > 0.0) { const unsigned c = (unsigned)(q + 0.5); if (c >= 1 && c < n) { n = c; } }
+    return n;
+  }();
+  return cpus;
+}
 
 class swa_pool {
  public:
@@ -47,7 +82,7 @@ class swa_pool {
  private:
   swa_pool() {
     const char * env = std::getenv("SWARM_AMD_HOST_THREADS");
-    unsigned n = env != nullptr ? (unsigned)std::atoi(env) : std::thread::hardware_concurrency();
+    unsigned n = env != nullptr ? (unsigned)std::atoi(env) : swa_host_cpus();
     if (n < 1) { n = 1; }
     if (n > 64) { n = 64; }
     for (unsigned i = 1; i < n; ++i) { workers_.emplace_back([this] { loop(); }); }
