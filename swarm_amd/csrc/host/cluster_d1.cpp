@@ -545,17 +545,30 @@ extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * d
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   if (mothur) { o.str("swarm_"); o.u64((uint64_t)differences); o.put('\t'); o.u64(r->swarmcount_adjusted); }
+  // A member's identifier is three dependent random reads away — order[k] -> its entry pointer -> the entry -> the
+  // header text — and the members of consecutive swarms are consecutive in `order`: what the walk will need 24, 16 and 8
+  // members ahead is asked for now (without that: ~100 ms of cache misses at 10 M amplicons on 16 threads, lease r5f).
+  const uint32_t * order = r->order.data();
+  const uint32_t n_all = r->n;
   auto format_range = [&](BufOut & sink, size_t begin, size_t end) {
+    if (begin < end) { sink.reserve(std::min<size_t>(((size_t)r->swarms[end - 1].end - r->swarms[begin].begin) * (db->longest_header + 2u) + 64, (size_t)8 << 20)); }
+    auto members = [&](uint32_t kb, uint32_t ke, bool & first) {
+      for (uint32_t k = kb; k < ke; ++k) {
+        if (k + 24u < n_all) { __builtin_prefetch(&db->ent[order[k + 24u]]); }
+        if (k + 16u < n_all) { __builtin_prefetch(db->ent[order[k + 16u]]); }
+        if (k + 8u < n_all) { __builtin_prefetch(db->hdr(order[k + 8u])); }
+        if (mothur) { sink.put(first ? '\t' : ','); }
+        else if (!first) { sink.put(' '); }
+        first = false;
+        swa_out::id(sink, db, order[k], usearch != 0, append_abundance);
+      }
+    };
     for (size_t k = begin; k < end; ++k) {
       const auto & s = r->swarms[k];
       if (s.attached != 0) { continue; }
       bool first = true;
-      for_each_member(r, s, [&](uint32_t a) {
-        if (mothur) { sink.put(first ? '\t' : ','); }
-        else if (!first) { sink.put(' '); }
-        first = false;
-        swa_out::id(sink, db, a, usearch != 0, append_abundance);
-      });
+      members(s.begin, s.end, first);
+      for (uint32_t g = s.graft_head; g != SWA_NO_AMPLICON; g = r->swarms[g].graft_next) { members(r->swarms[g].begin, r->swarms[g].end, first); }
       if (!mothur) { sink.put('\n'); }
     }
   };

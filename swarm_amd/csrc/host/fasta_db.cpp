@@ -14,6 +14,7 @@
 #include "pool.h"
 
 #include <fcntl.h>
+#include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -156,11 +157,35 @@ inline uint64_t bytes_hash(const char * s, uint32_t len) {
   return h ^ (h >> 29);
 }
 
+// 32 nucleotides at q -> 64 bits (2 bits each, first nucleotide lowest: the layout of src/db.cc:541-628), with AVX2;
+// false when any of the 32 bytes is not one of ACGTU / acgtu (the caller's byte loop then says what it is).  Upper-cased
+// by clearing bit 5; the low nibble selects the code (A 1 -> 0, C 3 -> 1, G 7 -> 2, T 4 -> 3, U 5 -> 3) and the high nibble
+// the letter must have (4 for A C G, 5 for T U); pairs, quads and octets of codes are folded with multiply-adds.
+__attribute__((target("avx2"))) bool pack32_avx2(const char * q, uint64_t * out) {
+  const __m256i raw = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q));
+  const __m256i up = _mm256_and_si256(raw, _mm256_set1_epi8((char)0xDF));
+  const __m256i lo = _mm256_and_si256(up, _mm256_set1_epi8(0x0F));
+  const __m256i hi = _mm256_and_si256(_mm256_srli_epi16(up, 4), _mm256_set1_epi8(0x0F));
+  const __m256i code_of = _mm256_setr_epi8(0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m256i high_of = _mm256_setr_epi8(-1, 4, -1, 4, 5, 5, -1, 4, -1, -1, -1, -1, -1, -1, -1, -1, -1, 4, -1, 4, 5, 5, -1, 4, -1, -1, -1, -1, -1, -1, -1, -1);
+  const __m256i ok = _mm256_cmpeq_epi8(_mm256_shuffle_epi8(high_of, lo), hi);
+  if (_mm256_movemask_epi8(ok) != -1) { return false; }
+  const __m256i codes = _mm256_shuffle_epi8(code_of, lo);                                        // 32 x 2 bits, one per byte
+  const __m256i pairs = _mm256_maddubs_epi16(codes, _mm256_set1_epi16(0x0401));                  // 16 x 4 bits in 16-bit lanes
+  const __m256i quads = _mm256_madd_epi16(pairs, _mm256_set1_epi32(0x00100001));                 // 8 x 8 bits in 32-bit lanes
+  const __m256i bytes = _mm256_shuffle_epi8(quads, _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                                                   0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+  const uint64_t low = (uint32_t)_mm256_extract_epi32(bytes, 0), high = (uint32_t)_mm256_extract_epi32(bytes, 4);
+  *out = low | (high << 32);
+  return true;
+}
+
 // parse records of [begin, end) — begin points at a '>' that starts a line (or at the file start)
 void parse_piece(const char * begin, const char * end, const int8_t * map, bool usearch, int64_t append_abundance,
                  uint32_t piece_no, Piece & out) {
   const char * p = begin;
   uint32_t lineno = 1;
+  static const bool have_avx2 = __builtin_cpu_supports("avx2") && std::getenv("SWARM_AMD_NO_AVX2") == nullptr;
   auto line_end = [&](const char * q) { const void * nl = std::memchr(q, '\n', (size_t)(end - q)); return nl ? (const char *)nl : end; };
   const size_t span = (size_t)(end - begin);
   auto & entries = out.data.entries;
@@ -195,6 +220,15 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
       const char * q = p;
       // eight nucleotides per turn while the line holds nothing else (the eight table lookups are
       // independent; 1.8x the byte-at-a-time loop); anything unusual drops to the loop below
+      if (have_avx2) {                                      // 32 nucleotides per turn: a whole word
+        uint64_t chunk;
+        while (q + 32 <= le && pack32_avx2(q, &chunk)) {
+          if (fill == 0u) { words.push_back(chunk); }
+          else { words.push_back(acc | (chunk << (2u * fill))); acc = chunk >> (64u - 2u * fill); }
+          len += 32u;
+          q += 32;
+        }
+      }
       while (q + 8 <= le) {
         const uint32_t c0 = (uint8_t)map[(uint8_t)q[0]], c1 = (uint8_t)map[(uint8_t)q[1]], c2 = (uint8_t)map[(uint8_t)q[2]],
                        c3 = (uint8_t)map[(uint8_t)q[3]], c4 = (uint8_t)map[(uint8_t)q[4]], c5 = (uint8_t)map[(uint8_t)q[5]],
@@ -283,16 +317,6 @@ unsigned worker_count(size_t bytes) {
   if (t > 64) { t = 64; }
   const size_t by_size = bytes / (4u << 20) + 1;            // at least 4 MB of text per thread
   return (unsigned)std::min<size_t>(t, by_size);
-}
-
-// threads of its own for a caller that runs BESIDE the pool's phases (the identifier / sequence checks)
-template <typename F>
-void run_transient(unsigned threads, F && fn) {
-  if (threads <= 1) { fn(0u); return; }
-  std::vector<std::thread> pool;
-  pool.reserve(threads);
-  for (unsigned t = 0; t < threads; ++t) { pool.emplace_back([&fn, t] { fn(t); }); }
-  for (auto & th : pool) { th.join(); }
 }
 
 // fn(t) for t in [0, tasks) on the process's worker threads (pool.h)
@@ -482,121 +506,127 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   auto words_of = [&](const swa_entry & e) { return pieces[e.piece()].words.data() + e.word_off; };
   timer.lap("pieces taken over");
 
-  // The two table-based checks below only read the parsed entries and produce an error or nothing: they run on their
-  // own threads next to the sort (at 10 M amplicons 50-100 ms that used to sit on the critical path); their verdict is
-  // taken where the sequential order of the checks puts it.
+  // ---- identifier uniqueness (db.cc:680-758) without a table in DRAM.  The reference's hash table over the
+  // identifiers is one cache miss per amplicon (round 4's lock-free version of it: 1.3 CPU seconds at 10 M amplicons,
+  // 40 % of the reader's — and CPU seconds are what a container with a CPU quota runs out of, lease r5f).  Here: a 64-bit
+  // hash per identifier (the headers stream, piece by piece), the (hash, entry) pairs partitioned by the hash's top bits
+  // into buckets of ~10 000 (counting sort: sequential writes), and per bucket a table that lives in L2.  Two equal
+  // 42-bit hash parts are compared as strings; the LATER entry of the earliest repetition is reported, like the
+  // sequential scan of the reference does.
   std::string dup_id_error, dup_seq_error;
   uint64_t dup_id_at = ~0ull, dup_seq_at = ~0ull;           // entry indices (the later entry of the earliest repetition)
-  const unsigned check_threads = std::max(1u, threads / 2);     // (the sort next to them is the critical path)
-  std::thread checker([&]() {
-    // ---- identifier uniqueness (db.cc:680-758): lock-free open addressing over entry indices
-    if (std::getenv("SWARM_AMD_EXPERIMENT_NO_ID_CHECK") == nullptr) {
-      const uint64_t tsize = n ? 2ull * n : 1;
-      std::unique_ptr<std::atomic<uint32_t>[]> idtab(new std::atomic<uint32_t>[tsize]);   // filled in parallel below
-      run_transient(check_threads, [&](unsigned t) {
-        for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { idtab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
-      });
-      auto id_span = [&](const swa_entry & e, const char *& s, uint32_t & l) {
-        const char * hdr = hdr_of(e);
-        if (e.ab_start > 0) { s = hdr; l = (uint32_t)e.ab_start; }
-        else { s = hdr + e.ab_end; l = e.hdr_len() - (uint32_t)e.ab_end; }
-      };
-      std::atomic<uint32_t> dup_entry{0xFFFFFFFFu};
-      run_transient(check_threads, [&](unsigned t) {
-        // entries and headers stream in file order; the table slot is the one random access per
-        // amplicon, so the slots of the next few identifiers are requested ahead of their turn
-        constexpr uint64_t kAhead = 8;
-        const uint64_t lo = n64 * t / check_threads, hi = n64 * (t + 1) / check_threads;
-        uint64_t ring[kAhead];
-        auto slot_of = [&](uint64_t i) {
-          const char * ids; uint32_t idl;
-          id_span(entry_at(i), ids, idl);
-          const uint64_t slot = bytes_hash(ids, idl) % tsize;
-          __builtin_prefetch(&idtab[slot], 1);
-          return slot;
-        };
-        for (uint64_t i = lo; i < std::min(hi, lo + kAhead); ++i) { ring[i % kAhead] = slot_of(i); }
-        for (uint64_t i = lo; i < hi; ++i) {
-          const char * ids; uint32_t idl;
-          id_span(entry_at(i), ids, idl);
-          uint64_t slot = ring[i % kAhead];
-          if (i + kAhead < hi) { ring[i % kAhead] = slot_of(i + kAhead); }
+  auto id_span = [&](const swa_entry & e, const char *& str, uint32_t & l) {
+    const char * hdr = hdr_of(e);
+    if (e.ab_start > 0) { str = hdr; l = (uint32_t)e.ab_start; }
+    else { str = hdr + e.ab_end; l = e.hdr_len() - (uint32_t)e.ab_end; }
+  };
+  // the same scheme for both checks: hash_of(entry) -> 64 bits, same(entry, entry) -> bool
+  auto earliest_repetition = [&](auto && hash_of, auto && same) -> uint64_t {
+    if (n < 2) { return ~0ull; }
+    unsigned bucket_bits = 1;
+    while (bucket_bits < 16 && (n64 >> bucket_bits) > 8192) { ++bucket_bits; }
+    const uint64_t buckets = 1ull << bucket_bits;
+    swa_vec<uint64_t> packed(n), parted(n);                 // key32 << 32 | entry; `bucket` = top bits of the hash, kept apart
+    swa_vec<uint16_t> bucket_of(n);
+    std::vector<uint64_t> place((size_t)threads * buckets, 0);
+    run_parallel(threads, [&](unsigned t) {
+      uint64_t * c = &place[(size_t)t * buckets];
+      uint64_t g = piece_first[t];
+      for (const swa_entry & e : pieces[t].entries) {
+        const uint64_t h = hash_of(e);
+        const uint64_t b = h >> (64u - bucket_bits);
+        packed[g] = (((h >> 22) & 0xFFFFFFFFull) << 32) | g;
+        bucket_of[g] = (uint16_t)b;
+        ++c[b];
+        ++g;
+      }
+    });
+    std::vector<uint64_t> start(buckets + 1, 0);
+    uint64_t at = 0;
+    for (uint64_t b = 0; b < buckets; ++b) {
+      start[b] = at;
+      for (unsigned t = 0; t < threads; ++t) { const uint64_t c = place[(size_t)t * buckets + b]; place[(size_t)t * buckets + b] = at; at += c; }
+    }
+    start[buckets] = at;
+    run_parallel(threads, [&](unsigned t) {
+      uint64_t * c = &place[(size_t)t * buckets];
+      for (uint64_t g = piece_first[t]; g < piece_first[t + 1]; ++g) { parted[c[bucket_of[g]]++] = packed[g]; }
+    });
+    std::atomic<uint64_t> found{~0ull};
+    std::atomic<uint64_t> next{0};
+    run_parallel(threads, [&](unsigned) {
+      std::vector<uint64_t> table;
+      for (;;) {
+        const uint64_t b = next.fetch_add(1);
+        if (b >= buckets) { break; }
+        const uint64_t m = start[b + 1] - start[b];
+        uint64_t tsize = 64;
+        while (tsize < 3 * m) { tsize <<= 1; }
+        table.assign(tsize, ~0ull);
+        for (uint64_t i = start[b]; i < start[b + 1]; ++i) {
+          const uint64_t rec = parted[i];
+          uint64_t slot = ((rec >> 32) * 0x9E3779B1ull) & (tsize - 1);
           for (;;) {
-            uint32_t cur = idtab[slot].load(std::memory_order_acquire);
-            if (cur == 0xFFFFFFFFu) {
-              if (idtab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
-            }
-            const char * os; uint32_t ol;
-            id_span(entry_at(cur), os, ol);
-            if (ol == idl && std::memcmp(os, ids, idl) == 0) {
-              // report the LATER of the two, like the sequential scan of the reference does
-              uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
-              uint32_t seen = dup_entry.load();
-              while (later < seen && !dup_entry.compare_exchange_weak(seen, later)) { }
+            const uint64_t cur = table[slot];
+            if (cur == ~0ull) { table[slot] = rec; break; }
+            if ((cur >> 32) == (rec >> 32) && same(entry_at((uint32_t)cur), entry_at((uint32_t)rec))) {
+              const uint64_t later = std::max<uint64_t>((uint32_t)cur, (uint32_t)rec);
+              uint64_t seen = found.load();
+              while (later < seen && !found.compare_exchange_weak(seen, later)) { }
+              // (the EARLIER of the two stays in the table: a third copy is then compared with it)
+              if ((uint32_t)rec < (uint32_t)cur) { table[slot] = rec; }
               break;
             }
-            slot = (slot + 1) % tsize;
+            slot = (slot + 1) & (tsize - 1);
           }
         }
-      });
-      if (dup_entry.load() != 0xFFFFFFFFu) {
-        const char * ids; uint32_t idl;
-        id_span(entry_at(dup_entry.load()), ids, idl);
-        dup_id_error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
-        dup_id_at = dup_entry.load();
       }
+    });
+    return found.load();
+  };
+  if (std::getenv("SWARM_AMD_EXPERIMENT_NO_ID_CHECK") == nullptr) {
+    dup_id_at = earliest_repetition(
+        [&](const swa_entry & e) { const char * ids; uint32_t idl; id_span(e, ids, idl); const uint64_t h = bytes_hash(ids, idl); return h * 0x9E3779B97F4A7C15ull; },
+        [&](const swa_entry & x, const swa_entry & y) {
+          const char * xs; const char * ys; uint32_t xl, yl;
+          id_span(x, xs, xl); id_span(y, ys, yl);
+          return xl == yl && std::memcmp(xs, ys, xl) == 0;
+        });
+    if (dup_id_at != ~0ull) {
+      const char * ids; uint32_t idl;
+      id_span(entry_at(dup_id_at), ids, idl);
+      dup_id_error = "\nError: Duplicated sequence identifier: " + std::string(ids, idl) + "\n";
     }
-
-    // duplicated sequences are checked here only for d > 1 (db.cc:763-790); d = 1 finds
-    // them while building the amplicon table (algod1.cc:1131-1150 / swa_d1_index_build)
-    if (check_dup_seqs && n > 1) {
-      const uint64_t tsize = 2ull * n;
-      std::unique_ptr<std::atomic<uint32_t>[]> tab(new std::atomic<uint32_t>[tsize]);
-      run_transient(check_threads, [&](unsigned t) {
-        for (uint64_t i = tsize * t / check_threads; i < tsize * (t + 1) / check_threads; ++i) { tab[i].store(0xFFFFFFFFu, std::memory_order_relaxed); }
-      });
-      std::atomic<uint32_t> dup{0xFFFFFFFFu};                  // the earliest entry that repeats an earlier one's sequence
-      run_transient(check_threads, [&](unsigned t) {
-        for (uint64_t i = n64 * t / check_threads; i < n64 * (t + 1) / check_threads; ++i) {
-          const swa_entry & e = entry_at(i);
+  }
+  timer.lap("identifiers checked");
+  // duplicated sequences are checked here only for d > 1 (db.cc:763-790); d = 1 finds
+  // them while building the amplicon table (algod1.cc:1131-1150 / swa_d1_index_build)
+  if (check_dup_seqs && n > 1) {
+    dup_seq_at = earliest_repetition(
+        [&](const swa_entry & e) {
           const uint64_t * w = words_of(e);
           const uint32_t nw = (e.seqlen + 31u) >> 5;
           uint64_t hsh = e.seqlen * 0x9E3779B97F4A7C15ull;
           for (uint32_t k = 0; k < nw; ++k) { hsh = (hsh ^ w[k]) * 0xff51afd7ed558ccdull; hsh ^= hsh >> 32; }
-          uint64_t slot = hsh % tsize;
-          for (;;) {
-            uint32_t cur = tab[slot].load(std::memory_order_acquire);
-            if (cur == 0xFFFFFFFFu) {
-              if (tab[slot].compare_exchange_strong(cur, (uint32_t)i, std::memory_order_acq_rel)) { break; }
-            }
-            const swa_entry & o = entry_at(cur);
-            if (o.seqlen == e.seqlen && std::memcmp(words_of(o), w, nw * 8ull) == 0) {
-              const uint32_t later = std::max<uint32_t>(cur, (uint32_t)i);
-              uint32_t seen = dup.load();
-              while (later < seen && !dup.compare_exchange_weak(seen, later)) { }
-              break;
-            }
-            slot = (slot + 1) % tsize;
-          }
-        }
-      });
-      if (dup.load() != 0xFFFFFFFFu) {
-        dup_seq_at = dup.load();
-        dup_seq_error = "\nError: some fasta entries have identical sequences.\n"
-                    "Swarm expects dereplicated fasta files.\n"
-                    "Such files can be produced with swarm or vsearch:\n"
-                    " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
-                    "or\n"
-                    " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
-      }
+          return hsh * 0x9E3779B97F4A7C15ull;
+        },
+        [&](const swa_entry & x, const swa_entry & y) {
+          return x.seqlen == y.seqlen && std::memcmp(words_of(x), words_of(y), ((x.seqlen + 31u) >> 5) * 8ull) == 0;
+        });
+    if (dup_seq_at != ~0ull) {
+      dup_seq_error = "\nError: some fasta entries have identical sequences.\n"
+                  "Swarm expects dereplicated fasta files.\n"
+                  "Such files can be produced with swarm or vsearch:\n"
+                  " swarm -d 0 -w derep.fasta -o /dev/null input.fasta\n"
+                  "or\n"
+                  " vsearch --derep_fulllength input.fasta --sizein --sizeout --output derep.fasta\n";
     }
-  });
-  struct JoinChecker { std::thread & t; ~JoinChecker() { if (t.joinable()) { t.join(); } } } join_checker{checker};
+    timer.lap("sequences checked");
+  }
   // The reference walks the entries once (db.cc:676-795): abundance value, empty identifier, repeated identifier are
   // fatal at the entry where they occur, a repeated sequence (d > 1) ends the walk there and is reported after it.
   // Hence: the earliest entry with any of them decides; at the same entry in that order.
   auto checks_verdict = [&]() {
-    if (checker.joinable()) { checker.join(); }
     if (late_at != ~0ull && late_at <= dup_id_at && late_at <= dup_seq_at) { db->error = late_error; return (int)SWA_E_ARG; }
     if (dup_id_at != ~0ull && dup_id_at <= dup_seq_at) { db->error = dup_id_error; return (int)SWA_E_ARG; }
     if (dup_seq_at != ~0ull) { db->error = dup_seq_error; return (int)SWA_E_DUPLICATES; }
@@ -627,6 +657,8 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
       return SWA_E_ARG;
     }
   }
+
+  if (const int rc_checks = checks_verdict()) { return rc_checks; }
 
   // ---- db order: abundance descending, then header (strcmp) ascending — db.cc:388-413.
   // The sort moves compact records: the abundance (saturating at 32 bits: two saturated ones are told apart through
@@ -696,8 +728,6 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
     }
   });
   timer.lap("db order");
-  if (const int rc_checks = checks_verdict()) { return rc_checks; }
-  timer.lap("identifier / sequence checks (waited for)");
   return SWA_OK;
 }
 

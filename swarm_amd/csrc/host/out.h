@@ -23,6 +23,7 @@ class BufOut {
   // format ranges of clusters on several threads and then emit the pieces in order)
   BufOut() : memory_only_(true) {}
   std::string take() { std::string out; out.swap(buf_); return out; }
+  void reserve(size_t bytes) { buf_.reserve(bytes); }
   explicit BufOut(const char * path) {
     if (path == nullptr) { return; }
     if (std::strcmp(path, "-") == 0) { fp_ = stdout; owned_ = false; }

@@ -109,6 +109,28 @@ def test_hostdb_db_order_of_a_large_file_sorted_on_several_threads(tmp_path):
     assert np.array_equal(hdb.seqs[hdb.seq_off[:2000].astype(np.int64)], first_word)
 
 
+def test_repeated_identifiers_in_a_large_file_are_reported_like_the_sequential_scan(tmp_path):
+    """The identifier check partitions the identifiers' hashes into buckets and looks at each bucket on its own
+    (fasta_db.cpp: earliest_repetition), on several threads: of several repeated identifiers — with different abundance
+    annotations, so the headers differ — the one whose SECOND occurrence comes first in the file is reported
+    (src/db.cc:680-758 walks the entries in order)."""
+    from swarm_amd.capi import SwaError
+    rng = np.random.default_rng(5)
+    n = 160_000
+    names = [f"id{int(x)}" for x in rng.permutation(n)]
+    names[120_000] = names[300]          # second occurrence at 120 000
+    names[90_000] = names[70_000]        # second occurrence at 90 000: the earliest
+    names[150_000] = names[90_000]       # a third copy
+    names[140_000] = names[5]
+    seq = ["".join("ACGT"[c] for c in rng.integers(0, 4, 45)) for _ in range(64)]
+    fa = tmp_path / "dups.fa"
+    fa.write_text("".join(f">{names[i]}_{1 + i % 7}\n{seq[i % 64]}{'ACGT'[i % 4] * (i % 5)}\n" for i in range(n)))
+    assert fa.stat().st_size > 8 << 20
+    with pytest.raises(SwaError) as e:
+        HostDb(fa)
+    assert f"Duplicated sequence identifier: {names[90_000]}\n" in str(e.value)
+
+
 def test_hostdb_usearch_and_append_abundance():
     hdb = HostDb(G / "d1_usearch.fasta", usearch_abundance=True, append_abundance=2)
     db = S.build_db([(h, s) for h, s in S.read_fasta(G / "d1_short.fasta")])
