@@ -34,6 +34,10 @@ typedef void (*swa_words_ready_fn)(void * user, const uint64_t * const * piece_w
 int swa_hostdb_read_fasta_staged(const char * path, int usearch_abundance, int64_t append_abundance, int check_duplicate_sequences,
                                  swa_words_ready_fn on_words, void * user, swa_hostdb ** out);
 void swa_hostdb_free(swa_hostdb * db);
+/* Releases what the handle holds beyond what its users still read: the reader's scratch memory and, with keep_words == 0,
+   the packed words — after swa_db_upload_unordered only the -w / -u writers and swa_hostdb_view read them on the host
+   (which then return nothing).  Safe beside the writers that do not: meant for a helper thread. */
+void swa_hostdb_trim(swa_hostdb * db, int keep_words);
 const char * swa_hostdb_error(const swa_hostdb * db);
 /* host pointers into the handle (valid until swa_hostdb_free).  swa_hostdb_view: the packed sequences contiguous in db
    order — gathered on the host the first time it is asked for; swa_hostdb_unordered_view: the database as the reader

@@ -345,7 +345,7 @@ struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the ph
 
 // sorts a[0, n) by `less` (a strict weak order) on `threads` threads; tmp[0, n) is scratch; the result is in a
 template <class Rec, class Less>
-void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less less, PhaseTimer * timer = nullptr) {
+void parallel_sample_sort(Rec * a, Rec * tmp, uint16_t * where, uint64_t n, unsigned threads, Less less, PhaseTimer * timer = nullptr) {
   if (threads <= 1 || n < 100000) { std::sort(a, a + n, less); return; }
   const unsigned buckets = std::min<unsigned>(threads * 8u, 1024u);
   constexpr uint64_t kOver = 64;                            // sampled records per bucket
@@ -356,7 +356,6 @@ void parallel_sample_sort(Rec * a, Rec * tmp, uint64_t n, unsigned threads, Less
   std::vector<Rec> split(buckets - 1);
   for (unsigned b = 1; b < buckets; ++b) { split[b - 1] = sample[(uint64_t)b * kOver]; }
   std::vector<uint64_t> place((size_t)threads * buckets, 0);
-  swa_vec<uint16_t> where(n);
   if (timer != nullptr) { timer->lap("  sort: sample + splitters"); }
   run_parallel(threads, [&](unsigned t) {
     uint64_t * c = &place[(size_t)t * buckets];
@@ -515,6 +514,13 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   // sequential scan of the reference does.
   std::string dup_id_error, dup_seq_error;
   uint64_t dup_id_at = ~0ull, dup_seq_at = ~0ull;           // entry indices (the later entry of the earliest repetition)
+  // ONE block of scratch memory for the checks and the sort, one after the other (34 bytes per amplicon: the sort's two
+  // record arrays and bucket numbers; the checks take 18 of them): fresh memory is paid for twice — populated when it
+  // is mapped, taken apart when it is freed, ~12 ms each way per 160 MB here — and the five arrays this replaces were
+  // each mapped and freed on this thread.  It stays with the handle until swa_hostdb_trim / swa_hostdb_free.
+  db->scratch.resize((size_t)n * 34 + 64);
+  char * const scratch = db->scratch.data();
+  timer.lap("scratch block");
   auto id_span = [&](const swa_entry & e, const char *& str, uint32_t & l) {
     const char * hdr = hdr_of(e);
     if (e.ab_start > 0) { str = hdr; l = (uint32_t)e.ab_start; }
@@ -526,8 +532,9 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
     unsigned bucket_bits = 1;
     while (bucket_bits < 16 && (n64 >> bucket_bits) > 8192) { ++bucket_bits; }
     const uint64_t buckets = 1ull << bucket_bits;
-    swa_vec<uint64_t> packed(n), parted(n);                 // key32 << 32 | entry; `bucket` = top bits of the hash, kept apart
-    swa_vec<uint16_t> bucket_of(n);
+    uint64_t * const packed = reinterpret_cast<uint64_t *>(scratch);          // key32 << 32 | entry; `bucket` = top bits of the hash, kept apart
+    uint64_t * const parted = packed + n;
+    uint16_t * const bucket_of = reinterpret_cast<uint16_t *>(parted + n);
     std::vector<uint64_t> place((size_t)threads * buckets, 0);
     run_parallel(threads, [&](unsigned t) {
       uint64_t * c = &place[(size_t)t * buckets];
@@ -666,7 +673,8 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   // prefixes fall through to strcmp: same order) and the entry's number.  Inputs that are already in db order (swarm's
   // own -w output, vsearch output) skip it.
   struct SortRec { uint64_t key8; uint32_t abundance, entry; };
-  swa_vec<SortRec> recs(n);
+  static_assert(sizeof(SortRec) == 16, "the scratch block is laid out for 16-byte sort records");
+  SortRec * const recs = reinterpret_cast<SortRec *>(scratch);
   run_parallel(threads, [&](unsigned t) {
     uint64_t g = piece_first[t];
     const char * pool = pieces[t].hdr_pool.data();
@@ -703,10 +711,11 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
     // order is a strict total order (identifiers are unique), so the result equals std::sort's.  (r04 used libstdc++'s
     // parallel multiway merge sort on 32-byte records: 151 ms at 10 M amplicons on 64 threads.)  32 threads, not 64: the
     // bucket sorts took 17-20 ms on 32 and 56-93 ms on 64 threads beside the checks' 32 (lease r5b).
-    swa_vec<SortRec> other(n);
+    SortRec * const other = recs + n;
+    uint16_t * const where = reinterpret_cast<uint16_t *>(other + n);
     const char * env_sort = std::getenv("SWARM_AMD_SORT_THREADS");
     const unsigned sort_threads = std::max(1u, std::min(threads, env_sort != nullptr ? (unsigned)std::atoi(env_sort) : 32u));
-    parallel_sample_sort(recs.data(), other.data(), n64, sort_threads, less, &timer);
+    parallel_sample_sort(recs, other, where, n64, sort_threads, less, &timer);
   }
   timer.lap("sort");
 
@@ -738,11 +747,23 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
 
 extern "C" void swa_hostdb_free(swa_hostdb * db) { delete db; }
 
+// What the handle holds beyond what its users still read: the reader's scratch block and — keep_words == 0 — the packed
+// words (once they are on the GPU nothing on the host reads them but -w, -u and swa_hostdb_view).  Meant for a helper
+// thread beside the GPU's work: taking 0.75 GB apart costs ~55 ms of one thread at 10 M amplicons, at process exit too.
+extern "C" void swa_hostdb_trim(swa_hostdb * db, int keep_words) {
+  if (db == nullptr) { return; }
+  swa_vec<char>().swap(db->scratch);
+  if (keep_words == 0 && !db->ordered) {
+    for (auto & pc : db->pieces) { std::vector<uint64_t>().swap(pc.words); }
+    db->words_gone = true;
+  }
+}
+
 extern "C" const char * swa_hostdb_error(const swa_hostdb * db) { return db != nullptr ? db->error.c_str() : ""; }
 
 // the packed sequences contiguous in db order (swa_db_view): gathered from the pieces the first time somebody asks
 static void order_on_host(swa_hostdb * db) {
-  if (db->ordered) { return; }
+  if (db->ordered || db->words_gone) { return; }
   const uint64_t n = db->n;
   db->seq_off.resize(n + 1);
   const unsigned threads = swa_pool::get().size();

@@ -337,6 +337,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
                uview.n, uview.longest);
 
   const uint32_t n = uview.n;
+  std::thread trimmer;
   swa_ctx * ctx = nullptr;
   swa_multi * multi = nullptr;           // d = 1 on several GPUs: SWARM_AMD_DEVICES=0,1,2,... (one rank per entry)
   if (n > 0) {
@@ -358,6 +359,10 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       stamp("context created");
       if (swa_db_upload_unordered(ctx, &uview) != SWA_OK) { die(swa_last_error(ctx)); }
       stamp("database uploaded");
+      // the reader's scratch memory and — unless an output prints sequences (-w) or aligns them (-u) — the packed words go
+      // back to the kernel on a thread of their own while the GPU works: the same pages cost the same time at exit
+      const bool keep_words = !o.seeds.empty() || !o.uclust.empty();
+      trimmer = std::thread([db, keep_words]() { swa_hostdb_trim(db, keep_words ? 1 : 0); stamp("(helper thread) scratch memory and word pools released"); });
     }
   }
 
@@ -541,6 +546,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
                  sum[1], sum[2]);
   }
+  if (trimmer.joinable()) { trimmer.join(); }
   stamp("results written");
   stamp_usage("results written");
   // Every output file is closed at this point.  What is left costs at exit by what the kernel has to take apart on ONE
