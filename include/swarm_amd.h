@@ -75,6 +75,9 @@ int  swa_abi_version(void);
    its own non-blocking stream). */
 int  swa_ctx_create(int device, void * stream, swa_ctx ** out);
 void swa_ctx_destroy(swa_ctx * ctx);
+/* optional, after the last context of `device` is destroyed: releases the HIP runtime's own state on it (hipDeviceReset);
+   a later swa_ctx_create starts it again */
+int  swa_runtime_shutdown(int device);
 /* message of the last failing call on this context ("" if none) */
 const char * swa_last_error(const swa_ctx * ctx);
 /* blocks until everything enqueued on the context's stream has finished */

@@ -59,6 +59,10 @@ int  swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint3
    (swa_d1_cluster_device), per-swarm sums on the host.  Needs the context that holds the network. */
 int  swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
 void swa_d1_result_free(swa_d1_result * res);
+/* swa_d1_cluster_resident leaves swarmid / generation / parent in HBM until a writer or accessor asks (they then return
+   SWA_E_ARG / NULL if the context has moved on).  A caller that will destroy the context early says so here: nothing is
+   fetched any more. */
+void swa_d1_result_detach(swa_d1_result * res);
 /* out4 = {swarms after grafting, largest swarm, max generations, swarms before grafting}
    (the numbers of the log's summary lines, src/algod1.cc:1484-1487) */
 void swa_d1_result_summary(const swa_d1_result * res, uint64_t * out4);

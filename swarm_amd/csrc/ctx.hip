@@ -62,6 +62,19 @@ extern "C" int swa_ctx_create(int device, void * stream, swa_ctx ** out) {
     }
     ctx->own_stream = true;
   }
+  // (the anomaly hunt: SWARM_AMD_POISON_MB=N fills N MB of HBM with non-zero bytes and frees them again first, so that
+  // what the context allocates next has been 0xA5 / 0xFF / 0x01 / 0x5A, not the zeros of a fresh box)
+  if (const char * poison = getenv("SWARM_AMD_POISON_MB")) {
+    std::vector<void *> held;
+    for (long left = atol(poison), k = 0; left > 0; left -= 256, ++k) {
+      void * p = nullptr;
+      if (hipMalloc(&p, (size_t)256 << 20) != hipSuccess) { break; }
+      (void)hipMemset(p, (int)((const unsigned char[]){0xA5, 0xFF, 0x01, 0x5A}[k % 4]), (size_t)256 << 20);
+      held.push_back(p);
+    }
+    (void)hipDeviceSynchronize();
+    for (void * p : held) { (void)hipFree(p); }
+  }
   // the status block and the views into it (swa_internal.h)
   if (swa_reserve(ctx, ctx->d_status, 4096) != SWA_OK || hipMemset(ctx->d_status.ptr, 0, 4096) != hipSuccess) {
     if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); }
@@ -127,6 +140,14 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
   if (ctx->ev_ready) { for (auto & e : ctx->ev) { (void)hipEventDestroy(e); } }
   if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); }
   delete ctx;
+}
+
+// After the last context is destroyed: the HIP runtime's own queues, pools and code objects (hipDeviceReset).  A caller
+// that is done with the GPU while it still has host work to do — the command line writing its output — runs this on a
+// helper thread, so that the driver's part of taking the process apart is not left for process exit.
+extern "C" int swa_runtime_shutdown(int device) {
+  if (hipSetDevice(device) != hipSuccess) { return SWA_E_DEVICE; }
+  return hipDeviceReset() == hipSuccess ? SWA_OK : SWA_E_DEVICE;
 }
 
 extern "C" const char * swa_last_error(const swa_ctx * ctx) {

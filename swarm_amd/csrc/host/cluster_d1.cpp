@@ -88,6 +88,7 @@ std::vector<uint32_t> output_numbers(const swa_d1_result * r) {
 // them has moved on
 bool need_details(const swa_d1_result * cr) {
   if (cr->details) { return true; }
+  if (cr->lazy_ctx == nullptr) { return false; }
   auto * r = const_cast<swa_d1_result *>(cr);
   const uint32_t n = r->n;
   const swa_hostdb * db = r->lazy_db;
@@ -446,6 +447,7 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
 }
 
 extern "C" void swa_d1_result_free(swa_d1_result * r) { delete r; }
+extern "C" void swa_d1_result_detach(swa_d1_result * r) { if (r != nullptr) { r->lazy_ctx = nullptr; } }
 
 extern "C" void swa_d1_result_summary(const swa_d1_result * r, uint64_t * out4) {
   out4[0] = r->swarmcount_adjusted;

@@ -752,14 +752,22 @@ extern "C" void swa_hostdb_free(swa_hostdb * db) { delete db; }
 // thread beside the GPU's work: taking 0.75 GB apart costs ~55 ms of one thread at 10 M amplicons, at process exit too.
 extern "C" void swa_hostdb_trim(swa_hostdb * db, int keep_words) {
   if (db == nullptr) { return; }
-  swa_vec<char>().swap(db->scratch);
+  // In slices: an unmap holds the process's memory-map lock while it takes the pages apart, and whoever wants to map
+  // or unmap meanwhile — hipMalloc on the main thread, a growing output buffer — waits for all of it (a 340-MB block
+  // at once stalled the index build's allocations for 75 ms, lease r5h).  MADV_DONTNEED gives the pages back under the
+  // shared lock, 16 MB (~1 ms) at a time; freeing the emptied block afterwards is quick.
+  if (!db->scratch.empty()) {
+    constexpr size_t kPage = 4096, kSlice = size_t(16) << 20;
+    const uintptr_t lo = ((uintptr_t)db->scratch.data() + kPage - 1) & ~(uintptr_t)(kPage - 1);
+    const uintptr_t hi = ((uintptr_t)db->scratch.data() + db->scratch.size()) & ~(uintptr_t)(kPage - 1);
+    for (uintptr_t a = lo; a < hi; a += kSlice) { (void)::madvise(reinterpret_cast<void *>(a), std::min<uintptr_t>(kSlice, hi - a), MADV_DONTNEED); }
+    swa_vec<char>().swap(db->scratch);
+  }
   if (keep_words == 0 && !db->ordered) {
-    for (auto & pc : db->pieces) { std::vector<uint64_t>().swap(pc.words); }
+    for (auto & pc : db->pieces) { std::vector<uint64_t>().swap(pc.words); }      // (a pool per parser thread: a few MB each)
     db->words_gone = true;
   }
 }
-
-extern "C" const char * swa_hostdb_error(const swa_hostdb * db) { return db != nullptr ? db->error.c_str() : ""; }
 
 // the packed sequences contiguous in db order (swa_db_view): gathered from the pieces the first time somebody asks
 static void order_on_host(swa_hostdb * db) {

@@ -298,7 +298,8 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     early = std::thread([&early_ctx, &early_rc, &words_ready, device]() {
       early_rc = swa_ctx_create(device, nullptr, &early_ctx);
       stamp("(helper thread) context created");
-      if (early_rc == SWA_OK) { (void)swa_ctx_warmup(early_ctx); }
+      // (the anomaly hunt, tools/stress/cold_runs.sh: no warm-up = every code object loaded by the step's own first launch)
+      if (early_rc == SWA_OK && std::getenv("SWARM_AMD_NO_WARMUP") == nullptr) { (void)swa_ctx_warmup(early_ctx); }
       stamp("(helper thread) code objects loaded, first copies done");
       const Words w = words_ready.get();
       if (early_rc == SWA_OK && !w.pools.empty()) {
@@ -337,7 +338,8 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
                uview.n, uview.longest);
 
   const uint32_t n = uview.n;
-  std::thread trimmer;
+  std::thread trimmer, gpu_release;
+  const int gpu_device = device;
   swa_ctx * ctx = nullptr;
   swa_multi * multi = nullptr;           // d = 1 on several GPUs: SWARM_AMD_DEVICES=0,1,2,... (one rank per entry)
   if (n > 0) {
@@ -362,7 +364,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       // the reader's scratch memory and — unless an output prints sequences (-w) or aligns them (-u) — the packed words go
       // back to the kernel on a thread of their own while the GPU works: the same pages cost the same time at exit
       const bool keep_words = !o.seeds.empty() || !o.uclust.empty();
-      trimmer = std::thread([db, keep_words]() { swa_hostdb_trim(db, keep_words ? 1 : 0); stamp("(helper thread) scratch memory and word pools released"); });
+      if (std::getenv("SWARM_AMD_NO_TRIM") == nullptr) trimmer = std::thread([db, keep_words]() { swa_hostdb_trim(db, keep_words ? 1 : 0); stamp("(helper thread) scratch memory and word pools released"); });
     }
   }
 
@@ -446,6 +448,19 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     phase(o, "Clustering:       ");
     uint64_t sum[4];
     swa_d1_result_summary(res, sum);
+    // Only the swarms file is wanted: the GPU's part is over.  The context and the HIP runtime are taken apart on a helper
+    // thread while this one writes — otherwise the driver does it at process exit, inside the caller's wall time.
+    if (resident && multi == nullptr && !o.fastidious && o.seeds.empty() && o.structure.empty() && o.uclust.empty() && o.stats.empty() &&
+        std::getenv("SWARM_AMD_KEEP_GPU") == nullptr) {
+      swa_d1_result_detach(res);
+      swa_ctx * gone = ctx;
+      ctx = nullptr;
+      gpu_release = std::thread([gone, gpu_device]() {
+        swa_ctx_destroy(gone);
+        (void)swa_runtime_shutdown(gpu_device);
+        stamp("(helper thread) GPU context and HIP runtime released");
+      });
+    }
 
     if (o.fastidious) {
       std::fprintf(g_log, "\nResults before fastidious processing:\n");
@@ -547,6 +562,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
                  sum[1], sum[2]);
   }
   if (trimmer.joinable()) { trimmer.join(); }
+  if (gpu_release.joinable()) { gpu_release.join(); }
   stamp("results written");
   stamp_usage("results written");
   // Every output file is closed at this point.  What is left costs at exit by what the kernel has to take apart on ONE
