@@ -921,7 +921,8 @@ def main() -> None:
             for name, fn in (("skewed", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 40)),
                              # the conserved-flank cliff: flanks that swallow a 64-nt window whole, and a
                              # V4-like set — 250 nt, 60 % of the positions conserved across centroids
-                             ("skewed_70", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 70)),
+                             # (200 nt: with 70 + 70 conserved of 150 the 10-nt cores of 200 000 centroids collide — identical sequences)
+                             ("skewed_70", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 200}), n_total, 5, 70)),
                              ("v4_like", lambda: extra_measurement(torch, dev, device_index, argparse.Namespace(**{**vars(args), "length": 250}), n_total, 5, 0, 0.0, False, 60)),
                              ("heavy_tail", lambda: extra_measurement(torch, dev, device_index, args, n_total, 5, 0, 0.1)),
                              # 400-bp amplicons: the pair route with 13-word records (128-byte lines), 1 M x 400, d = 1

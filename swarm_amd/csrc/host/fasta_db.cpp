@@ -747,6 +747,8 @@ extern "C" int swa_hostdb_read_fasta(const char * path, int usearch, int64_t app
 
 extern "C" void swa_hostdb_free(swa_hostdb * db) { delete db; }
 
+extern "C" const char * swa_hostdb_error(const swa_hostdb * db) { return db != nullptr ? db->error.c_str() : ""; }
+
 // What the handle holds beyond what its users still read: the reader's scratch block and — keep_words == 0 — the packed
 // words (once they are on the GPU nothing on the host reads them but -w, -u and swa_hostdb_view).  Meant for a helper
 // thread beside the GPU's work: taking 0.75 GB apart costs ~55 ms of one thread at 10 M amplicons, at process exit too.
