@@ -75,9 +75,6 @@ int  swa_abi_version(void);
    its own non-blocking stream). */
 int  swa_ctx_create(int device, void * stream, swa_ctx ** out);
 void swa_ctx_destroy(swa_ctx * ctx);
-/* optional, after the last context of `device` is destroyed: releases the HIP runtime's own state on it (hipDeviceReset);
-   a later swa_ctx_create starts it again */
-int  swa_runtime_shutdown(int device);
 /* message of the last failing call on this context ("" if none) */
 const char * swa_last_error(const swa_ctx * ctx);
 /* blocks until everything enqueued on the context's stream has finished */
@@ -340,9 +337,12 @@ int swa_dn_graph_totals(swa_ctx * ctx, uint64_t * out3);
 /* ---- d = 1 on several GPUs of one node --------------------------------
    Replaces the thread fan-out of src/algod1.cc:1166-1167 / src/utils/threads.h:145-162: one context, stream and
    host thread per listed device inside the calling process; the database replicated, the probing divided by
-   ownership of anchor groups (swa_d1_set_ownership), every rank's flat link list all-gathered with RCCL over
-   xGMI, CSR assembled on the device; fastidious: heavy amplicons split, graft_cand combined with
-   ncclAllReduce(min).  A device may be listed more than once (several ranks on one GPU: the exchange then uses
+   ownership of anchor groups (swa_d1_set_ownership): routed index build (the ranks' id lists all-to-all, grouped
+   ncclSend / ncclRecv over xGMI), every rank's flat link list gathered on rank 0 (grouped ncclSend / ncclRecv: the one
+   consumer of the network is the host behind rank 0 — an all-gather, which round 2 used and `bench.py --gpus N` still
+   times as the north star names it, moves world x the bytes), CSR assembled there on the device; fastidious: heavy
+   amplicons split, graft_cand combined with ncclAllReduce(min).  librccl.so is loaded when the first handle with ranks
+   on distinct devices is created, not with the library.  A device may be listed more than once (several ranks on one GPU: the exchange then uses
    device-to-device copies — RCCL admits one rank per GPU); results never depend on the device list. */
 typedef struct swa_multi swa_multi;
 int  swa_multi_create(const int * devices, int ndevices, swa_multi ** out);

@@ -34,10 +34,6 @@ typedef void (*swa_words_ready_fn)(void * user, const uint64_t * const * piece_w
 int swa_hostdb_read_fasta_staged(const char * path, int usearch_abundance, int64_t append_abundance, int check_duplicate_sequences,
                                  swa_words_ready_fn on_words, void * user, swa_hostdb ** out);
 void swa_hostdb_free(swa_hostdb * db);
-/* Releases what the handle holds beyond what its users still read: the reader's scratch memory and, with keep_words == 0,
-   the packed words — after swa_db_upload_unordered only the -w / -u writers and swa_hostdb_view read them on the host
-   (which then return nothing).  Safe beside the writers that do not: meant for a helper thread. */
-void swa_hostdb_trim(swa_hostdb * db, int keep_words);
 const char * swa_hostdb_error(const swa_hostdb * db);
 /* host pointers into the handle (valid until swa_hostdb_free).  swa_hostdb_view: the packed sequences contiguous in db
    order — gathered on the host the first time it is asked for; swa_hostdb_unordered_view: the database as the reader
@@ -59,10 +55,6 @@ int  swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint3
    (swa_d1_cluster_device), per-swarm sums on the host.  Needs the context that holds the network. */
 int  swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
 void swa_d1_result_free(swa_d1_result * res);
-/* swa_d1_cluster_resident leaves swarmid / generation / parent in HBM until a writer or accessor asks (they then return
-   SWA_E_ARG / NULL if the context has moved on).  A caller that will destroy the context early says so here: nothing is
-   fetched any more. */
-void swa_d1_result_detach(swa_d1_result * res);
 /* out4 = {swarms after grafting, largest swarm, max generations, swarms before grafting}
    (the numbers of the log's summary lines, src/algod1.cc:1484-1487) */
 void swa_d1_result_summary(const swa_d1_result * res, uint64_t * out4);

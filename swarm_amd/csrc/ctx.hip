@@ -142,14 +142,6 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
   delete ctx;
 }
 
-// After the last context is destroyed: the HIP runtime's own queues, pools and code objects (hipDeviceReset).  A caller
-// that is done with the GPU while it still has host work to do — the command line writing its output — runs this on a
-// helper thread, so that the driver's part of taking the process apart is not left for process exit.
-extern "C" int swa_runtime_shutdown(int device) {
-  if (hipSetDevice(device) != hipSuccess) { return SWA_E_DEVICE; }
-  return hipDeviceReset() == hipSuccess ? SWA_OK : SWA_E_DEVICE;
-}
-
 extern "C" const char * swa_last_error(const swa_ctx * ctx) {
   return ctx != nullptr ? ctx->err.c_str() : "null context";
 }

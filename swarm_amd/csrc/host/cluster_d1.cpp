@@ -447,7 +447,6 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
 }
 
 extern "C" void swa_d1_result_free(swa_d1_result * r) { delete r; }
-extern "C" void swa_d1_result_detach(swa_d1_result * r) { if (r != nullptr) { r->lazy_ctx = nullptr; } }
 
 extern "C" void swa_d1_result_summary(const swa_d1_result * r, uint64_t * out4) {
   out4[0] = r->swarmcount_adjusted;

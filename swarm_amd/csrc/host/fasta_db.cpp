@@ -517,7 +517,7 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   // ONE block of scratch memory for the checks and the sort, one after the other (34 bytes per amplicon: the sort's two
   // record arrays and bucket numbers; the checks take 18 of them): fresh memory is paid for twice — populated when it
   // is mapped, taken apart when it is freed, ~12 ms each way per 160 MB here — and the five arrays this replaces were
-  // each mapped and freed on this thread.  It stays with the handle until swa_hostdb_trim / swa_hostdb_free.
+  // each mapped and freed on this thread.  It stays with the handle (unmapping 340 MB here would cost this thread 25 ms; at process exit it costs the same or — when the kernel takes the address space apart on its own time — nothing).
   db->scratch.resize((size_t)n * 34 + 64);
   char * const scratch = db->scratch.data();
   timer.lap("scratch block");
@@ -749,31 +749,9 @@ extern "C" void swa_hostdb_free(swa_hostdb * db) { delete db; }
 
 extern "C" const char * swa_hostdb_error(const swa_hostdb * db) { return db != nullptr ? db->error.c_str() : ""; }
 
-// What the handle holds beyond what its users still read: the reader's scratch block and — keep_words == 0 — the packed
-// words (once they are on the GPU nothing on the host reads them but -w, -u and swa_hostdb_view).  Meant for a helper
-// thread beside the GPU's work: taking 0.75 GB apart costs ~55 ms of one thread at 10 M amplicons, at process exit too.
-extern "C" void swa_hostdb_trim(swa_hostdb * db, int keep_words) {
-  if (db == nullptr) { return; }
-  // In slices: an unmap holds the process's memory-map lock while it takes the pages apart, and whoever wants to map
-  // or unmap meanwhile — hipMalloc on the main thread, a growing output buffer — waits for all of it (a 340-MB block
-  // at once stalled the index build's allocations for 75 ms, lease r5h).  MADV_DONTNEED gives the pages back under the
-  // shared lock, 16 MB (~1 ms) at a time; freeing the emptied block afterwards is quick.
-  if (!db->scratch.empty()) {
-    constexpr size_t kPage = 4096, kSlice = size_t(16) << 20;
-    const uintptr_t lo = ((uintptr_t)db->scratch.data() + kPage - 1) & ~(uintptr_t)(kPage - 1);
-    const uintptr_t hi = ((uintptr_t)db->scratch.data() + db->scratch.size()) & ~(uintptr_t)(kPage - 1);
-    for (uintptr_t a = lo; a < hi; a += kSlice) { (void)::madvise(reinterpret_cast<void *>(a), std::min<uintptr_t>(kSlice, hi - a), MADV_DONTNEED); }
-    swa_vec<char>().swap(db->scratch);
-  }
-  if (keep_words == 0 && !db->ordered) {
-    for (auto & pc : db->pieces) { std::vector<uint64_t>().swap(pc.words); }      // (a pool per parser thread: a few MB each)
-    db->words_gone = true;
-  }
-}
-
 // the packed sequences contiguous in db order (swa_db_view): gathered from the pieces the first time somebody asks
 static void order_on_host(swa_hostdb * db) {
-  if (db->ordered || db->words_gone) { return; }
+  if (db->ordered) { return; }
   const uint64_t n = db->n;
   db->seq_off.resize(n + 1);
   const unsigned threads = swa_pool::get().size();

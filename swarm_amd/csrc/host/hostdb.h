@@ -101,8 +101,7 @@ struct swa_hostdb {
   // the packed sequences in db order, contiguous (the layout of swa_db_view): made on demand, swa_hostdb_view
   swa_vec<uint64_t> seqs, seq_off;
   bool ordered = false;
-  swa_vec<char> scratch;                    // the reader's scratch block (swa_hostdb_trim)
-  bool words_gone = false;                  // swa_hostdb_trim(db, 0) released the word pools
+  swa_vec<char> scratch;                    // the reader's scratch block (checks, sort), kept until the handle is freed
   std::vector<const uint64_t *> piece_ptrs;   // what swa_hostdb_unordered_view points at
   std::vector<uint64_t> piece_counts;
   std::string error;

@@ -338,8 +338,6 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
                uview.n, uview.longest);
 
   const uint32_t n = uview.n;
-  std::thread trimmer, gpu_release;
-  const int gpu_device = device;
   swa_ctx * ctx = nullptr;
   swa_multi * multi = nullptr;           // d = 1 on several GPUs: SWARM_AMD_DEVICES=0,1,2,... (one rank per entry)
   if (n > 0) {
@@ -361,10 +359,6 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       stamp("context created");
       if (swa_db_upload_unordered(ctx, &uview) != SWA_OK) { die(swa_last_error(ctx)); }
       stamp("database uploaded");
-      // the reader's scratch memory and — unless an output prints sequences (-w) or aligns them (-u) — the packed words go
-      // back to the kernel on a thread of their own while the GPU works: the same pages cost the same time at exit
-      const bool keep_words = !o.seeds.empty() || !o.uclust.empty();
-      if (std::getenv("SWARM_AMD_NO_TRIM") == nullptr) trimmer = std::thread([db, keep_words]() { swa_hostdb_trim(db, keep_words ? 1 : 0); stamp("(helper thread) scratch memory and word pools released"); });
     }
   }
 
@@ -448,19 +442,6 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     phase(o, "Clustering:       ");
     uint64_t sum[4];
     swa_d1_result_summary(res, sum);
-    // Only the swarms file is wanted: the GPU's part is over.  The context and the HIP runtime are taken apart on a helper
-    // thread while this one writes — otherwise the driver does it at process exit, inside the caller's wall time.
-    if (resident && multi == nullptr && !o.fastidious && o.seeds.empty() && o.structure.empty() && o.uclust.empty() && o.stats.empty() &&
-        std::getenv("SWARM_AMD_KEEP_GPU") == nullptr) {
-      swa_d1_result_detach(res);
-      swa_ctx * gone = ctx;
-      ctx = nullptr;
-      gpu_release = std::thread([gone, gpu_device]() {
-        swa_ctx_destroy(gone);
-        (void)swa_runtime_shutdown(gpu_device);
-        stamp("(helper thread) GPU context and HIP runtime released");
-      });
-    }
 
     if (o.fastidious) {
       std::fprintf(g_log, "\nResults before fastidious processing:\n");
@@ -561,8 +542,6 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
                  sum[1], sum[2]);
   }
-  if (trimmer.joinable()) { trimmer.join(); }
-  if (gpu_release.joinable()) { gpu_release.join(); }
   stamp("results written");
   stamp_usage("results written");
   // Every output file is closed at this point.  What is left costs at exit by what the kernel has to take apart on ONE
