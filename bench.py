@@ -48,6 +48,20 @@ import json
 import os
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # before torch / the library load libgomp (see swarm_amd/capi.py)
+
+
+def _usable_cpus() -> int:              # (affinity and cgroup CPU quota: swarm_amd/capi.py usable_cpus, host/pool.h swa_host_cpus)
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, round(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(min(32, _usable_cpus())))   # (the host phases' OpenMP teams, as the command line sets them)
 import subprocess
 import sys
 import tempfile

@@ -12,6 +12,30 @@ import os
 # libgomp's default (workers spin between parallel regions) costs the host phases up to 30x on a many-core GPU host
 # (see host/main.cpp); it reads the variable when it is first loaded, which importing this module usually precedes.
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: affinity, cut down to the cgroup's CPU quota (what swa_host_cpus, host/pool.h,
+    computes for the library's own worker threads) — a container that sees 256 CPUs and may use 16 is throttled as soon
+    as more than 16 threads are busy."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, round(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, round(q / p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+# (the OpenMP teams of the host phases, like the command line sets them: host/main.cpp)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(32, usable_cpus())))
 import subprocess
 from pathlib import Path
 
