@@ -893,6 +893,7 @@ static uint32_t anchor_max_nwin(const swa_ctx *) {
 }
 // groups of 65..pair_big members go to the pair kernel as well (one workgroup each); SWA_D1_PAIR_BIG=64 leaves
 // them to the tiled kernel (test switch)
+static bool member_index_enabled();
 static uint32_t pair_big_limit() {
   const char * env = getenv("SWA_D1_PAIR_BIG");
   return env != nullptr ? std::min<uint32_t>(kPairBigCap, std::max<uint32_t>(kSeedsPerItem, (uint32_t)atoi(env))) : kPairBigCap;
@@ -1243,6 +1244,9 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   k.nwin = ctx->anchor_w / 32u;
   k.flags = dflags;
   k.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
+  // (single GPU, the whole database keyed: the short sequences and their possible neighbours become members of the plain
+  // kernel's table; a rank of a multi-GPU job keeps the database-wide table for them)
+  k.mark_short = (!routed && ctx->owner_world == 1u && member_index_enabled()) ? static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr) : nullptr;
   if (const char * e = getenv("SWA_D1_GUARD_TEST")) {         // (test hook: a wrong index, on purpose; "...-once": only the first build)
     static int builds = 0;
     const bool once = strstr(e, "-once") != nullptr;
@@ -1833,8 +1837,10 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   }
   if (flags[1] != 0) { ctx->db_unordered = true; }
   *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
-  // (groups left to the plain kernel are the ONLY reason: a table of their members alone serves it — build_member_index)
-  ctx->only_oversized = flags[4] != 0 && flags[1] == 0 && flags[3] == 0;
+  // (groups left to the plain kernel — and, on a single GPU, sequences too short for two windows — are the ONLY reason: a
+  // table of their members alone serves it — build_member_index)
+  ctx->only_oversized = flags[1] == 0 && (flags[4] != 0 || flags[3] != 0) &&
+                        (flags[3] == 0 || (ctx->owner_world == 1u && ctx->route_ids[0] == nullptr && member_index_enabled()));
   ctx->over_mass = flags[5];
   return SWA_OK;
 }

@@ -509,10 +509,9 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     swa_d1_result_summary(res, sum);
     std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
                  sum[1], sum[2]);
-    // (experiment, lease r5j — what decides between the short and the long process exit: A = the result arrays, which a
-    // pinned copy was made into, stay mapped; B = they are unmapped and the process lingers 3 ms)
-    if (const char * e = std::getenv("SWARM_AMD_EXPERIMENT_EXIT")) { if (e[0] == 'B') { swa_d1_result_free(res); usleep(3000); } }
-    else { swa_d1_result_free(res); }
+    // (the result's arrays are left to the kernel with the rest, unless an orderly teardown was asked for: unmapping them
+    // here is time the caller waits, lease r5j)
+    if (std::getenv("SWARM_AMD_FULL_TEARDOWN") != nullptr) { swa_d1_result_free(res); }
   } else {
     // ---- d >= 2: host greedy loop, every q-gram / alignment step on the GPU
     swa_dn_result * res = nullptr;
