@@ -158,6 +158,12 @@ __global__ __launch_bounds__(256) void k_dg_scatter(const GroupArgs a, const uin
   }
 }
 
+// BLOCKED = false: the tiles of k_dg_pairs (4096 pairs, at most kStride items a group); true: the blocks of k_dg_pairs_lds
+// (kBlockT targets x kBlockQ queries each, item.tile = target block + target blocks x query chunk)
+constexpr uint32_t kBlockT = 64;          // targets of a block: one per lane
+constexpr uint32_t kBlockQ = 256;         // queries of a block, staged kStageQ at a time
+constexpr uint32_t kStageQ = 16;
+template <bool BLOCKED>
 __global__ __launch_bounds__(256) void k_dg_items(const uint32_t * __restrict__ cnt_t, const uint32_t * __restrict__ cnt_q,
                                                   const uint32_t * __restrict__ tot, const uint64_t * __restrict__ offsets,
                                                   uint64_t asize, dg_item * items, uint32_t * counter, uint32_t cap) {
@@ -168,6 +174,10 @@ __global__ __launch_bounds__(256) void k_dg_items(const uint32_t * __restrict__ 
   const uint64_t start = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   auto items_of = [&](uint64_t s) -> uint32_t {
     if (tot[s] == 0u) { return 0u; }
+    if (BLOCKED) {
+      const uint64_t blocks = (uint64_t)((cnt_t[s] + kBlockT - 1u) / kBlockT) * ((cnt_q[s] + kBlockQ - 1u) / kBlockQ);
+      return (uint32_t)(blocks < 0x7FFFFFFFull ? blocks : 0x7FFFFFFFull);
+    }
     const uint64_t tiles = ((uint64_t)cnt_t[s] * cnt_q[s] + kTile - 1) / kTile;
     return (uint32_t)(tiles < kStride ? tiles : kStride);
   };
@@ -292,6 +302,126 @@ __global__ __launch_bounds__(256) void k_dg_pairs(const PairArgs a) {
               }
             }
           }
+        }
+        const uint64_t m = __ballot(take);
+        if (m != 0ull) {
+          if (take) { stage[nstage + (uint32_t)__popcll(m & lane_lt)] = ((unsigned long long)q << 32) | t; }
+          nstage += (uint32_t)__popcll(m);
+          if (nstage > kStage - 64u) { flush(); }
+        }
+      }
+    }
+  }
+  if (nstage != 0u) { flush(); }
+  for (int o = 32; o > 0; o >>= 1) { compared += shfl_u64(compared, lane ^ o); }
+  if (lane == 0 && compared != 0ull) { atomicAdd(&a.counters[1], compared); }
+}
+
+// The same pairs, block by block (r05).  k_dg_pairs computes every pair from global memory: two lengths, two offsets, up
+// to (k + 1)(2 d + 1) windows cut out of the target's words and two 128-byte signatures PER PAIR — 16 ms of 57 at
+// 1 M x 400, d = 3, 0.07 of the HBM roofline on bytes that mostly came from L2.  Here a wave takes a
+// block of a group: 64 targets, one per lane, each with its windows at every shift (cut out once), its validity bits and
+// its signature in registers; the queries pass by in LDS, kStageQ at a time — their windows, lengths, ids and
+// signatures are read by all lanes at the same address (a broadcast) — so a pair costs ~2 instructions of a wave, and
+// the global reads are one signature and a few words per MEMBER of the block.  D = the template's d (<= 3: 28 window
+// registers); other d: k_dg_pairs.
+template <int D>
+__global__ __launch_bounds__(256) void k_dg_pairs_lds(const PairArgs a) {
+  constexpr int NS = 2 * D + 1;
+  struct QRec { uint64_t sig[16]; uint64_t win[D + 1]; uint32_t id, len; };
+  __shared__ unsigned long long stage_all[4][kStage];
+  __shared__ QRec qrec_all[4][kStageQ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long * stage = stage_all[wave];
+  QRec * qrec = qrec_all[wave];
+  uint32_t nstage = 0;
+  unsigned long long compared = 0;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  auto flush = [&]() {
+    wave_lds_sync();
+    unsigned long long base = 0;
+    if (lane == 0) { base = atomicAdd(&a.counters[0], (unsigned long long)nstage); }
+    base = shfl_u64(base, 0);
+    for (uint32_t i = lane; i < nstage; i += 64u) { if (base + i < a.pair_cap) { a.pairs[base + i] = stage[i]; } }
+    nstage = 0;
+    wave_lds_sync();
+  };
+  const uint32_t nitems = min(*a.item_count, a.item_cap);
+  const uint32_t nwaves = gridDim.x * 4u;
+  const uint32_t K = a.k;                                     // this launch's window (<= D), wave-uniform
+  for (uint32_t it = blockIdx.x * 4u + wave; it < nitems; it += nwaves) {
+    const dg_item item = a.items[it];
+    const uint32_t * targets = a.members + item.begin;
+    const uint32_t * queries = targets + item.nt;
+    const uint32_t ntb = (item.nt + kBlockT - 1u) / kBlockT;
+    const uint32_t tb = item.tile % ntb, qc = item.tile / ntb;
+    // ---- my target: windows at every shift of the windows 0 .. K, validity, signature
+    const uint32_t ti = tb * kBlockT + (uint32_t)lane;
+    const bool have_t = ti < item.nt;
+    const uint32_t t = have_t ? targets[ti] : 0u;
+    const int lt = have_t ? (int)a.seqlen[t] : 0;
+    const uint64_t * st = a.seqs + a.seq_off[t];
+    uint64_t twin[D + 1][NS];
+    uint32_t valid = 0u;
+#pragma unroll
+    for (int k2 = 0; k2 <= D; ++k2) {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int pos = k2 * (int)a.wlen + s2 - D;
+        const bool ok = have_t && (uint32_t)k2 <= K && pos >= 0 && pos + (int)a.wlen <= lt;
+        twin[k2][s2] = ok ? window(st, (uint32_t)pos, a.wlen) : 0ull;
+        valid |= ok ? 1u << (k2 * NS + s2) : 0u;
+      }
+    }
+    uint64_t tsig[16];
+    {
+      const ulonglong2 * gt = a.sigs + (uint64_t)t * 8u;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { const ulonglong2 y = have_t ? gt[w] : make_ulonglong2(0ull, 0ull); tsig[2 * w] = y.x; tsig[2 * w + 1] = y.y; }
+    }
+    const uint32_t q_begin = qc * kBlockQ, q_end = min(item.nq, q_begin + kBlockQ);
+    for (uint32_t qs = q_begin; qs < q_end; qs += kStageQ) {
+      const uint32_t nq_here = min(kStageQ, q_end - qs);
+      wave_lds_sync();
+      // ---- the next queries into LDS: lanes [16 j', 16 j' + 16) carry the signature words of query 4 r + j'
+      for (uint32_t r = 0; r < kStageQ / 4u; ++r) {
+        const uint32_t j = 4u * r + ((uint32_t)lane >> 4), w = (uint32_t)lane & 15u;
+        if (j < nq_here) {
+          const uint32_t q = queries[qs + j];
+          qrec[j].sig[w] = reinterpret_cast<const uint64_t *>(a.sigs + (uint64_t)q * 8u)[w];
+        }
+      }
+      if ((uint32_t)lane < nq_here) {
+        const uint32_t q = queries[qs + (uint32_t)lane];
+        const uint64_t * sq = a.seqs + a.seq_off[q];
+        qrec[lane].id = q; qrec[lane].len = a.seqlen[q];
+#pragma unroll
+        for (int k2 = 0; k2 <= D; ++k2) { qrec[lane].win[k2] = (uint32_t)k2 <= K ? window(sq, (uint32_t)k2 * a.wlen, a.wlen) : 0ull; }
+      }
+      wave_lds_sync();
+      for (uint32_t j = 0; j < nq_here; ++j) {
+        const uint32_t q = qrec[j].id;
+        const int dl = (int)qrec[j].len - lt;
+        bool take = have_t && q < t && dl >= -D && dl <= D;
+        // the pair belongs to the FIRST window of the query that reappears (shifted) in the target
+        bool earlier = false, here = false;
+#pragma unroll
+        for (int k2 = 0; k2 <= D; ++k2) {
+          const uint64_t wq = qrec[j].win[k2];
+          bool hit = false;
+#pragma unroll
+          for (int s2 = 0; s2 < NS; ++s2) { hit = hit || (((valid >> (k2 * NS + s2)) & 1u) != 0u && twin[k2][s2] == wq); }
+          earlier = earlier || ((uint32_t)k2 < K && hit);
+          here = here || ((uint32_t)k2 == K && hit);        // (the group key may collide: window K must really reappear)
+        }
+        take = take && !earlier && here;
+        if (__ballot(take) != 0ull) {
+          // q-gram bound (qgram_diff, src/qgram.cc:68-96): ceil(popcount(sig_q ^ sig_t) / 10) <= d
+          uint32_t pop = 0;
+#pragma unroll
+          for (int w = 0; w < 16; ++w) { pop += (uint32_t)__popcll(qrec[j].sig[w] ^ tsig[w]); }
+          if (take) { ++compared; }
+          take = take && (pop + 9u) / 10u <= (uint32_t)D;
         }
         const uint64_t m = __ballot(take);
         if (m != 0ull) {
@@ -509,13 +639,19 @@ int swa_dn_graph_compute(swa_ctx * ctx, int no_cluster_breaking) {
                                              ctx->stream));
         hipLaunchKernelGGL(k_dg_scatter, gn, b, 0, ctx->stream, g, tot, goff, cur_t, cur_q, members);
         SWA_HIP(ctx, hipMemsetAsync(dflags + 8, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(k_dg_items, ga, b, 0, ctx->stream, cnt_t, cnt_q, tot, goff, asize, items, dflags + 8, item_cap);
+        // blocks of 64 targets x 256 queries for the LDS kernel (d = 2, 3; SWA_DN_PAIRS=plain: the per-pair kernel, as for other d)
+        static const bool plain_pairs = [] { const char * e = getenv("SWA_DN_PAIRS"); return e != nullptr && e[0] == 'p'; }();
+        const bool blocked = !plain_pairs && (d == 2u || d == 3u);
+        if (blocked) { hipLaunchKernelGGL(k_dg_items<true>, ga, b, 0, ctx->stream, cnt_t, cnt_q, tot, goff, asize, items, dflags + 8, item_cap); }
+        else { hipLaunchKernelGGL(k_dg_items<false>, ga, b, 0, ctx->stream, cnt_t, cnt_q, tot, goff, asize, items, dflags + 8, item_cap); }
         PairArgs p{};
         p.seqs = ctx->db.seqs; p.seq_off = ctx->db.seq_off; p.seqlen = ctx->db.seqlen;
         p.sigs = static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr);
         p.members = members; p.items = items; p.item_count = dflags + 8; p.item_cap = item_cap; p.d = d; p.k = k; p.wlen = wlen;
         p.pairs = static_cast<unsigned long long *>(ctx->d_fpairs.ptr); p.counters = fc; p.pair_cap = ctx->dn_pair_cap;
-        hipLaunchKernelGGL(k_dg_pairs, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, p);
+        if (blocked && d == 2u) { hipLaunchKernelGGL(k_dg_pairs_lds<2>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, p); }
+        else if (blocked) { hipLaunchKernelGGL(k_dg_pairs_lds<3>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, p); }
+        else { hipLaunchKernelGGL(k_dg_pairs, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, p); }
         SWA_HIP(ctx, hipGetLastError());
         launches += 9;
       }
