@@ -306,8 +306,11 @@ __global__ __launch_bounds__(128) void k_align_wfa(const WfaArgs w) {
   uint64_t * qw = lds + (size_t)(2 * group) * a.maxwords;
   uint64_t * dw = qw + a.maxwords;
   // wavefront history: [step][M | I | D][lane], offset + 1 as u16 (0 = invalid)
+  // (room for the steps this scoring HAS, not for the most a scoring may have: 25 steps at the default penalties and
+  // d = 3 are 19 KB a workgroup instead of 49 — eight workgroups a CU instead of three; the kernel waits on dependent LDS
+  // round trips, so the waves in flight are its throughput, r05)
   uint16_t * hist = reinterpret_cast<uint16_t *>(lds + (size_t)(2 * kGroups) * a.maxwords) +
-                    (size_t)group * (kWfaMaxSteps * 3 * G);
+                    (size_t)group * ((size_t)w.nsteps * 3 * G);
   const int W = a.W;
   const int k = t - 1 - W;
   const bool lane_in_band = t >= 1 && t <= 2 * W + 1;
@@ -617,9 +620,9 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, 
     w.steps = static_cast<const swa_wfa_step *>(ctx->d_wfa.ptr);
     w.nsteps = ctx->wfa_steps;
     uint64_t wblocks = ((uint64_t)max_count + 3) / 4;
-    if (wblocks > cap) { wblocks = cap; }
+    if (wblocks > 2 * cap) { wblocks = 2 * cap; }
     if (wblocks < 1) { wblocks = 1; }
-    const size_t wlds = sizeof(uint64_t) * (size_t)a.maxwords * 8 + sizeof(uint16_t) * 4 * (size_t)kWfaMaxSteps * 3 * 32;
+    const size_t wlds = sizeof(uint64_t) * (size_t)a.maxwords * 8 + sizeof(uint16_t) * 4 * (size_t)w.nsteps * 3 * 32;
     hipLaunchKernelGGL(k_align_wfa, dim3((unsigned)wblocks), dim3(128), wlds, ctx->stream, w);
   } else if (generic) {
     a.W = W64 > 0x3FFFFFFF ? 0x3FFFFFFF : (int)W64;
