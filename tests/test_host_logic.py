@@ -131,6 +131,54 @@ def test_repeated_identifiers_in_a_large_file_are_reported_like_the_sequential_s
     assert f"Duplicated sequence identifier: {names[90_000]}\n" in str(e.value)
 
 
+def test_unordered_view_and_the_staging_notice_describe_the_same_database(tmp_path):
+    """The reader keeps the packed words where its parser threads wrote them (file order, one pool per thread) and tells a
+    caller about the pools as soon as the parse is done (swa_hostdb_read_fasta_staged: what the command line's GPU helper
+    thread copies while the reader sorts).  swa_hostdb_unordered_view — what swa_db_upload_unordered takes — must point at
+    the same pools, and pools + src_off must spell the db-order sequences of swa_hostdb_view word for word."""
+    import ctypes as C
+    from swarm_amd.capi import DbUnorderedView, DbView
+    rng = np.random.default_rng(3)
+    n = 150_000
+    text = "".join(f">r{i}_{1 + int(a)}\n{''.join('ACGT'[c] for c in rng.integers(0, 4, int(L)))}\n"
+                   for i, (a, L) in enumerate(zip(rng.integers(0, 30, n), rng.integers(20, 90, n))))
+    fa = tmp_path / "staged.fa"
+    fa.write_text(text)
+    assert fa.stat().st_size > 8 << 20                       # several parser threads
+    lib = capi.load_library()
+    told = {}
+    NOTICE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32)
+
+    def on_words(user, pools, counts, pieces):
+        told["pools"] = [pools[p] for p in range(pieces)]
+        told["counts"] = [int(counts[p]) for p in range(pieces)]
+
+    h = C.c_void_p()
+    lib.swa_hostdb_read_fasta_staged.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int, NOTICE, C.c_void_p, C.POINTER(C.c_void_p)]
+    assert lib.swa_hostdb_read_fasta_staged(str(fa).encode(), 0, 0, 0, NOTICE(on_words), None, C.byref(h)) == 0
+    try:
+        u = DbUnorderedView()
+        lib.swa_hostdb_unordered_view(h, C.byref(u))
+        assert u.n == n and u.pieces == len(told["pools"]) >= 2
+        pools = C.cast(u.piece_words, C.POINTER(C.c_void_p))
+        counts = C.cast(u.piece_word_count, C.POINTER(C.c_uint64))
+        assert [pools[p] for p in range(u.pieces)] == told["pools"] and [int(counts[p]) for p in range(u.pieces)] == told["counts"]
+        words = np.concatenate([np.frombuffer((C.c_char * (8 * c)).from_address(a), dtype=np.uint64) for a, c in zip(told["pools"], told["counts"]) if c])
+        src_off = np.frombuffer((C.c_char * (8 * n)).from_address(u.src_off), dtype=np.uint64).astype(np.int64)
+        seqlen = np.frombuffer((C.c_char * (4 * n)).from_address(u.seqlen), dtype=np.uint32)
+        v = DbView()
+        lib.swa_hostdb_view(h, C.byref(v))
+        seq_off = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(v.seq_off), dtype=np.uint64).astype(np.int64)
+        seqs = np.frombuffer((C.c_char * (8 * int(seq_off[n]))).from_address(v.seqs), dtype=np.uint64)
+        nw = (seqlen.astype(np.int64) + 31) >> 5
+        assert np.array_equal(seq_off[1:] - seq_off[:-1], nw)
+        for k in range(int(nw.max())):                      # word k of every amplicon that has one
+            has = nw > k
+            assert np.array_equal(words[src_off[has] + k], seqs[seq_off[:-1][has] + k])
+    finally:
+        lib.swa_hostdb_free(h)
+
+
 def test_hostdb_usearch_and_append_abundance():
     hdb = HostDb(G / "d1_usearch.fasta", usearch_abundance=True, append_abundance=2)
     db = S.build_db([(h, s) for h, s in S.read_fasta(G / "d1_short.fasta")])
