@@ -591,7 +591,7 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
     });
     return found.load();
   };
-  if (std::getenv("SWARM_AMD_EXPERIMENT_NO_ID_CHECK") == nullptr) {
+  {
     dup_id_at = earliest_repetition(
         [&](const swa_entry & e) { const char * ids; uint32_t idl; id_span(e, ids, idl); const uint64_t h = bytes_hash(ids, idl); return h * 0x9E3779B97F4A7C15ull; },
         [&](const swa_entry & x, const swa_entry & y) {

@@ -291,7 +291,6 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
   std::promise<Words> words_promise;
   std::future<Words> words_ready = words_promise.get_future();
   bool words_told = false;
-  const bool gpu_after_read = std::getenv("SWARM_AMD_GPU_AFTER_READ") != nullptr;     // (experiment: the reader alone, then the GPU)
   const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
   const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
   auto start_helper = [&]() {
@@ -308,7 +307,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       }
     });
   };
-  if (!use_multi && !gpu_after_read) { start_helper(); }
+  if (!use_multi) { start_helper(); }
 
   // ---- read the database (seam L2, host side)
   swa_hostdb * db = nullptr;
@@ -326,7 +325,6 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
   if (!words_told) { words_promise.set_value(Words{}); }
   stamp("database read and ordered");
   stamp_usage("after the read");
-  if (!use_multi && gpu_after_read) { start_helper(); }
   if (early.joinable()) { early.join(); }
   if (rc != SWA_OK) { die_raw(db != nullptr ? swa_hostdb_error(db) : "\nError: out of memory"); }
   phase(o, "Reading sequences:");
@@ -546,15 +544,14 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
   }
   stamp("results written");
   stamp_usage("results written");
-  // Every output file is closed at this point.  What is left costs at exit by what the kernel has to take apart on ONE
-  // thread: ~75 ms per GB of host pages on the bench host, nothing measurable for device memory (lease r5a,
-  // tools/experiments/init_cost.hip).  So the host database's pages go back now, on all worker threads
-  // (swa_hostdb_free -> swa_release_pages: a few ms), and the device side and the HIP runtime are left to the kernel
-  // (SWARM_AMD_FULL_TEARDOWN=1 keeps the orderly path, e.g. under a leak checker).
+  // Every output file is closed at this point.  What the process still holds costs at exit by what the kernel has to take
+  // apart on ONE thread — ~75 ms per GB of host pages on the bench host, nothing measurable for device memory — or next
+  // to nothing when a kernel worker that still holds the address space does it on its own time.  Freeing
+  // anything here first only adds to the caller's wait (measured: in parallel, in slices, on helper threads — leases
+  // c, i), so everything is left to the kernel (SWARM_AMD_FULL_TEARDOWN=1 keeps the orderly path, e.g. under a leak checker).
   if (std::getenv("SWARM_AMD_FULL_TEARDOWN") == nullptr) {
     if (g_log != stderr && g_log != stdout) { std::fclose(g_log); }
     std::fflush(nullptr);
-    if (std::getenv("SWARM_AMD_FREE_AT_EXIT") != nullptr) { swa_hostdb_free(db); stamp("host database released"); }
     std::_Exit(EXIT_SUCCESS);
   }
   if (multi != nullptr) { swa_multi_destroy(multi); }
