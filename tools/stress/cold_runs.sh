@@ -20,7 +20,7 @@ for ((r = 0; r < RUNS; ++r)); do
   if [ $rc -eq 0 ] && [ "$got" == "$WANT" ]; then ok[$c]=$((${ok[$c]:-0} + 1)); else bad[$c]=$((${bad[$c]:-0} + 1)); cp /tmp/cold_err.txt gpurun_out/stress/cold_failure_$r.txt; fi
   if grep -q "guard" /tmp/cold_err.txt; then retried[$c]=$((${retried[$c]:-0} + 1)); cp /tmp/cold_err.txt gpurun_out/stress/cold_guard_$r.txt; fi
 done
-serial=$(rocm-smi --showserial 2>/dev/null | grep -i "serial number" | head -1 | awk '{print $NF}')
+serial=$(rocm-smi --showserial 2>/dev/null | grep -i "GPU\[0\]" | head -1 | awk "{print \$NF}")
 {
 printf '{"gpu_serial": "%s", "n": %s, "runs": %s, "seconds": %s, "want_md5": "%s", "by_condition": {' "$serial" "$N" "$RUNS" "$((SECONDS - t0))" "$WANT"
 first=1
