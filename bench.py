@@ -1031,7 +1031,24 @@ def main() -> None:
                     else:
                         out["roofline"].update({"achieved": counter_gbs, "frac": counter_gbs / HBM_PEAK_GBS,
                                                 "achieved_note": "counter bytes of the dominant kernel / its duration"})
+                        if dom == "groups":
+                            out["roofline"]["bound_note"] = ("k_group1 is bound by the NUMBER of instructions its sixteen waves issue against LDS-resident tables "
+                                                             "(DESIGN 3.2: 32 k instructions a wave for ~10 records a lane), neither by HBM nor by VALU throughput; "
+                                                             "the HBM fraction is what the contract asks for, the pair kernels - one per cent shorter on this box - are "
+                                                             "graded by VALU issue under `pair_kernels`")
                         out["roofline"]["hbm"] = hbm_view
+                # the pair kernels by the resource that binds them, whichever kernel is the longest on this box (k_group1 and the
+                # two pair passes are within two per cent of one another)
+                pk = [out["roofline"]["kernels"][g] for g in ("pairs0", "pairs1") if g in out["roofline"]["kernels"] and out["roofline"]["kernels"][g].get("valu_wave_instructions_per_s")]
+                if pk:
+                    rate = sum(k["valu_wave_instructions"] for k in pk) / sum(k["ms"] * 1e-3 for k in pk)
+                    out["roofline"]["pair_kernels"] = {"bound": "valu", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_S, "unit": "wave-instr/s",
+                                                       "frac": rate / VALU_PEAK_WAVE_INSTR_S, "ms": sum(k["ms"] for k in pk),
+                                                       "hbm_bytes_measured": sum(k.get("hbm_bytes_measured", 0.0) for k in pk)}
+                    if ceil is not None:
+                        meas = max((ceil.get(k, {}).get("rate") or 0.0) for k in ("valu_3op", "valu_simple")) or None
+                        if meas:
+                            out["roofline"]["pair_kernels"]["frac_of_measured_ceiling"] = rate / meas
             # what the driver's record keeps is the top level of this line: the numbers a reader of BENCH_rNN.json needs
             # beside `value` live there, not under config
             for name in ("whole_run", "host_seam_ms", "first_step_ms"):

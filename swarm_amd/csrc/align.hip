@@ -285,6 +285,7 @@ struct WfaArgs {
   AlignArgs a;
   const swa_wfa_step * steps;
   uint32_t nsteps;
+  uint32_t ring;                  // steps of history kept: a step reads at most ring - 1 steps back
 };
 
 // 32 nucleotides of `seq` starting at position p (2 bits each, LSB first)
@@ -306,11 +307,13 @@ __global__ __launch_bounds__(128) void k_align_wfa(const WfaArgs w) {
   uint64_t * qw = lds + (size_t)(2 * group) * a.maxwords;
   uint64_t * dw = qw + a.maxwords;
   // wavefront history: [step][M | I | D][lane], offset + 1 as u16 (0 = invalid)
-  // (room for the steps this scoring HAS, not for the most a scoring may have: 25 steps at the default penalties and
-  // d = 3 are 19 KB a workgroup instead of 49 — eight workgroups a CU instead of three; the kernel waits on dependent LDS
-  // round trips, so the waves in flight are its throughput, r05)
+  // (a RING of the steps a step can look back to — score - mismatch, - gap extension, - gap opening - extension are a few
+  // list entries away —, not room for the most steps a scoring may have: 49 KB a workgroup and three workgroups a CU
+  // became a few KB and as many waves as a CU holds; the kernel waits on dependent LDS round trips, so the waves in flight
+  // are its throughput: 21.2 -> 11.7 ms with the history sized by the steps in use, r05)
   uint16_t * hist = reinterpret_cast<uint16_t *>(lds + (size_t)(2 * kGroups) * a.maxwords) +
-                    (size_t)group * ((size_t)w.nsteps * 3 * G);
+                    (size_t)group * ((size_t)w.ring * 3 * G);
+  const uint32_t ring = w.ring;
   const int W = a.W;
   const int k = t - 1 - W;
   const bool lane_in_band = t >= 1 && t <= 2 * W + 1;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(128) void k_align_wfa(const WfaArgs w) {
       if (__ballot(running) == 0ull) { break; }
       const swa_wfa_step st = w.steps[i];
       auto load = [&](int from, int which) -> int {
-        return from >= 0 ? (int)hist[((size_t)from * 3 + which) * G + t] - 1 : -1;
+        return from >= 0 ? (int)hist[((size_t)((uint32_t)from % ring) * 3 + which) * G + t] - 1 : -1;
       };
       const int m_x = load(st.from_x, 0);                     // own diagonal
       const int m_oe = load(st.from_oe, 0);
@@ -377,9 +380,9 @@ __global__ __launch_bounds__(128) void k_align_wfa(const WfaArgs w) {
           }
         }
       }
-      hist[((size_t)i * 3 + 0) * G + t] = (uint16_t)(M + 1);
-      hist[((size_t)i * 3 + 1) * G + t] = (uint16_t)(I + 1);
-      hist[((size_t)i * 3 + 2) * G + t] = (uint16_t)(D + 1);
+      hist[((size_t)(i % ring) * 3 + 0) * G + t] = (uint16_t)(M + 1);
+      hist[((size_t)(i % ring) * 3 + 1) * G + t] = (uint16_t)(I + 1);
+      hist[((size_t)(i % ring) * 3 + 2) * G + t] = (uint16_t)(D + 1);
       // finished when the end diagonal's furthest point is the last column (then row = dl too)
       const bool at_end = running && lane_in_band && k == kend && M == ql;
       const uint64_t endmask = __ballot(at_end);
@@ -556,6 +559,12 @@ extern "C" int swa_search_begin(swa_ctx * ctx, uint64_t mismatch, uint64_t gapop
       SWA_HIP(ctx, hipMemcpyAsync(ctx->d_wfa.ptr, steps.data(), steps.size() * sizeof(swa_wfa_step), hipMemcpyHostToDevice, ctx->stream));
       SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       ctx->wfa_steps = (uint32_t)steps.size();
+      // how far back (in steps) a step looks: its history is a ring of that many steps (k_align_wfa)
+      uint32_t back = 1;
+      for (size_t j = 0; j < steps.size(); ++j) {
+        for (const int32_t from : {steps[j].from_x, steps[j].from_oe, steps[j].from_e}) { if (from >= 0) { back = std::max<uint32_t>(back, (uint32_t)(j - (size_t)from)); } }
+      }
+      ctx->wfa_ring = back + 1;
     }
   }
   return SWA_OK;
@@ -619,10 +628,11 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, 
     w.a = a;
     w.steps = static_cast<const swa_wfa_step *>(ctx->d_wfa.ptr);
     w.nsteps = ctx->wfa_steps;
+    w.ring = std::min<uint32_t>(ctx->wfa_ring != 0 ? ctx->wfa_ring : ctx->wfa_steps, ctx->wfa_steps);
     uint64_t wblocks = ((uint64_t)max_count + 3) / 4;
     if (wblocks > 2 * cap) { wblocks = 2 * cap; }
     if (wblocks < 1) { wblocks = 1; }
-    const size_t wlds = sizeof(uint64_t) * (size_t)a.maxwords * 8 + sizeof(uint16_t) * 4 * (size_t)w.nsteps * 3 * 32;
+    const size_t wlds = sizeof(uint64_t) * (size_t)a.maxwords * 8 + sizeof(uint16_t) * 4 * (size_t)w.ring * 3 * 32;
     hipLaunchKernelGGL(k_align_wfa, dim3((unsigned)wblocks), dim3(128), wlds, ctx->stream, w);
   } else if (generic) {
     a.W = W64 > 0x3FFFFFFF ? 0x3FFFFFFF : (int)W64;

@@ -100,6 +100,7 @@ struct swa_ctx {
   uint64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13, resolution = 1;
   bool search_ready = false;
   uint32_t wfa_steps = 0;        // > 0: the wavefront alignment kernel is exact for the penalties / d in use
+  uint32_t wfa_ring = 0;         // steps of history k_align_wfa keeps (the furthest a step looks back + 1)
   swa_dbuf d_wfa;
 
   // fused d >= 2 scan state (scan.hip)
