@@ -179,6 +179,63 @@ def test_unordered_view_and_the_staging_notice_describe_the_same_database(tmp_pa
         lib.swa_hostdb_free(h)
 
 
+def test_the_avx2_packer_and_the_byte_loop_pack_the_same_words(tmp_path):
+    """fasta_db.cpp packs 32 nucleotides a turn with AVX2 where the CPU has it (pack32_avx2) and falls back to 8 / 1 a turn
+    at line ends, odd characters and on other CPUs: the same file read with SWARM_AMD_NO_AVX2=1 in a process of its own
+    (the switch is read once per process) must give the same database, word for word."""
+    import hashlib
+    import subprocess
+    import sys
+    rng = np.random.default_rng(17)
+    lines = []
+    for i in range(3000):
+        L = 1 + int(rng.integers(0, 700))
+        seq = "".join(rng.choice(list("ACGTUacgtu"), size=L))
+        lines.append(f">q{i}_{1 + int(rng.integers(0, 9))}\n")
+        width = int(rng.choice([31, 32, 33, 63, 64, 65, 100, 1000]))
+        lines.extend(seq[at:at + width] + "\n" for at in range(0, L, width))
+    fa = tmp_path / "packers.fa"
+    fa.write_text("".join(lines))
+
+    def digest_here():
+        hdb = HostDb(fa)
+        return hashlib.md5(hdb.seqs.tobytes() + hdb.seq_off.tobytes() + hdb.seqlen.tobytes()).hexdigest()
+
+    code = ("import sys, hashlib; sys.path.insert(0, sys.argv[1]); from swarm_amd import HostDb; h = HostDb(sys.argv[2]); "
+            "print(hashlib.md5(h.seqs.tobytes() + h.seq_off.tobytes() + h.seqlen.tobytes()).hexdigest())")
+    import os
+    other = subprocess.run([sys.executable, "-c", code, str(S.ROOT), str(fa)], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, SWARM_AMD_NO_AVX2="1"))
+    assert other.returncode == 0, other.stderr[-1000:]
+    assert other.stdout.strip() == digest_here()
+    db = S.db_from_fasta(fa)                                  # ... and the independent Python packer's
+    hdb = HostDb(fa)
+    assert np.array_equal(hdb.seqs, db.seqs[:len(hdb.seqs)]) and np.array_equal(hdb.seq_off, db.seq_off)
+
+
+def test_repeated_sequences_in_a_large_file_for_d_above_one(tmp_path):
+    """The d > 1 duplicate-sequence check (src/db.cc:763-790) goes through the same partitioned tables as the identifier check:
+    a large file with three copies of one sequence and two of another ends in the reference's text (SWA_E_DUPLICATES), the
+    same file without them reads fine."""
+    from swarm_amd.capi import SwaError
+    rng = np.random.default_rng(23)
+    n = 140_000
+    seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, int(L))) for L in rng.integers(40, 70, n)]
+    clean = tmp_path / "clean.fa"
+    clean.write_text("".join(f">u{i}_{1 + i % 5}\n{s}\n" for i, s in enumerate(seqs)))
+    assert clean.stat().st_size > 8 << 20
+    assert HostDb(clean, check_duplicate_sequences=True).n == n
+    seqs[100_000] = seqs[77]
+    seqs[130_000] = seqs[77]
+    seqs[60_001] = seqs[60_000]
+    dups = tmp_path / "dups.fa"
+    dups.write_text("".join(f">u{i}_{1 + i % 5}\n{s}\n" for i, s in enumerate(seqs)))
+    with pytest.raises(SwaError) as e:
+        HostDb(dups, check_duplicate_sequences=True)
+    assert e.value.code == capi.SWA_E_DUPLICATES and "identical sequences" in str(e.value)
+    assert HostDb(dups, check_duplicate_sequences=False).n == n     # (d = 1 finds them on the GPU instead)
+
+
 def test_hostdb_usearch_and_append_abundance():
     hdb = HostDb(G / "d1_usearch.fasta", usearch_abundance=True, append_abundance=2)
     db = S.build_db([(h, s) for h, s in S.read_fasta(G / "d1_short.fasta")])
