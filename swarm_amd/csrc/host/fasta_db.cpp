@@ -347,7 +347,8 @@ struct PhaseTimer {                       // SWARM_AMD_DB_TIMING=1 prints the ph
 template <class Rec, class Less>
 void parallel_sample_sort(Rec * a, Rec * tmp, uint16_t * where, uint64_t n, unsigned threads, Less less, PhaseTimer * timer = nullptr) {
   if (threads <= 1 || n < 100000) { std::sort(a, a + n, less); return; }
-  const unsigned buckets = std::min<unsigned>(threads * 8u, 1024u);
+  static const unsigned env_buckets = [] { const char * e = std::getenv("SWARM_AMD_SORT_BUCKETS"); return e != nullptr ? (unsigned)std::atoi(e) : 0u; }();
+  const unsigned buckets = env_buckets >= 2u ? std::min(env_buckets, 4096u) : std::min<unsigned>(threads * 8u, 1024u);
   constexpr uint64_t kOver = 64;                            // sampled records per bucket
   const uint64_t nsample = (uint64_t)buckets * kOver;
   std::vector<Rec> sample(nsample);
@@ -405,7 +406,18 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   *out = db;
   Input in;
   if (!load_input(path, in, db->error)) { return SWA_E_ARG; }
-  struct Unmap { Input & i; ~Unmap() { if (i.mapped) { ::munmap(const_cast<char *>(i.data), i.size); i.mapped = false; } } } unmap{in};
+  // The mapping of the input stays with the handle, like the scratch block below: unmapping 1.6 GB of text costs this
+  // thread ~25 ms; with the handle (or the process) it costs the same or — when the kernel takes the address space apart
+  // on its own time — nothing, and the pages are the page cache's either way.  (On a failed read it goes at once.)
+  struct Unmap {
+    Input & i; swa_hostdb * db; bool keep = false;
+    ~Unmap() {
+      if (!i.mapped) { return; }
+      if (keep) { db->input_map = const_cast<char *>(i.data); db->input_size = i.size; }
+      else { ::munmap(const_cast<char *>(i.data), i.size); }
+      i.mapped = false;
+    }
+  } unmap{in, db};
 
   int8_t map[256];
   std::memset(map, -1, sizeof(map));
@@ -737,6 +749,7 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
     }
   });
   timer.lap("db order");
+  unmap.keep = true;
   return SWA_OK;
 }
 

@@ -102,6 +102,9 @@ struct swa_hostdb {
   swa_vec<uint64_t> seqs, seq_off;
   bool ordered = false;
   swa_vec<char> scratch;                    // the reader's scratch block (checks, sort), kept until the handle is freed
+  char * input_map = nullptr;               // the mapping of the FASTA file, kept until the handle is freed (fasta_db.cpp)
+  size_t input_size = 0;
+  ~swa_hostdb() { if (input_map != nullptr) { ::munmap(input_map, input_size); } }
   std::vector<const uint64_t *> piece_ptrs;   // what swa_hostdb_unordered_view points at
   std::vector<uint64_t> piece_counts;
   std::string error;
