@@ -15,16 +15,17 @@
 #include <vector>
 
 #include "../../../include/swarm_amd.h"
+#include "pool.h"
 #include "../../../include/swarm_amd_host.h"
 
 // std::vector whose resize() leaves trivially-constructible elements uninitialised: the big
 // arrays below are filled by parallel loops right after being sized, and a value-initialising
 // resize would first zero (and page-fault) hundreds of MB on one thread.  Large blocks are
-// populated up front by a few threads (MADV_POPULATE_WRITE): 64 threads first-touching 4 KiB
-// pages of one fresh mapping contend in the kernel (the reader's gather phase took 270 ms at
-// 10 M amplicons that way, 177 ms populated; transparent huge pages do as well but may stall in
-// compaction).  SWARM_AMD_HOST_ALLOC: 0 plain, 1 transparent huge pages, n >= 2 populate with n
-// threads (default 8).
+// populated up front by a few threads (MADV_POPULATE_WRITE) when many workers will fill them: 64
+// threads first-touching 4 KiB pages of one fresh mapping contend in the kernel (the reader's
+// gather phase took 270 ms at 10 M amplicons that way, 177 ms populated; transparent huge pages
+// do as well but may stall in compaction).  SWARM_AMD_HOST_ALLOC: 0 plain, 1 transparent huge
+// pages, n >= 2 populate with n threads (default: 0 up to 32 usable CPUs, else 8).
 template <class T>
 struct swa_default_init_allocator {
   using value_type = T;
@@ -36,7 +37,10 @@ struct swa_default_init_allocator {
     const size_t bytes = n * sizeof(T);
     void * p = nullptr;
     if (bytes >= kHugeFrom) {
-      static const int mode = [] { const char * e = std::getenv("SWARM_AMD_HOST_ALLOC"); return e == nullptr ? 8 : std::atoi(e); }();
+      // (default: plain first touch by the workers that fill the block when there are few of them — 16 under the bench
+      // box's CPU quota: the reader finishes 30 ms earlier than with the blocks populated up front, lease r5r —, populated by
+      // 8 threads when there are many: 64 workers first-touching one fresh mapping contend in the kernel, round 4)
+      static const int mode = [] { const char * e = std::getenv("SWARM_AMD_HOST_ALLOC"); return e == nullptr ? (swa_host_cpus() > 32u ? 8 : 0) : std::atoi(e); }();
       p = std::aligned_alloc(kHugePage, (bytes + kHugePage - 1) & ~(kHugePage - 1));
       if (p != nullptr && mode == 1) { (void)::madvise(p, bytes, MADV_HUGEPAGE); }
       if (p != nullptr && mode >= 2) {                         // populate with `mode` threads
