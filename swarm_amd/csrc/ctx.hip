@@ -76,7 +76,9 @@ extern "C" int swa_ctx_create(int device, void * stream, swa_ctx ** out) {
     for (void * p : held) { (void)hipFree(p); }
   }
   // the status block and the views into it (swa_internal.h)
-  if (swa_reserve(ctx, ctx->d_status, 4096) != SWA_OK || hipMemset(ctx->d_status.ptr, 0, 4096) != hipSuccess) {
+  if (swa_reserve(ctx, ctx->d_status, 4096) != SWA_OK || hipMemset(ctx->d_status.ptr, 0, 4096) != hipSuccess ||
+      hipHostMalloc(&ctx->h_status, 4096, hipHostMallocDefault) != hipSuccess) {
+    swa_release(ctx->d_status);
     if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
     return SWA_E_NOMEM;
@@ -137,6 +139,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
   }
   for (auto & b : ctx->d_stream) { swa_release(b); }
   if (ctx->h_scan_pinned != nullptr) { (void)hipHostFree(ctx->h_scan_pinned); }
+  if (ctx->h_status != nullptr) { (void)hipHostFree(ctx->h_status); }
   if (ctx->ev_ready) { for (auto & e : ctx->ev) { (void)hipEventDestroy(e); } }
   if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); }
   delete ctx;

@@ -1804,7 +1804,7 @@ static int build_member_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
 // those members only, duplicates inside the owned prefix groups.  *needs_table is set when some
 // seed can only be served by the plain kernel (a sequence shorter than 65 nt anywhere, a group
 // too large for LDS) or the db order does not hold: the caller then builds the full index.
-static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool * needs_table, uint32_t * oversized_mass = nullptr,
+static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool * needs_table, uint32_t * dups, uint32_t * oversized_mass = nullptr,
                              uint32_t * shortest = nullptr) {
   const uint32_t n = ctx->db.n;
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
@@ -1821,10 +1821,12 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   // [4] groups left to the plain kernel (oversized / a member too long) [5] their members [6] 0xFFFFFFFF - shortest sequence
   // (ONE copy of the status block: the flags, and how long the work lists are — the network call then launches no kernel
   // over an empty one)
-  uint32_t status[512] = {};
-  SWA_HIP(ctx, hipMemcpyAsync(status, ctx->d_status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+  // (into the context's pinned mirror: a copy to pageable memory is staged by the runtime, ~15 us more per look)
+  auto * status = static_cast<uint32_t *>(ctx->h_status);
+  SWA_HIP(ctx, hipMemcpyAsync(status, ctx->d_status.ptr, 512 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t * flags = status;
+  *dups = flags[0];
   memcpy(ctx->list_counts, status + 256 + kCounterBase, sizeof(ctx->list_counts));
   ctx->list_counts_ready = true;
   if (oversized_mass != nullptr) { *oversized_mass = flags[5]; }
@@ -1833,7 +1835,7 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
     if (ctx->stream_extra_bits >= 8) { return swa_fail_msg(ctx, SWA_E_DEVICE, "streaming index build: partition still too coarse"); }
     ctx->stream_extra_bits += 2;
     SWA_HIP(ctx, hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), ctx->stream));
-    return build_owned_index(ctx, first, count, needs_table, oversized_mass, shortest);
+    return build_owned_index(ctx, first, count, needs_table, dups, oversized_mass, shortest);
   }
   if (flags[1] != 0) { ctx->db_unordered = true; }
   *needs_table = flags[1] != 0 || flags[3] != 0 || flags[4] != 0;
@@ -1890,7 +1892,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     SWA_TRY(ensure_anchor_windows(ctx));
     const uint32_t sampled = ctx->anchor_a;
     const bool routed = ctx->route_ids[0] != nullptr;        // (the lists were made under these windows: no second thoughts)
-    SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &mass, &shortest));
+    SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &group_dups, &mass, &shortest));
     // Conserved flanks: when a noticeable part of the database sits in groups too large for LDS (everybody shares
     // the first or last 32 nt), the anchor windows move inwards, 32 nt at a time, as far as the shortest sequence
     // allows (every seed needs win_a + win_b + 65 nt), and the setting with the fewest stranded members wins.  Window
@@ -1907,7 +1909,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
         ctx->anchor_w = 32;                                     // (moved windows: anchor_nwin_for)
         SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
         uint32_t m = 0;
-        SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &m));
+        SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &group_dups, &m));
         if (m < best_mass) { best_mass = m; best = w; }
         if (m <= n / 64u) { break; }
       }
@@ -1915,7 +1917,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
         ctx->anchor_a = ctx->anchor_b = best;
         ctx->anchor_w = best == sampled ? ctx->windows_w : 32u;
         SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream));
-        SWA_TRY(build_owned_index(ctx, first, count, &needs_table));
+        SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &group_dups));
       }
     }
     ctx->windows_chosen = ctx->anchor_a;                     // (what the safety net settled on, for the next build)
@@ -1925,9 +1927,12 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
       // nothing but groups too large for the pair kernels stands in the way: a table of their members is all the plain kernel needs
       SWA_TRY(build_member_index(ctx, ctx->owner_world > 1 ? 0u : first, ctx->owner_world > 1 ? n : count));
       owned_ok = true;
+      // (the member table's own search for identical sequences may have raised the flag since the build looked at it)
+      auto * mirror = static_cast<uint32_t *>(ctx->h_status);
+      SWA_HIP(ctx, hipMemcpyAsync(mirror, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      group_dups = mirror[0];
     }
-    SWA_HIP(ctx, hipMemcpyAsync(&group_dups, ctx->d_flags.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!owned_ok) { SWA_HIP(ctx, hipMemsetAsync(ctx->d_flags.ptr, 0, 16 * sizeof(uint32_t), ctx->stream)); }
   }
   uint32_t flag = group_dups;
@@ -2168,13 +2173,15 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     swa_t1(ctx, 4);
     // ONE copy of the status block's first 512 bytes: flags | stats (links, fullest segment, members staged) | the guard's
     // counters | last CSR offset, links sorted
-    uint64_t status[64] = {};
-    SWA_HIP(ctx, hipMemcpyAsync(status, ctx->d_status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
-    uint32_t unserved = 0;                                   // fallback seeds listed while there is no table to serve them
+    auto * status = static_cast<uint64_t *>(ctx->h_status);   // (the pinned mirror)
+    SWA_HIP(ctx, hipMemcpyAsync(status, ctx->d_status.ptr, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t * unserved_at = reinterpret_cast<uint32_t *>(status + 64);
+    *unserved_at = 0;                                        // fallback seeds listed while there is no table to serve them
     if (check_unserved) {
-      SWA_HIP(ctx, hipMemcpyAsync(&unserved, static_cast<uint32_t *>(ctx->d_acounters.ptr) + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+      SWA_HIP(ctx, hipMemcpyAsync(unserved_at, static_cast<uint32_t *>(ctx->d_acounters.ptr) + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t unserved = *unserved_at;
     const uint64_t * got = status + 8 + 8;                    // d_stats[8 ..]: links, fullest segment, members staged by pass
     const uint64_t * guard = status + 24;
     const uint32_t anchor_overflow = reinterpret_cast<const uint32_t *>(status)[2];

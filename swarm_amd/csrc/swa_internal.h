@@ -60,6 +60,7 @@ struct swa_ctx {
   //   partition sorted · [1024, 2048) d_acounters.  d_flags / d_stats / d_guard / d_acounters are VIEWS into it (never freed
   //   on their own; their `bytes` is their room, so swa_reserve leaves them alone).
   swa_dbuf d_status;
+  void * h_status = nullptr;     // 4 KB of pinned host memory: where the d = 1 step looks at the status block
   swa_dbuf d_flags;              // u32[16]: [0] duplicate flag
   swa_dbuf d_stats;              // u64[8] probe statistics + [8] edge counter
   swa_dbuf d_edges;              // u64 edge list (src << 32 | dst)

@@ -82,11 +82,10 @@ def main():
         ctx.timing_enable(True)
         T.run("upload", lambda: ctx.upload_hostdb(hdb))
         T.run("index_build", ctx.d1_index_build)
-        off, nb = T.run("network_incl_download", ctx.d1_network)
+        T.run("network_resident", ctx.d1_network_resident)     # (the command line's route: the network stays in HBM)
         ms = ctx.timing_read()
         res["gpu_ms"] = {"seqhash": ms[0], "table": ms[1], "dup": ms[2], "network": ms[3], "csr": ms[4]}
-        cl = T.run("host_clustering", lambda: D1Clusters(hdb, off, nb))
-        res["links"] = int(len(nb))
+        cl = T.run("clustering_gpu_plus_sums", lambda: D1Clusters.from_resident(ctx, hdb))
         if args.fastidious:
             flags, stats = T.run("light_flags", cl.light_flags)
             graft, counters = T.run("fastidious_gpu", lambda: ctx.d1_fastidious(flags, stats[2]))
