@@ -120,10 +120,16 @@ bool swarm_abundance(const char * h, uint32_t len, int32_t & start, int32_t & en
   for (uint32_t i = 0; i < digits; ++i) { if (h[us + 1 + i] < '0' || h[us + 1 + i] > '9') { return false; } }
   start = (int32_t)us;
   end = (int32_t)len;
+  if (digits <= 18) {                // (no overflow possible; "_" alone gives 0 like atol(""))
+    int64_t v = 0;
+    for (uint32_t i = 0; i < digits; ++i) { v = v * 10 + (h[us + 1 + i] - '0'); }
+    number = v;
+    return true;
+  }
   char tmp[24];
   std::memcpy(tmp, h + us + 1, digits);
   tmp[digits] = 0;
-  number = std::atol(tmp);          // "_" alone gives 0 like atol("")
+  number = std::atol(tmp);
   return true;
 }
 
@@ -180,6 +186,29 @@ __attribute__((target("avx2"))) bool pack32_avx2(const char * q, uint64_t * out)
   return true;
 }
 
+// the same for the last r < 32 nucleotides of a line: 32 bytes are read at q (the caller knows they exist), the first r
+// must be nucleotides, the rest — the line's end and whatever follows — is ignored; *out holds 2 r bits
+__attribute__((target("avx2"))) bool pack_tail_avx2(const char * q, uint32_t r, uint64_t * out) {
+  const __m256i raw = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q));
+  const __m256i up = _mm256_and_si256(raw, _mm256_set1_epi8((char)0xDF));
+  const __m256i lo = _mm256_and_si256(up, _mm256_set1_epi8(0x0F));
+  const __m256i hi = _mm256_and_si256(_mm256_srli_epi16(up, 4), _mm256_set1_epi8(0x0F));
+  const __m256i code_of = _mm256_setr_epi8(0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m256i high_of = _mm256_setr_epi8(-1, 4, -1, 4, 5, 5, -1, 4, -1, -1, -1, -1, -1, -1, -1, -1, -1, 4, -1, 4, 5, 5, -1, 4, -1, -1, -1, -1, -1, -1, -1, -1);
+  const __m256i iota = _mm256_setr_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+  const __m256i inside = _mm256_cmpgt_epi8(_mm256_set1_epi8((char)r), iota);                     // bytes [0, r)
+  const __m256i ok = _mm256_cmpeq_epi8(_mm256_shuffle_epi8(high_of, lo), hi);
+  if (_mm256_movemask_epi8(_mm256_or_si256(ok, _mm256_andnot_si256(inside, _mm256_set1_epi8(-1)))) != -1) { return false; }
+  const __m256i codes = _mm256_and_si256(_mm256_shuffle_epi8(code_of, lo), inside);
+  const __m256i pairs = _mm256_maddubs_epi16(codes, _mm256_set1_epi16(0x0401));
+  const __m256i quads = _mm256_madd_epi16(pairs, _mm256_set1_epi32(0x00100001));
+  const __m256i bytes = _mm256_shuffle_epi8(quads, _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                                                   0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+  const uint64_t low = (uint32_t)_mm256_extract_epi32(bytes, 0), high = (uint32_t)_mm256_extract_epi32(bytes, 4);
+  *out = low | (high << 32);
+  return true;
+}
+
 // parse records of [begin, end) — begin points at a '>' that starts a line (or at the file start)
 void parse_piece(const char * begin, const char * end, const int8_t * map, bool usearch, int64_t append_abundance,
                  uint32_t piece_no, Piece & out) {
@@ -227,6 +256,17 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
           else { words.push_back(acc | (chunk << (2u * fill))); acc = chunk >> (64u - 2u * fill); }
           len += 32u;
           q += 32;
+        }
+        const uint32_t rest = (uint32_t)(le - q);           // the line's last nucleotides in one turn, too
+        if (rest != 0u && rest < 32u && q + 32 <= end && pack_tail_avx2(q, rest, &chunk)) {
+          acc |= chunk << (2u * fill);
+          if (fill + rest >= 32u) {
+            words.push_back(acc);
+            acc = chunk >> (2u * (32u - fill));             // (fill >= 1 here: rest < 32)
+          }
+          fill = (fill + rest) & 31u;
+          len += rest;
+          q = le;
         }
       }
       while (q + 8 <= le) {
@@ -395,6 +435,146 @@ void parallel_sample_sort(Rec * a, Rec * tmp, uint16_t * where, uint64_t n, unsi
   if (timer != nullptr) { timer->lap("  sort: buckets sorted"); }
 }
 
+// ---- the db-order sort by radix (the usual case)
+// A sort record: the abundance (saturating at 32 bits), the first 8 header bytes big endian, the entry's number.  Its
+// integer key K = (abundance descending, key8 ascending) decides the db order wherever it differs; records with equal K
+// (same abundance, identifiers that share their first 8 bytes) are put right afterwards by the full comparison.
+struct SortRec { uint64_t key8; uint32_t abundance, entry; };
+static_assert(sizeof(SortRec) == 16, "the scratch block is laid out for 16-byte sort records");
+
+inline bool k_before(const SortRec & a, const SortRec & b) { return a.abundance != b.abundance ? a.abundance > b.abundance : a.key8 < b.key8; }
+inline bool k_equal(const SortRec & a, const SortRec & b) { return a.abundance == b.abundance && a.key8 == b.key8; }
+
+// r[0, n) by K with byte-wise LSD passes between r and s (meant for pieces that fit the core's cache); digits on which
+// all records agree — the abundance's upper bytes, a constant first letter — cost no pass.  The result is in r.
+void lsd_sort_by_k(SortRec * r, SortRec * s, size_t n) {
+  if (n < 48) {
+    for (size_t i = 1; i < n; ++i) {                          // insertion sort
+      const SortRec x = r[i];
+      size_t j = i;
+      while (j > 0 && k_before(x, r[j - 1])) { r[j] = r[j - 1]; --j; }
+      r[j] = x;
+    }
+    return;
+  }
+  uint32_t hist[12][256];
+  std::memset(hist, 0, sizeof(hist));
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t k = r[i].key8;
+    const uint32_t a = ~r[i].abundance;
+    for (int d = 0; d < 8; ++d) { ++hist[d][(k >> (8 * d)) & 255u]; }
+    for (int d = 0; d < 4; ++d) { ++hist[8 + d][(a >> (8 * d)) & 255u]; }
+  }
+  SortRec * src = r, * dst = s;
+  for (int d = 0; d < 12; ++d) {
+    uint32_t * h = hist[d];
+    bool one_bin = false;
+    uint32_t at = 0;
+    for (int b = 0; b < 256; ++b) { const uint32_t c = h[b]; if (c == n) { one_bin = true; } h[b] = at; at += c; }
+    if (one_bin) { continue; }
+    if (d < 8) {
+      const int shift = 8 * d;
+      for (size_t i = 0; i < n; ++i) { dst[h[(src[i].key8 >> shift) & 255u]++] = src[i]; }
+    } else {
+      const int shift = 8 * (d - 8);
+      for (size_t i = 0; i < n; ++i) { dst[h[((~src[i].abundance) >> shift) & 255u]++] = src[i]; }
+    }
+    std::swap(src, dst);
+  }
+  if (src != r) { std::memcpy(r, src, n * sizeof(SortRec)); }
+}
+
+// a[0, n) into db order on `threads` threads: splitters from a regular sample, every thread files its share of the
+// records under them (K alone: records with equal K share a bucket), every bucket — about 8 K records, the two copies
+// fit a core's L2 — is sorted by LSD passes and its runs of equal K by `full_less`.  tmp[0, n) and where[0, n) are
+// scratch; the result is in a.  false (nothing moved): the sample says that K decides too little — identifiers with a
+// long common prefix — and the caller sorts by comparisons.  (No record's abundance may be saturated.)
+template <class Less>
+bool parallel_radix_sort(SortRec * a, SortRec * tmp, uint16_t * where, uint64_t n, unsigned threads, Less full_less, PhaseTimer * timer) {
+  static const unsigned env_buckets = [] { const char * e = std::getenv("SWARM_AMD_SORT_BUCKETS"); return e != nullptr ? (unsigned)std::atoi(e) : 0u; }();
+  const unsigned buckets = env_buckets >= 2u ? std::min(env_buckets, 16384u)
+                                             : (unsigned)std::min<uint64_t>(std::max<uint64_t>(n / 8192u, (uint64_t)threads * 8u), 16384u);
+  constexpr uint64_t kOver = 32;                            // sampled records per bucket
+  const uint64_t nsample = (uint64_t)buckets * kOver;
+  std::vector<SortRec> sample(2 * nsample);
+  for (uint64_t i = 0; i < nsample; ++i) { sample[i] = a[(n - 1) * i / (nsample - 1)]; }
+  lsd_sort_by_k(sample.data(), sample.data() + nsample, nsample);
+  uint64_t ties = 0;
+  for (uint64_t i = 1; i < nsample; ++i) { ties += k_equal(sample[i], sample[i - 1]) ? 1u : 0u; }
+  if (ties * 4 > nsample) { return false; }
+  // the splitters, padded with "after everything" to one less than a power of two: every search takes the same steps, so
+  // four records are searched at once (the chain of dependent loads of one search leaves the core idle otherwise)
+  unsigned padded = 1;
+  while (padded < buckets) { padded <<= 1; }
+  std::vector<SortRec> split(padded, SortRec{~0ull, 0u, 0u});
+  for (unsigned b = 1; b < buckets; ++b) { split[b - 1] = sample[(uint64_t)b * kOver]; }
+  std::vector<uint64_t> place((size_t)threads * buckets, 0);
+  if (timer != nullptr) { timer->lap("  sort: sample + splitters"); }
+  run_parallel(threads, [&](unsigned t) {
+    uint64_t * c = &place[(size_t)t * buckets];
+    const SortRec * sp = split.data();
+    // 1 if x comes before s by K, without a branch
+    auto before = [](const SortRec & x, const SortRec & s) -> unsigned {
+      return (unsigned)(x.abundance > s.abundance) | ((unsigned)(x.abundance == s.abundance) & (unsigned)(x.key8 < s.key8));
+    };
+    const uint64_t lo_i = n * t / threads, hi_i = n * (t + 1) / threads;
+    uint64_t i = lo_i;
+    for (; i + 4 <= hi_i; i += 4) {                         // bucket = number of splitters not above the record
+      const SortRec x0 = a[i], x1 = a[i + 1], x2 = a[i + 2], x3 = a[i + 3];
+      unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      for (unsigned step = padded >> 1; step > 0; step >>= 1) {
+        b0 += step & (before(x0, sp[b0 + step - 1]) - 1u);
+        b1 += step & (before(x1, sp[b1 + step - 1]) - 1u);
+        b2 += step & (before(x2, sp[b2 + step - 1]) - 1u);
+        b3 += step & (before(x3, sp[b3 + step - 1]) - 1u);
+      }
+      b0 = std::min(b0, buckets - 1); b1 = std::min(b1, buckets - 1); b2 = std::min(b2, buckets - 1); b3 = std::min(b3, buckets - 1);
+      where[i] = (uint16_t)b0; where[i + 1] = (uint16_t)b1; where[i + 2] = (uint16_t)b2; where[i + 3] = (uint16_t)b3;
+      ++c[b0]; ++c[b1]; ++c[b2]; ++c[b3];
+    }
+    for (; i < hi_i; ++i) {
+      const SortRec x = a[i];
+      unsigned b = 0;
+      for (unsigned step = padded >> 1; step > 0; step >>= 1) { b += step & (before(x, sp[b + step - 1]) - 1u); }
+      b = std::min(b, buckets - 1);
+      where[i] = (uint16_t)b;
+      ++c[b];
+    }
+  });
+  std::vector<uint64_t> start(buckets + 1, 0);
+  uint64_t at = 0;
+  for (unsigned b = 0; b < buckets; ++b) {
+    start[b] = at;
+    for (unsigned t = 0; t < threads; ++t) { const uint64_t c = place[(size_t)t * buckets + b]; place[(size_t)t * buckets + b] = at; at += c; }
+  }
+  start[buckets] = at;
+  if (timer != nullptr) { timer->lap("  sort: buckets found"); }
+  run_parallel(threads, [&](unsigned t) {
+    uint64_t * c = &place[(size_t)t * buckets];
+    for (uint64_t i = n * t / threads; i < n * (t + 1) / threads; ++i) { tmp[c[where[i]]++] = a[i]; }
+  });
+  if (timer != nullptr) { timer->lap("  sort: records filed"); }
+  std::atomic<unsigned> next{0};
+  run_parallel(threads, [&](unsigned) {
+    for (;;) {
+      const unsigned b = next.fetch_add(1);
+      if (b >= buckets) { break; }
+      SortRec * const r = tmp + start[b];
+      const uint64_t m = start[b + 1] - start[b];
+      lsd_sort_by_k(r, a + start[b], m);                    // (a's own stretch of the same size is the second buffer)
+      for (uint64_t i = 0; i < m;) {                        // runs of equal K: the identifiers decide
+        uint64_t j = i + 1;
+        while (j < m && k_equal(r[j], r[i])) { ++j; }
+        if (j - i > 1) { std::sort(r + i, r + j, full_less); }
+        i = j;
+      }
+      std::memcpy(a + start[b], r, m * sizeof(SortRec));
+    }
+  });
+  if (timer != nullptr) { timer->lap("  sort: buckets sorted by radix"); }
+  return true;
+}
+
 }  // namespace
 
 
@@ -506,9 +686,11 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
     for (unsigned t = 0; t < threads; ++t) { ptrs[t] = pieces[t].words.data(); counts[t] = pieces[t].words.size(); }
     on_words(user, ptrs.data(), counts.data(), threads);
   }
-  // entry g of the file (pieces hold almost equal shares of the entries: a guess and a step or two)
+  // entry g of the file (pieces hold almost equal shares of the entries: a guess — by a multiplication, this runs
+  // several times per amplicon — and a step or two)
+  const uint64_t pieces_per_entry_q32 = ((uint64_t)threads << 32) / std::max<uint64_t>(n64, 1);
   auto entry_at = [&](uint64_t g) -> const swa_entry & {
-    unsigned p = (unsigned)std::min<uint64_t>(threads - 1, g * threads / std::max<uint64_t>(n64, 1));
+    unsigned p = (unsigned)std::min<uint64_t>(threads - 1, (g * pieces_per_entry_q32) >> 32);
     while (g < piece_first[p]) { --p; }
     while (g >= piece_first[p + 1]) { ++p; }
     return pieces[p].entries[g - piece_first[p]];
@@ -684,9 +866,8 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   // their entries), the first 8 header bytes big endian (they decide most ties without touching the header text; equal
   // prefixes fall through to strcmp: same order) and the entry's number.  Inputs that are already in db order (swarm's
   // own -w output, vsearch output) skip it.
-  struct SortRec { uint64_t key8; uint32_t abundance, entry; };
-  static_assert(sizeof(SortRec) == 16, "the scratch block is laid out for 16-byte sort records");
   SortRec * const recs = reinterpret_cast<SortRec *>(scratch);
+  std::atomic<bool> saturated{false};                       // an abundance of 2^32 - 1 or more somewhere: K does not order those
   run_parallel(threads, [&](unsigned t) {
     uint64_t g = piece_first[t];
     const char * pool = pieces[t].hdr_pool.data();
@@ -696,6 +877,7 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
       uint64_t key = 0;
       for (uint32_t i = 0; i < 8; ++i) { key = (key << 8) | (i < hlen ? h[i] : 0u); }
       recs[g] = SortRec{key, (uint32_t)std::min<uint64_t>(e.abundance, 0xFFFFFFFFull), (uint32_t)g};
+      if (e.abundance >= 0xFFFFFFFFull) { saturated.store(true, std::memory_order_relaxed); }
       ++g;
     }
   });
@@ -727,7 +909,13 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
     uint16_t * const where = reinterpret_cast<uint16_t *>(other + n);
     const char * env_sort = std::getenv("SWARM_AMD_SORT_THREADS");
     const unsigned sort_threads = std::max(1u, std::min(threads, env_sort != nullptr ? (unsigned)std::atoi(env_sort) : 32u));
-    parallel_sample_sort(recs, other, where, n64, sort_threads, less, &timer);
+    // The records' integer key (abundance, first 8 identifier bytes) sorts by radix — a third of the comparison sort's CPU
+    // time at 10 M amplicons —; identifiers that mostly share their first 8 bytes, saturated abundances and small inputs
+    // take the comparison sort.  Both leave the one db order (identifiers are unique: a strict total order).
+    static const bool no_radix = std::getenv("SWARM_AMD_NO_RADIX_SORT") != nullptr;
+    const bool by_radix = !no_radix && sort_threads > 1 && n64 >= 100000 && !saturated.load() &&
+                          parallel_radix_sort(recs, other, where, n64, sort_threads, less, &timer);
+    if (!by_radix) { parallel_sample_sort(recs, other, where, n64, sort_threads, less, &timer); }
   }
   timer.lap("sort");
 
@@ -740,7 +928,10 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   run_parallel(threads, [&](unsigned t) {
     const uint64_t lo = n64 * t / threads, hi = n64 * (t + 1) / threads;
     for (uint64_t k = lo; k < hi; ++k) {
-      if (k + 16 < hi) { __builtin_prefetch(&entry_at(recs[k + 16].entry)); }
+      if (k + 32 < hi) {                                    // (an entry is 40 bytes: it may lie across two cache lines)
+        const char * ahead = reinterpret_cast<const char *>(&entry_at(recs[k + 32].entry));
+        __builtin_prefetch(ahead + 8); __builtin_prefetch(ahead + 31);
+      }
       const swa_entry & e = entry_at(recs[k].entry);
       db->ent[k] = &e;
       db->seqlen[k] = e.seqlen;

@@ -109,6 +109,45 @@ def test_hostdb_db_order_of_a_large_file_sorted_on_several_threads(tmp_path):
     assert np.array_equal(hdb.seqs[hdb.seq_off[:2000].astype(np.int64)], first_word)
 
 
+@pytest.mark.parametrize("style,radix", [("mostly_distinct_prefixes", True), ("short_names", True), ("wide_abundances", True),
+                                         ("shared_prefixes", False), ("one_saturated_abundance", False)])
+def test_hostdb_db_order_by_radix_and_by_comparisons(tmp_path, monkeypatch, capfd, style, radix):
+    """The db-order sort of a large file takes the records' integer key — abundance, first 8 identifier bytes — through a
+    radix sort (fasta_db.cpp: parallel_radix_sort) and settles runs of equal keys by strcmp; identifiers that mostly share
+    their first 8 bytes and abundances of 2^32 - 1 or more take the comparison sort.  Either way: abundance descending,
+    then header bytes ascending (src/db.cc:388-413)."""
+    rng = np.random.default_rng(23)
+    n = 140_000
+    ids = rng.permutation(n)
+    abund = np.maximum(1, (1.0 / rng.random(n) ** 1.5).astype(np.int64) % 300)
+    if style == "mostly_distinct_prefixes":       # every fifth identifier shares its first 8 bytes with up to nine others
+        names = [f"q{int(x):08d}" if i % 5 == 0 else f"s{int(x)}" for i, x in enumerate(ids)]
+    elif style == "short_names":                  # shorter than 8 bytes, some a prefix of others ("a1" < "a10" < "a2")
+        names = [f"a{int(x)}" for x in ids]
+    elif style == "wide_abundances":              # every byte of the 32-bit abundance in use, none saturated
+        names = [f"s{int(x)}" for x in ids]
+        abund = (2.0 ** (rng.random(n) * 31.9)).astype(np.int64) + 1
+        abund[:3] = [2 ** 32 - 2, 2 ** 32 - 2, 2 ** 31]
+    elif style == "shared_prefixes":              # the first 8 bytes say nothing
+        names = [f"amplicon{int(x):07d}" for x in ids]
+    else:
+        names = [f"s{int(x)}" for x in ids]
+        abund[77] = 2 ** 32 - 1
+    seq = ["".join("ACGT"[c] for c in rng.integers(0, 4, 60)) for _ in range(97)]
+    fa = tmp_path / "large.fa"
+    fa.write_text("".join(f">{names[i]}_{int(abund[i])}\n{seq[i % 97]}{'ACGT'[i % 4] * (i % 7)}\n" for i in range(n)))
+    assert fa.stat().st_size > 8 << 20
+    monkeypatch.setenv("SWARM_AMD_DB_TIMING", "1")
+    capfd.readouterr()
+    hdb = HostDb(fa)
+    err = capfd.readouterr().err
+    assert ("sorted by radix" in err) == radix, err
+    want = sorted(range(n), key=lambda i: (-int(abund[i]), f"{names[i]}_{int(abund[i])}".encode()))
+    assert [hdb.header(k) for k in range(n)] == [f"{names[i]}_{int(abund[i])}".encode() for i in want]
+    assert np.array_equal(hdb.abundance, np.array([int(abund[i]) for i in want], dtype=np.uint64))
+    assert np.array_equal(hdb.seqlen, np.array([60 + i % 7 for i in want], dtype=np.uint32))
+
+
 def test_repeated_identifiers_in_a_large_file_are_reported_like_the_sequential_scan(tmp_path):
     """The identifier check partitions the identifiers' hashes into buckets and looks at each bucket on its own
     (fasta_db.cpp: earliest_repetition), on several threads: of several repeated identifiers — with different abundance
@@ -181,7 +220,7 @@ def test_unordered_view_and_the_staging_notice_describe_the_same_database(tmp_pa
 
 def test_the_avx2_packer_and_the_byte_loop_pack_the_same_words(tmp_path):
     """fasta_db.cpp packs 32 nucleotides a turn with AVX2 where the CPU has it (pack32_avx2) and falls back to 8 / 1 a turn
-    at line ends, odd characters and on other CPUs: the same file read with SWARM_AMD_NO_AVX2=1 in a process of its own
+    at odd characters and on other CPUs (a line's last nucleotides: pack_tail_avx2, one masked turn): the same file read with SWARM_AMD_NO_AVX2=1 in a process of its own
     (the switch is read once per process) must give the same database, word for word."""
     import hashlib
     import subprocess
@@ -193,9 +232,10 @@ def test_the_avx2_packer_and_the_byte_loop_pack_the_same_words(tmp_path):
         seq = "".join(rng.choice(list("ACGTUacgtu"), size=L))
         lines.append(f">q{i}_{1 + int(rng.integers(0, 9))}\n")
         width = int(rng.choice([31, 32, 33, 63, 64, 65, 100, 1000]))
-        lines.extend(seq[at:at + width] + "\n" for at in range(0, L, width))
+        nl = "\r\n" if i % 10 == 3 else "\n"                 # (a carriage return ends the 32-at-a-time turns: byte loop)
+        lines.extend(seq[at:at + width] + nl for at in range(0, L, width))
     fa = tmp_path / "packers.fa"
-    fa.write_text("".join(lines))
+    fa.write_bytes("".join(lines).encode()[:-1])             # (the last line ends with the file: no 32 bytes to load there)
 
     def digest_here():
         hdb = HostDb(fa)
