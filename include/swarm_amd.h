@@ -82,6 +82,9 @@ int  swa_ctx_synchronize(swa_ctx * ctx);
 /* Optional: pays the device's first-use costs (memory pools, copy queues, code-object loads) now — e.g. on a helper
    thread while the caller reads its input. */
 int  swa_ctx_warmup(swa_ctx * ctx);
+/* The same for a caller that knows its d: 1 loads the d = 1 step's and the clustering's code objects, >= 2 those of the q-gram,
+   pair-graph and alignment kernels (and the clustering's), anything else all of them. */
+int  swa_ctx_warmup_for(swa_ctx * ctx, int differences);
 
 /* Per-kernel timing with HIP events on the context's stream (off by default).
    swa_timing_read: ms[0] seqhash, [1] table+Bloom build, [2] duplicate check,

@@ -71,7 +71,7 @@ class DbUnorderedView(C.Structure):
 
 
 EXPORTS = [
-    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_d1_anchor_windows", "swa_d1_anchor_width",
+    "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_ctx_warmup_for", "swa_d1_anchor_windows", "swa_d1_anchor_width",
     "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident",
     "swa_db_upload", "swa_db_attach", "swa_db_stage_words", "swa_db_upload_unordered", "swa_hostdb_unordered_view", "swa_hostdb_read_fasta_staged", "swa_cli_main", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
@@ -360,11 +360,12 @@ class Context:
             raise SwaError(rc, self.lib.swa_last_error(self.h).decode())
         return rc
 
-    def warmup(self) -> None:
-        """First-use costs of the device (code objects of every kernel file, copy queues) now, not inside the first call that
-        needs them: what the command line does on a helper thread beside the FASTA read (swa_ctx_warmup)."""
-        self.lib.swa_ctx_warmup.argtypes = [C.c_void_p]
-        self._check(self.lib.swa_ctx_warmup(self.h))
+    def warmup(self, differences: int | None = None) -> None:
+        """First-use costs of the device (code objects of the kernel files, copy queues) now, not inside the first call that
+        needs them: what the command line does on a helper thread beside the FASTA read (swa_ctx_warmup; with `differences`
+        only the kernel files a run at that d launches: swa_ctx_warmup_for)."""
+        self.lib.swa_ctx_warmup_for.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.swa_ctx_warmup_for(self.h, -1 if differences is None else int(differences)))
 
     def synchronize(self) -> None:
         self._check(self.lib.swa_ctx_synchronize(self.h))

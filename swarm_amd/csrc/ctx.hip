@@ -3,6 +3,9 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
+#include <cstdio>
+
 int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e) {
   if (ctx != nullptr) {
     ctx->err = std::string(what) + ": " + hipGetErrorString(e);
@@ -23,7 +26,12 @@ int swa_reserve(swa_ctx * ctx, swa_dbuf & buf, size_t bytes) {
     buf.bytes = 0;
   }
   if (bytes == 0) { bytes = 16; }
+  static const bool timing = getenv("SWARM_AMD_ALLOC_TIMING") != nullptr;      // (development aid: what every allocation costs)
+  const auto t0 = std::chrono::steady_clock::now();
   const hipError_t e = hipMalloc(&buf.ptr, bytes);
+  if (timing) {
+    fprintf(stderr, "[alloc] %12zu bytes  %8.1f us\n", bytes, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
   if (e != hipSuccess) {
     buf.ptr = nullptr;
     return swa_fail(ctx, SWA_E_NOMEM, "hipMalloc", e);
@@ -103,7 +111,10 @@ void swa_warm_qgram(swa_ctx * ctx);       // qgram.hip
 void swa_warm_scan(swa_ctx * ctx);        // scan.hip
 __global__ void k_warm(uint32_t * p) { if (threadIdx.x == 0u && p != nullptr) { p[0] = 1u; } }
 
-extern "C" int swa_ctx_warmup(swa_ctx * ctx) {
+// differences: the d the caller is going to cluster with — 1: the d = 1 step and the clustering on the device; >= 2: the
+// q-gram / pair-graph / alignment kernels and the clustering; anything else (swa_ctx_warmup): all of them.  A code object
+// costs 3-5 ms to load: a `swarm -d 1` run does not wait for the four it never launches.
+extern "C" int swa_ctx_warmup_for(swa_ctx * ctx, int differences) {
   if (ctx == nullptr) { return SWA_E_ARG; }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   void * d = nullptr;
@@ -111,14 +122,17 @@ extern "C" int swa_ctx_warmup(swa_ctx * ctx) {
   SWA_HIP(ctx, hipMalloc(&d, 64u << 20));
   SWA_HIP(ctx, hipMemcpyAsync(d, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, ctx->stream, static_cast<uint32_t *>(d));
-  swa_warm_d1(ctx);
+  const bool all = differences < 1;
+  if (all || differences == 1) { swa_warm_d1(ctx); }
   swa_warm_cluster(ctx);
-  swa_warm_dn(ctx); swa_warm_align(ctx); swa_warm_qgram(ctx); swa_warm_scan(ctx);
+  if (all || differences >= 2) { swa_warm_dn(ctx); swa_warm_align(ctx); swa_warm_qgram(ctx); swa_warm_scan(ctx); }
   SWA_HIP(ctx, hipMemcpyAsync(host.data(), d, 4096, hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SWA_HIP(ctx, hipFree(d));
   return SWA_OK;
 }
+
+extern "C" int swa_ctx_warmup(swa_ctx * ctx) { return swa_ctx_warmup_for(ctx, -1); }
 
 extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
   if (ctx == nullptr) { return; }

@@ -294,11 +294,13 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
   const char * dev_env = std::getenv("SWARM_AMD_DEVICE");
   const int device = !devices.empty() ? devices[0] : (dev_env != nullptr ? std::atoi(dev_env) : 0);
   auto start_helper = [&]() {
-    early = std::thread([&early_ctx, &early_rc, &words_ready, device]() {
+    const int warm_for = (int)o.differences;
+    early = std::thread([&early_ctx, &early_rc, &words_ready, device, warm_for]() {
       early_rc = swa_ctx_create(device, nullptr, &early_ctx);
       stamp("(helper thread) context created");
-      // (the anomaly hunt, tools/stress/cold_runs.sh: no warm-up = every code object loaded by the step's own first launch)
-      if (early_rc == SWA_OK && std::getenv("SWARM_AMD_NO_WARMUP") == nullptr) { (void)swa_ctx_warmup(early_ctx); }
+      // (the anomaly hunt, tools/stress/cold_runs.sh: no warm-up = every code object loaded by the step's own first launch;
+      // loading them on a thread of their own beside the copy below was tried: no gain — lease r5w)
+      if (early_rc == SWA_OK && std::getenv("SWARM_AMD_NO_WARMUP") == nullptr) { (void)swa_ctx_warmup_for(early_ctx, warm_for); }
       stamp("(helper thread) code objects loaded, first copies done");
       const Words w = words_ready.get();
       if (early_rc == SWA_OK && !w.pools.empty()) {
