@@ -83,7 +83,7 @@ extern "C" int swa_d0_write_swarms(const swa_d0_result * r, const swa_hostdb * d
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   if (mothur) { o.str("swarm_"); o.u64((uint64_t)differences); o.put('\t'); o.u64(r->clusters.size()); }
-  swa_format_in_pieces(o, r->clusters.size(), r->members.size() >= kParallelOutputFrom, [&](BufOut & sink, size_t begin, size_t end) {
+  swa_format_in_weighted_pieces(o, r->clusters.size(), r->members.size() >= kParallelOutputFrom, [&](size_t ci) -> uint64_t { return 1u + r->clusters[ci].size; }, [&](BufOut & sink, size_t begin, size_t end) {
     for (size_t ci = begin; ci < end; ++ci) {
       const auto & c = r->clusters[ci];
       for (uint32_t k = 0; k < c.size; ++k) {

@@ -410,7 +410,7 @@ extern "C" int swa_dn_write_uclust(const swa_dn_result * r, const swa_hostdb * d
   if (!o.ok()) { return SWA_E_ARG; }
   // one alignment per member — the most expensive writer by far (the reference's is serial, too),
   // and every swarm is independent: formatted by several threads, written in order
-  swa_format_in_pieces(o, r->swarms.size(), r->order.size() >= 200, [&](BufOut & sink, size_t begin, size_t end) {
+  swa_format_in_weighted_pieces(o, r->swarms.size(), r->order.size() >= 200, [&](size_t k) -> uint64_t { return 1u + (r->swarms[k].end - r->swarms[k].begin); }, [&](BufOut & sink, size_t begin, size_t end) {
     swa_nw_scratch scratch;
     for (size_t cluster_no = begin; cluster_no < end; ++cluster_no) {
       const auto & s = r->swarms[cluster_no];

@@ -78,11 +78,10 @@ class BufOut {
 // sizes; an alignment per member for -u).
 inline int swa_host_team() { return std::max(1, std::min<int>(omp_get_max_threads(), (int)std::min(swa_host_cpus(), 32u))); }
 
+// pieces [bounds[p], bounds[p + 1]) of the items, formatted by the team, written in order by the calling thread
 template <class F>
-void swa_format_in_pieces(BufOut & o, size_t items, bool parallel, F && format) {
-  const int threads = swa_host_team();
-  if (!parallel || threads < 3 || items < 2) { format(o, (size_t)0, items); return; }
-  const size_t npieces = std::min<size_t>(items, (size_t)threads * 8);
+void swa_run_pieces(BufOut & o, const std::vector<size_t> & bounds, int threads, F && format) {
+  const size_t npieces = bounds.size() - 1;
   std::vector<std::string> pieces(npieces);
   std::vector<std::atomic<int>> ready(npieces);
   for (auto & r : ready) { r.store(0, std::memory_order_relaxed); }
@@ -100,12 +99,58 @@ void swa_format_in_pieces(BufOut & o, size_t items, bool parallel, F && format) 
         const size_t p = next.fetch_add(1, std::memory_order_relaxed);
         if (p >= npieces) { break; }
         BufOut sink;
-        format(sink, items * p / npieces, items * (p + 1) / npieces);
+        format(sink, bounds[p], bounds[p + 1]);
         pieces[p] = sink.take();
         ready[p].store(1, std::memory_order_release);
       }
     }
   }
+}
+
+template <class F>
+void swa_format_in_pieces(BufOut & o, size_t items, bool parallel, F && format) {
+  const int threads = swa_host_team();
+  if (!parallel || threads < 3 || items < 2) { format(o, (size_t)0, items); return; }
+  const size_t npieces = std::min<size_t>(items, (size_t)threads * 8);
+  std::vector<size_t> bounds(npieces + 1);
+  for (size_t p = 0; p <= npieces; ++p) { bounds[p] = items * p / npieces; }
+  swa_run_pieces(o, bounds, threads, format);
+}
+
+// The same with pieces of equal WEIGHT — weight(k) = what item k costs to format, e.g. the members a swarm prints.  Swarms
+// come largest first: pieces of equal item counts put a tenth of a plain run's members — and, with --fastidious, where the
+// heavy swarms in front print the millions of light ones grafted onto them, most of the file — into the first piece, which
+// one thread then formats while the writer and the other threads wait for it.
+template <class W, class F>
+void swa_format_in_weighted_pieces(BufOut & o, size_t items, bool parallel, W && weight, F && format) {
+  const int threads = swa_host_team();
+  if (!parallel || threads < 3 || items < 2) { format(o, (size_t)0, items); return; }
+  const size_t npieces = std::min<size_t>(items, (size_t)threads * 8);
+  // sums over chunks of the items by all threads, then every boundary by a search over the chunks and a walk inside one
+  const size_t nchunks = std::min<size_t>(items, 4096);
+  std::vector<uint64_t> upto(nchunks + 1, 0);
+#pragma omp parallel for schedule(static) num_threads(threads)
+  for (int64_t c = 0; c < (int64_t)nchunks; ++c) {
+    uint64_t sum = 0;
+    for (size_t k = items * (size_t)c / nchunks; k < items * ((size_t)c + 1) / nchunks; ++k) { sum += weight(k); }
+    upto[(size_t)c + 1] = sum;
+  }
+  for (size_t c = 0; c < nchunks; ++c) { upto[c + 1] += upto[c]; }
+  const uint64_t total = upto[nchunks];
+  std::vector<size_t> bounds(npieces + 1, items);
+  bounds[0] = 0;
+  for (size_t p = 1; p < npieces; ++p) {
+    if (total == 0) { bounds[p] = items * p / npieces; continue; }
+    const uint64_t target = total / npieces * p + total % npieces * p / npieces;      // total * p / npieces without the overflow
+    const size_t c = (size_t)(std::upper_bound(upto.begin(), upto.end(), target) - upto.begin()) - 1;   // upto[c] <= target < upto[c + 1]
+    if (c >= nchunks) { bounds[p] = items; continue; }
+    uint64_t acc = upto[c];
+    size_t k = items * c / nchunks;
+    const size_t chunk_end = items * (c + 1) / nchunks;
+    while (k < chunk_end && acc + weight(k) <= target) { acc += weight(k); ++k; }
+    bounds[p] = std::max(k, bounds[p - 1]);
+  }
+  swa_run_pieces(o, bounds, threads, format);
 }
 
 namespace swa_out {

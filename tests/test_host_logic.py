@@ -398,7 +398,18 @@ def test_parallel_writers_equal_serial(tmp_path):
         "first = np.arange(n, dtype=np.uint32); first -= (first % np.uint32(4)) * (rng.random(n) < 0.5)\n"
         "first = first[first]            # idempotent: every non-seed points at a seed\n"
         "d0 = D0Clusters(hdb, first)\n"
-        "d0.write_swarms(sys.argv[1] + '.d0o'); d0.write_seeds(sys.argv[1] + '.d0w')\n")
+        "d0.write_swarms(sys.argv[1] + '.d0o'); d0.write_seeds(sys.argv[1] + '.d0w')\n"
+        "# --fastidious: light swarms grafted onto heavy ones print with them and nothing in their own place (the pieces are cut\n"
+        "# by what the swarms PRINT: swa_format_in_weighted_pieces) — synthetic candidates: every other light amplicon -> a heavy one\n"
+        "flags, stats = cl.light_flags(40)\n"
+        "heavy = np.flatnonzero(flags == 0).astype(np.uint32); light = np.flatnonzero(flags == 1)\n"
+        "assert len(heavy) > 1000 and len(light) > 1000, (len(heavy), len(light))\n"
+        "graft = np.full(n, 0xFFFFFFFF, dtype=np.uint32)\n"
+        "pick = light[rng.random(len(light)) < 0.5]\n"
+        "graft[pick] = heavy[rng.integers(0, len(heavy), len(pick))]\n"
+        "assert len(pick) > 60000, len(pick)      # (from 50 000 pairs on the attach loop runs on all threads: graft_sorted_pairs_in_parallel)\n"
+        "assert cl.graft(graft) > 100\n"
+        "cl.write_swarms(sys.argv[1] + '.go'); cl.write_structure(sys.argv[1] + '.gi'); cl.write_stats(sys.argv[1] + '.gs')\n")
     outs = []
     for threads in ("1", "4"):
         out = tmp_path / f"o{threads}"
@@ -408,8 +419,8 @@ def test_parallel_writers_equal_serial(tmp_path):
         outs.append(out)
     assert outs[0].stat().st_size > 2_000_000
     assert filecmp.cmp(outs[0], outs[1], shallow=False)
-    for ext in (".r", ".i", ".w", ".u", ".d0o", ".d0w"):
-        assert os.path.getsize(str(outs[0]) + ext) > 1_000_000, ext
+    for ext in (".r", ".i", ".w", ".u", ".d0o", ".d0w", ".go", ".gi", ".gs"):
+        assert os.path.getsize(str(outs[0]) + ext) > (100_000 if ext == ".gs" else 1_000_000), ext
         assert filecmp.cmp(str(outs[0]) + ext, str(outs[1]) + ext, shallow=False), ext
 
 
