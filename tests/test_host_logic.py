@@ -109,19 +109,23 @@ def test_hostdb_db_order_of_a_large_file_sorted_on_several_threads(tmp_path):
     assert np.array_equal(hdb.seqs[hdb.seq_off[:2000].astype(np.int64)], first_word)
 
 
-@pytest.mark.parametrize("style,radix", [("mostly_distinct_prefixes", True), ("short_names", True), ("wide_abundances", True),
-                                         ("shared_prefixes", False), ("one_saturated_abundance", False)])
+@pytest.mark.parametrize("style,radix", [("mostly_distinct_prefixes", True), ("ties_beyond_16_bytes", True), ("short_names", True), ("wide_abundances", True),
+                                         ("shared_prefixes", False), ("saturated_abundances", True)])
 def test_hostdb_db_order_by_radix_and_by_comparisons(tmp_path, monkeypatch, capfd, style, radix):
     """The db-order sort of a large file takes the records' integer key — abundance, first 8 identifier bytes — through a
-    radix sort (fasta_db.cpp: parallel_radix_sort) and settles runs of equal keys by strcmp; identifiers that mostly share
-    their first 8 bytes and abundances of 2^32 - 1 or more take the comparison sort.  Either way: abundance descending,
-    then header bytes ascending (src/db.cc:388-413)."""
+    radix sort (fasta_db.cpp: parallel_radix_sort) and settles runs of equal keys by the next 8 identifier bytes, then by
+    strcmp; identifiers that mostly share their first 8 bytes take the comparison sort; records whose abundance saturates the
+    key's 32 bits (2^32 - 1 and more) are put in front and ordered among themselves through their entries.  Either way:
+    abundance descending, then header bytes ascending (src/db.cc:388-413)."""
     rng = np.random.default_rng(23)
     n = 140_000
     ids = rng.permutation(n)
     abund = np.maximum(1, (1.0 / rng.random(n) ** 1.5).astype(np.int64) % 300)
     if style == "mostly_distinct_prefixes":       # every fifth identifier shares its first 8 bytes with up to nine others
-        names = [f"q{int(x):08d}" if i % 5 == 0 else f"s{int(x)}" for i, x in enumerate(ids)]
+        names = [f"q{i // 5:08d}" if i % 5 == 0 else f"s{int(x)}" for i, x in enumerate(ids)]      # (q0000123 0 .. 9: runs of ten)
+    elif style == "ties_beyond_16_bytes":         # ... in runs of seven whose members agree in their first 16 bytes (and some end there)
+        names = [(f"r{i // 35:07d}________{i // 5 % 7}" if i // 5 % 7 else f"r{i // 35:07d}________") if i % 5 == 0 else f"s{int(x)}"
+                 for i, x in enumerate(ids)]
     elif style == "short_names":                  # shorter than 8 bytes, some a prefix of others ("a1" < "a10" < "a2")
         names = [f"a{int(x)}" for x in ids]
     elif style == "wide_abundances":              # every byte of the 32-bit abundance in use, none saturated
@@ -130,9 +134,9 @@ def test_hostdb_db_order_by_radix_and_by_comparisons(tmp_path, monkeypatch, capf
         abund[:3] = [2 ** 32 - 2, 2 ** 32 - 2, 2 ** 31]
     elif style == "shared_prefixes":              # the first 8 bytes say nothing
         names = [f"amplicon{int(x):07d}" for x in ids]
-    else:
+    else:                                         # 2^32 - 1 and more: in front, ordered among themselves through their entries
         names = [f"s{int(x)}" for x in ids]
-        abund[77] = 2 ** 32 - 1
+        abund[[77, 5, 139_000, 60_001, 99_999, 3, 4]] = [2 ** 32 - 1, 2 ** 32, 2 ** 40, 2 ** 32 + 5, 2 ** 32 + 5, 2 ** 32 - 1, 2 ** 32 - 2]
     seq = ["".join("ACGT"[c] for c in rng.integers(0, 4, 60)) for _ in range(97)]
     fa = tmp_path / "large.fa"
     fa.write_text("".join(f">{names[i]}_{int(abund[i])}\n{seq[i % 97]}{'ACGT'[i % 4] * (i % 7)}\n" for i in range(n)))
