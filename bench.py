@@ -176,9 +176,8 @@ def cpu_baseline(fasta: Path, n: int, length: int, seed: int) -> dict:
                     best = (threads, dt)
             threads, dt = best
             return {"output_md5": md5_of(f"{tmp}/ref.o"), "value": sample_n / dt, "unit": "amplicons/s", "cores": threads, "kind": "reference",
-                    "sample": f"unmodified reference swarm 3.1.6 (oracle/_ref/swarm) -d 1, whole run (FASTA read + "
-                              f"network + clustering + output) on {sample_n} x {length} bp synthetic amplicons, best "
-                              f"of [{'; '.join(tried)}] on a {cores}-core host"}
+                    "seconds": round(dt, 2), "tried": "; ".join(tried), "host_cores": cores,
+                    "sample": f"reference swarm 3.1.6 -d 1 -t {threads}, whole run (FASTA to -o) on {sample_n} x {length} bp, best of -t 8/16/32"}
         # port: the single-threaded C oracle's network construction (test infrastructure, timed only)
         sys.path.insert(0, str(ROOT / "tests"))
         import support as S
@@ -627,6 +626,104 @@ def cpp_multi_check(fasta: Path, world: int) -> dict:
     return res
 
 
+LINE_LIMIT = 8192          # the driver's record keeps a line it can parse: r04's 17.7 KB did, r05's 21.7 KB did not — stay well below
+
+
+def _short(text, limit: int = 120):
+    return text if not isinstance(text, str) or len(text) <= limit else text[:limit - 3] + "..."
+
+
+def _pick(src, keys, limit: int = 120) -> dict:
+    return {k: _short(src[k], limit) for k in keys if isinstance(src, dict) and k in src and not isinstance(src[k], (dict, list))}
+
+
+def _num(x, digits: int = 6):
+    """Numbers of the side objects to a few significant digits (the headline's own keys stay exact)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _num(v, digits) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+def compact_line(out: dict, detail_path: str | None = None) -> dict:
+    """The ONE line the driver parses: the contract's headline keys exactly as measured, `config` =
+    what names the workload, `roofline` = the dominant kernel's object + its HBM view + the step, `cpu_baseline`, and the
+    other configs / the whole run as a few scalars each.  Everything else the run measured (ceilings, per-kernel traffic,
+    the eight extra d=1 sets, phase tables) is `out` itself, written to the side file named under `detail`."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in head if k in out}
+    cfg = out.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "per_gpu_queries", "db_amplicons", "step", "route", "sharding", "build", "neighbour_links",
+                                 "exchange", "owned_links_rank0"), 125)
+    r = out.get("roofline", {})
+    roof = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "algorithmic_bytes_per_launch",
+                     "dominant_group", "peak_measured", "frac_of_measured_ceiling", "step_traffic_over_minimum"), 100)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):           # (the contract's keys are always there)
+        roof.setdefault(k, r.get(k))
+    if isinstance(r.get("hbm"), dict):
+        roof["hbm"] = _num(_pick(r["hbm"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes")))
+    if isinstance(r.get("step"), dict):
+        roof["step"] = _num(_pick(r["step"], ("ms", "algorithmic_bytes", "hbm_bytes_measured", "minimum_bytes", "frac_of_hbm_peak")))
+    if isinstance(r.get("pair_kernels"), dict):
+        roof["pair_kernels"] = _num(_pick(r["pair_kernels"], ("bound", "achieved", "peak", "unit", "frac", "ms", "hbm_bytes_measured", "frac_of_measured_ceiling")))
+    if isinstance(r.get("kernels"), dict):                                        # per kernel group: ms only (the rest is in the side file)
+        roof["kernel_ms"] = {g: _num(v.get("ms"), 4) for g, v in r["kernels"].items() if isinstance(v, dict)}
+    line["roofline"] = roof
+    for k in ("cpu_baseline", "cpu_baseline_10M"):
+        if isinstance(out.get(k), dict):
+            line[k] = _num(_pick(out[k], ("value", "unit", "cores", "kind", "seconds", "sample"), 125))
+    wr = out.get("whole_run")
+    if isinstance(wr, dict):
+        w = {}
+        for size, rec in wr.items():
+            if isinstance(rec, dict):
+                w[size] = _num(_pick(rec, ("seconds", "median_s", "p95_s", "max_s", "runs", "amplicons_per_s", "output_md5_equals_reference", "error")))
+        w["what"] = "swarm_amd/bin/swarm -d 1 -o, one process from start to exit, FASTA in, swarms file out"
+        line["whole_run"] = w
+    if isinstance(out.get("first_step_ms"), dict):
+        line["first_step_ms"] = _num(_pick(out["first_step_ms"], ("first_step_ms", "repeated_step_ms", "error")))
+    if isinstance(out.get("host_seam_ms"), dict):
+        line["host_seam_ms"] = _num(_pick(out["host_seam_ms"], ("upload_ms", "index_build_ms", "network_incl_download_ms", "total_ms", "amplicons_per_s", "error")))
+    c1 = cfg.get("configs1")
+    if isinstance(c1, dict):
+        line["configs1"] = _num(_pick(c1, ("workload", "value", "unit", "ms_per_step", "neighbour_links", "error")))
+    for k in ("configs2", "configs3"):
+        c = out.get(k) if isinstance(out.get(k), dict) else cfg.get(k)
+        if isinstance(c, dict):
+            rec = _num(_pick(c, ("workload", "pipeline_total_s", "value", "unit", "counters_equal_reference_log", "qgram_comparisons_per_s",
+                                 "aligned_pairs_per_s", "clustering_seconds", "full_matrix_equivalent_cells_per_s", "banded_cells_per_s", "error"), 100))
+            if isinstance(c.get("cpu_baseline"), dict):
+                rec["cpu_baseline"] = _num(_pick(c["cpu_baseline"], ("value", "unit", "cores", "kind", "seconds", "sample", "error"), 125))
+            line[k] = rec
+    for k in ("simulated", "sharded_csr_equals_whole"):
+        if k in out:
+            line[k] = _short(out[k], 160)
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:           # cannot happen with the keys above; if it ever does, the contract's keys survive
+        for k in ("host_seam_ms", "first_step_ms", "configs1", "whole_run", "configs3", "configs2", "cpu_baseline_10M"):
+            line.pop(k, None)
+            if len(json.dumps(line)) < LINE_LIMIT:
+                break
+    return line
+
+
+def emit(out: dict) -> None:
+    """Side file with everything + the one compact line (the LAST thing on stdout)."""
+    detail = os.environ.get("SWA_BENCH_DETAIL", str(ROOT / "bench_detail.json"))
+    try:
+        Path(detail).write_text(json.dumps(out, indent=1) + "\n")
+        shown = os.path.relpath(detail, ROOT) if detail.startswith(str(ROOT)) else detail
+    except OSError as e:
+        print(f"bench.py: could not write {detail}: {e}", file=sys.stderr)
+        shown = None
+    print(json.dumps(compact_line(out, shown)), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -881,14 +978,13 @@ def main() -> None:
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_total} synthetic amplicons x {args.length} bp, d=1 ({args.per_gpu} per GPU: the size "
-                            "BASELINE.json's metric names; configs[1] under config.configs1)",
+                "workload": f"{n_total} synthetic amplicons x {args.length} bp, d=1 ({args.per_gpu} per GPU; the metric's own size; configs[1]: configs1)",
                 "per_gpu_queries": count,
                 "db_amplicons": n_total,
                 "step": "swa_d1_index_build + swa_d1_network_device (B1 seam), db and CSR resident in HBM"
                         + ("; ownership by anchor group, links exchanged all-to-all by seed range, RCCL all-gather of CSR slices"
-                           if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else "")
-                        + ("; routed index build (swa_d1_route_slice, ids all-to-all, swa_d1_index_build_routed)" if routed else ""),
+                           if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else ""),
+                "build": ("routed index build (swa_d1_route_slice, all-to-all to the owners, swa_d1_index_build_routed)" if routed else "local"),
                 "route": "streaming (d1_stream.inc)" if streaming else "table (round 2)",
                 "sharding": ("owned" if owned else "range") if (sim_world or world) > 1 else "none",
                 "neighbour_links": int(hits_seen[0]),
@@ -1065,7 +1161,7 @@ def main() -> None:
             sample_n = min(n_total, 1_000_000)
             out["cpu_baseline"] = cpu_baseline(gen_fasta(sample_n, args.length, args.seed), sample_n, args.length, args.seed)
             out["cpu_baseline"].pop("output_md5", None)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if not (rank == 0 and world == 1 and not sim_world and not args.no_extras):
         ctx.close()
     if world > 1:

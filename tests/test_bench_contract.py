@@ -44,6 +44,46 @@ def check_roofline(r: dict) -> None:
         assert r["hbm"]["traffic"] > 0 and abs(r["hbm"]["frac"] - r["hbm"]["achieved"] / 8000.0) < 1e-9
 
 
+def check_compact(line: dict) -> None:
+    """The printed line: the contract's roofline keys as scalars (the driver's record keeps scalars and short strings)."""
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "valu")
+    assert (r["unit"], r["peak"]) in (("GB/s", 8000.0), ("wave-instr/s", 256 * 4 * 0.5 * 2.4e9))
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert "traffic" in r and r["avg_kernel_ms"] > 0
+    for k, v in line.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                assert not isinstance(vv, str) or len(vv) <= 128, (k, kk)
+
+
+def test_a_full_shape_line_stays_below_eight_kilobytes():
+    """the line of a FULL default run (every extra, counters, ceilings — round 5's closing line, 21.7 KB as it
+    was printed then) through the trimming the bench now prints with."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = json.loads((ROOT / "profiles" / "r05" / "bench_default_closing.json").read_text())
+    assert len(json.dumps(full)) > 20000
+    # (what this round adds to the full shape: baselines of configs[2] / configs[3], percentiles of the whole run)
+    base = {"value": 1.0e5, "unit": "amplicons/s", "cores": 16, "kind": "reference", "seconds": 12.3, "sample": "x" * 300}
+    full["configs2"]["cpu_baseline"] = dict(base)
+    full["configs3"]["cpu_baseline"] = dict(base)
+    full["whole_run"]["n10000000"].update({"median_s": 0.21, "p95_s": 0.24, "max_s": 0.3, "runs": 40})
+    line = bench.compact_line(full, "bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT == 8192 and len(text) < 6000
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k]
+    check_headline(line, 10_000_000, 10, 2)
+    check_compact(line)
+    assert line["roofline"]["traffic"] == full["roofline"]["traffic"] and line["roofline"]["hbm"]["frac"] > 0
+    assert line["roofline"]["step"]["minimum_bytes"] > 0 and line["roofline"]["step_traffic_over_minimum"] > 1
+    assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["value"] > 0
+    assert line["configs2"]["cpu_baseline"]["kind"] == "reference" and line["configs3"]["qgram_comparisons_per_s"] > 0
+    assert line["whole_run"]["n10000000"]["p95_s"] == 0.24 and line["detail"] == "bench_detail.json"
+    assert set(line["config"]) <= {"workload", "per_gpu_queries", "db_amplicons", "step", "route", "sharding", "build", "neighbour_links"}
+
+
 @pytest.mark.gpu
 def test_the_line_this_build_prints_on_the_gpu():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--per-gpu", "1000000"],
@@ -51,9 +91,13 @@ def test_the_line_this_build_prints_on_the_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly ONE JSON line"
+    assert len(lines[0]) < 8192, "the driver must be able to parse the line (r05's 21.7 KB line left BENCH_r05.parsed null)"
     line = json.loads(lines[0])
     check_headline(line, 1_000_000, 3, 1)
-    check_roofline(line["roofline"])
+    check_compact(line)
+    detail = json.loads((ROOT / line["detail"]).read_text())    # everything the run measured: the side file the line names
+    assert detail["value"] == line["value"] and detail["ms_per_step"] == line["ms_per_step"]
+    check_roofline(detail["roofline"])
     assert "cpu_baseline" not in line                           # (--no-extras: nothing beside the headline)
 
 
