@@ -54,6 +54,14 @@ int  swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, const uint3
 /* The same result from the network that swa_d1_network_resident left in HBM: evaluated on the GPU
    (swa_d1_cluster_device), per-swarm sums on the host.  Needs the context that holds the network. */
 int  swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
+/* The command line's form of the above: swarm / generation / parent and the per-swarm sums stay in HBM until an accessor,
+   swa_d1_light_flags, swa_d1_graft or one of the -i -s -u -w writers asks for them (a plain `-o` run never does).  The
+   caller keeps `ctx` alive, and its clustering untouched, until swa_d1_result_detach returned or the result is freed.
+   swa_d1_result_detach fetches what is still on the device (SWA_E_DEVICE and swa_d1_result_error when that fails);
+   after it the result does not refer to the context any more. */
+int  swa_d1_cluster_resident_lazy(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
+int  swa_d1_result_detach(swa_d1_result * res);
+const char * swa_d1_result_error(const swa_d1_result * res);
 void swa_d1_result_free(swa_d1_result * res);
 /* out4 = {swarms after grafting, largest swarm, max generations, swarms before grafting}
    (the numbers of the log's summary lines, src/algod1.cc:1484-1487) */
@@ -63,7 +71,7 @@ const uint32_t * swa_d1_result_parent(const swa_d1_result * res);      /* [n], S
 const uint32_t * swa_d1_result_generation(const swa_d1_result * res);  /* [n] */
 /* is_light[n] <- swarm mass < boundary; stats5 = {light swarms, amplicons in light swarms,
    nt in light swarms, heavy swarms, amplicons in heavy swarms} (src/algod1.cc:1291-1328) */
-void swa_d1_light_flags(const swa_d1_result * res, int64_t boundary, uint8_t * is_light, uint64_t * stats5);
+int  swa_d1_light_flags(const swa_d1_result * res, int64_t boundary, uint8_t * is_light, uint64_t * stats5);
 /* attach_candidates (src/algod1.cc:274-336): graft_cand[n] as returned by swa_d1_fastidious;
    returns the number of grafts made */
 uint32_t swa_d1_graft(swa_d1_result * res, const uint32_t * graft_cand);

@@ -34,8 +34,8 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
-# (the OpenMP teams of the host phases, like the command line sets them: host/main.cpp)
-os.environ.setdefault("OMP_NUM_THREADS", str(min(32, usable_cpus())))
+# (The library sizes its own OpenMP teams — num_threads(swa_host_team()) on every parallel region, host/out.h — so this
+# module does not touch OMP_NUM_THREADS: other OpenMP users of the importing process keep their own setting.)
 import subprocess
 from pathlib import Path
 
@@ -72,7 +72,7 @@ class DbUnorderedView(C.Structure):
 
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_ctx_warmup_for", "swa_d1_anchor_windows", "swa_d1_anchor_width",
-    "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident",
+    "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident", "swa_d1_cluster_resident_lazy", "swa_d1_result_detach", "swa_d1_result_error",
     "swa_db_upload", "swa_db_attach", "swa_db_stage_words", "swa_db_upload_unordered", "swa_hostdb_unordered_view", "swa_hostdb_read_fasta_staged", "swa_cli_main", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
@@ -154,7 +154,11 @@ def load_library() -> C.CDLL:
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_void_p
     lib.swa_d1_light_flags.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, u64p]
-    lib.swa_d1_light_flags.restype = None
+    lib.swa_d1_light_flags.restype = C.c_int
+    lib.swa_d1_result_detach.argtypes = [C.c_void_p]
+    lib.swa_d1_result_detach.restype = C.c_int
+    lib.swa_d1_result_error.argtypes = [C.c_void_p]
+    lib.swa_d1_result_error.restype = C.c_char_p
     lib.swa_d1_graft.argtypes = [C.c_void_p, C.c_void_p]
     lib.swa_d1_graft.restype = C.c_uint32
     lib.swa_d1_write_swarms.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_int64]
@@ -256,20 +260,30 @@ class D1Clusters:
         self.h = h
 
     @classmethod
-    def from_resident(cls, ctx: "Context", hdb: HostDb) -> "D1Clusters":
+    def from_resident(cls, ctx: "Context", hdb: HostDb, lazy: bool = False) -> "D1Clusters":
         """The same result from the network ctx.d1_network_resident() left in HBM: agglomeration on the GPU
-        (swa_d1_cluster_device), per-swarm sums on the host."""
+        (swa_d1_cluster_device), per-swarm sums on the host.  lazy = the command line's form (swa_d1_cluster_resident_lazy):
+        swarm / generation / parent stay in HBM until asked for; the result then keeps the context alive."""
         self = cls.__new__(cls)
         self.lib = load_library()
         self.hdb = hdb
         self._keep = None
-        self.lib.swa_d1_cluster_resident.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        self._ctx = ctx if lazy else None
+        fn = self.lib.swa_d1_cluster_resident_lazy if lazy else self.lib.swa_d1_cluster_resident
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         h = C.c_void_p()
-        rc = self.lib.swa_d1_cluster_resident(ctx.h, hdb.h, C.byref(h))
+        rc = fn(ctx.h, hdb.h, C.byref(h))
         self.h = h
         if rc != SWA_OK:
-            raise SwaError(rc, "swa_d1_cluster_resident failed: " + ctx.lib.swa_last_error(ctx.h).decode())
+            raise SwaError(rc, "swa_d1_cluster_resident failed: " + (self.lib.swa_d1_result_error(h) or ctx.lib.swa_last_error(ctx.h)).decode())
         return self
+
+    def detach(self) -> None:
+        """Fetch whatever a lazy result still has on the device; afterwards it does not need its context."""
+        rc = self.lib.swa_d1_result_detach(self.h)
+        if rc != SWA_OK:
+            raise SwaError(rc, "swa_d1_result_detach failed: " + self.lib.swa_d1_result_error(self.h).decode())
+        self._ctx = None
 
     def summary(self) -> dict:
         out = np.zeros(4, dtype=np.uint64)
@@ -279,6 +293,10 @@ class D1Clusters:
     def _arr(self, fn) -> np.ndarray:
         ptr = fn(self.h)
         n = self.hdb.n
+        if not ptr:
+            if n == 0:
+                return np.zeros(0, dtype=np.uint32)
+            raise SwaError(SWA_E_DEVICE, "the clustering's details could not be fetched: " + self.lib.swa_d1_result_error(self.h).decode())
         buf = (C.c_char * (4 * n)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.uint32, count=n).copy()
 
@@ -294,7 +312,9 @@ class D1Clusters:
     def light_flags(self, boundary: int = 3):
         flags = np.zeros(self.hdb.n, dtype=np.uint8)
         stats = np.zeros(5, dtype=np.uint64)
-        self.lib.swa_d1_light_flags(self.h, boundary, _ptr(flags), _p64(stats))
+        rc = self.lib.swa_d1_light_flags(self.h, boundary, _ptr(flags), _p64(stats))
+        if rc != SWA_OK:
+            raise SwaError(rc, "swa_d1_light_flags failed: " + self.lib.swa_d1_result_error(self.h).decode())
         return flags, [int(x) for x in stats]
 
     def graft(self, graft_cand: np.ndarray) -> int:

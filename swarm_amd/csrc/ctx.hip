@@ -306,10 +306,21 @@ extern "C" int swa_db_upload_unordered(swa_ctx * ctx, const swa_db_unordered_vie
   SWA_TRY(swa_reserve(ctx, ctx->d_seqlen, uint64_t(n) * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_abund, uint64_t(n) * sizeof(uint64_t)));
   // src_off travels through the buffer that will hold the offsets' scan input afterwards
-  swa_dbuf d_src, d_counts;
+  // (While the gather runs the packed words are in HBM twice — the staged pools and d_seqs: 2 x 0.4 GB at 10 M x 150, 2 x 4 GB
+  // at 100 M; on SWA_E_NOMEM a caller can still take swa_hostdb_view + swa_db_upload, which gathers on the host.)  Every way
+  // out of this function releases the temporaries; a failure also gives the staged words back.
+  swa_dbuf d_src, d_counts, d_tmp;
+  bool uploaded = false;
+  struct Cleanup {
+    swa_ctx * ctx; swa_dbuf & a; swa_dbuf & b; swa_dbuf & c; bool & ok;
+    ~Cleanup() {
+      swa_release(a); swa_release(b); swa_release(c);
+      if (!ok) { swa_release(ctx->d_words_stage); ctx->staged_first = nullptr; ctx->staged_words = 0; }
+    }
+  } cleanup{ctx, d_src, d_counts, d_tmp, uploaded};
   SWA_TRY(swa_reserve(ctx, d_src, uint64_t(n) * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, d_counts, (uint64_t(n) + 1) * sizeof(uint64_t)));
-  auto release_tmp = [&]() { swa_release(d_src); swa_release(d_counts); };
+  auto release_tmp = [&]() {};
   auto fail_hip = [&](hipError_t e, const char * what) { release_tmp(); return swa_fail(ctx, SWA_E_DEVICE, what, e); };
   hipError_t e;
   if ((e = hipMemcpyAsync(d_src.ptr, h->src_off, uint64_t(n) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { return fail_hip(e, "hipMemcpyAsync"); }
@@ -321,22 +332,20 @@ extern "C" int swa_db_upload_unordered(swa_ctx * ctx, const swa_db_unordered_vie
   size_t need = 0;
   (void)rocprim::exclusive_scan(nullptr, need, static_cast<uint64_t *>(d_counts.ptr), static_cast<uint64_t *>(ctx->d_seq_off.ptr), 0ull,
                                 (size_t)n + 1, rocprim::plus<uint64_t>(), ctx->stream);
-  swa_dbuf d_tmp;
-  if (swa_reserve(ctx, d_tmp, need + 16) != SWA_OK) { release_tmp(); return SWA_E_NOMEM; }
+  if (swa_reserve(ctx, d_tmp, need + 16) != SWA_OK) { return SWA_E_NOMEM; }
   e = rocprim::exclusive_scan(d_tmp.ptr, need, static_cast<uint64_t *>(d_counts.ptr), static_cast<uint64_t *>(ctx->d_seq_off.ptr), 0ull,
                               (size_t)n + 1, rocprim::plus<uint64_t>(), ctx->stream);
-  if (e != hipSuccess) { swa_release(d_tmp); return fail_hip(e, "rocprim::exclusive_scan"); }
+  if (e != hipSuccess) { return fail_hip(e, "rocprim::exclusive_scan"); }
   hipLaunchKernelGGL(k_db_gather_words, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t *>(ctx->d_words_stage.ptr),
                      static_cast<const uint64_t *>(d_src.ptr), static_cast<const uint64_t *>(ctx->d_seq_off.ptr), n,
                      static_cast<uint64_t *>(ctx->d_seqs.ptr));
   uint64_t placed = 0;                                        // = seq_off[n]: the words the amplicons take, <= the pools' words
-  if ((e = hipMemcpyAsync(&placed, static_cast<uint64_t *>(ctx->d_seq_off.ptr) + n, sizeof(placed), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) { swa_release(d_tmp); return fail_hip(e, "hipMemcpyAsync"); }
-  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { swa_release(d_tmp); return fail_hip(e, "hipStreamSynchronize"); }
-  swa_release(d_tmp);
-  release_tmp();
+  if ((e = hipMemcpyAsync(&placed, static_cast<uint64_t *>(ctx->d_seq_off.ptr) + n, sizeof(placed), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) { return fail_hip(e, "hipMemcpyAsync"); }
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { return fail_hip(e, "hipStreamSynchronize"); }
   if (placed > total) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_db_upload_unordered: the amplicons' words exceed the pools'"); }
   SWA_HIP(ctx, hipMemsetAsync(static_cast<uint64_t *>(ctx->d_seqs.ptr) + placed, 0, 2 * sizeof(uint64_t), ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uploaded = true;
   swa_release(ctx->d_words_stage);
   ctx->staged_first = nullptr;
   ctx->staged_words = 0;

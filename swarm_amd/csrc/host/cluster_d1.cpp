@@ -59,7 +59,7 @@ template <class V, class T>
 void fill_parallel(V & v, size_t n, T value) {
   v.resize(n);
   auto * p = v.data();
-#pragma omp parallel for schedule(static) if (n >= 100000)
+#pragma omp parallel for schedule(static) if (n >= 100000) num_threads(swa_host_team())
   for (int64_t i = 0; i < (int64_t)n; ++i) { p[i] = value; }
 }
 
@@ -106,7 +106,7 @@ bool need_details(const swa_d1_result * cr) {
     return false;
   }
   const auto & gen = r->generation;
-#pragma omp parallel for schedule(dynamic, 1024)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(swa_host_team())
   for (int64_t s = 0; s < (int64_t)r->swarms.size(); ++s) {
     auto & sw = r->swarms[(size_t)s];
     for (uint32_t k = sw.begin; k < sw.end; ++k) {
@@ -120,8 +120,13 @@ bool need_details(const swa_d1_result * cr) {
     }
   }
   r->details = true;
+  r->lazy_ctx = nullptr;                                    // (nothing of the context is needed from here on)
   return true;
 }
+
+// what an entry point returns when the details could not be had: the fetch's own failure (SWA_E_DEVICE, text in
+// swa_d1_result_error) — never SWA_E_ARG, which the command line reports as "Unable to open ... file" 
+int details_failed(const swa_d1_result * r) { return r->error.empty() ? SWA_E_ARG : SWA_E_DEVICE; }
 
 }  // namespace
 
@@ -164,11 +169,11 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   swa_vec<uint8_t> active, next_active;
   fill_parallel(active, n, (uint8_t)1);
   fill_parallel(next_active, n, (uint8_t)0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(swa_host_team())
   for (int64_t v = 0; v < n64; ++v) { label[(size_t)v] = (uint32_t)v; }
   for (bool changed = true; changed;) {
     changed = false;
-#pragma omp parallel for schedule(dynamic, 8192) reduction(|| : changed)
+#pragma omp parallel for schedule(dynamic, 8192) reduction(|| : changed) num_threads(swa_host_team())
     for (int64_t u = 0; u < n64; ++u) {
       if (active[(size_t)u] == 0) { continue; }
       active[(size_t)u] = 0;
@@ -189,18 +194,18 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   //    parent(v): smallest id of the previous level that points at v
   auto & gen = r->generation;
   auto & parent = r->parent;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(swa_host_team())
   for (int64_t v = 0; v < n64; ++v) { gen[(size_t)v] = label[(size_t)v] == (uint32_t)v ? 0u : kUnset; parent[(size_t)v] = kUnset; }
   // Frontier by frontier (not a sweep over all amplicons per level: swarms can be hundreds of generations
   // deep): the nodes of level - 1 are a list; a node is claimed for `level` by exactly one thread (compare and
   // swap on its generation), which appends it to that thread's piece of the next list; parents are the
   // smallest claiming or co-claiming id, by atomic minimum.
   {
-    const int nthreads = std::max(1, omp_get_max_threads());
+    const int nthreads = std::max(1, swa_host_team());
     std::vector<std::vector<uint32_t>> piece((size_t)nthreads);
     std::vector<uint32_t> frontier, next;
     // level 0 = the seeds
-#pragma omp parallel
+#pragma omp parallel num_threads(swa_host_team())
     {
       auto & mine = piece[(size_t)omp_get_thread_num()];
       mine.clear();
@@ -211,13 +216,13 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
       std::vector<size_t> at((size_t)nthreads + 1, 0);
       for (int t = 0; t < nthreads; ++t) { at[(size_t)t + 1] = at[(size_t)t] + piece[(size_t)t].size(); }
       into.resize(at[(size_t)nthreads]);
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swa_host_team())
       for (int t = 0; t < nthreads; ++t) { std::copy(piece[(size_t)t].begin(), piece[(size_t)t].end(), into.begin() + (std::ptrdiff_t)at[(size_t)t]); }
     };
     gather_pieces(frontier);
     for (uint32_t level = 1; !frontier.empty(); ++level) {
       const int64_t fsize = (int64_t)frontier.size();
-#pragma omp parallel
+#pragma omp parallel num_threads(swa_host_team())
       {
         auto & mine = piece[(size_t)omp_get_thread_num()];
         mine.clear();
@@ -244,9 +249,9 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   // 3. swarms in seed order, members by (generation, id)
   // swarm number of every seed = number of seeds before it: per-block counts, prefix, numbering
   swa_vec<uint32_t> sid_of_seed(n);
-  const int blocks = std::max(1, omp_get_max_threads());
+  const int blocks = std::max(1, swa_host_team());
   std::vector<uint32_t> seeds_before((size_t)blocks + 1, 0);
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swa_host_team())
   for (int b = 0; b < blocks; ++b) {
     uint32_t c = 0;
     for (int64_t v = n64 * b / blocks; v < n64 * (b + 1) / blocks; ++v) { c += label[(size_t)v] == (uint32_t)v ? 1u : 0u; }
@@ -254,7 +259,7 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   }
   for (int b = 0; b < blocks; ++b) { seeds_before[(size_t)b + 1] += seeds_before[(size_t)b]; }
   const uint32_t nswarms = seeds_before[(size_t)blocks];
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swa_host_team())
   for (int b = 0; b < blocks; ++b) {
     uint32_t next = seeds_before[(size_t)b];
     for (int64_t v = n64 * b / blocks; v < n64 * (b + 1) / blocks; ++v) {
@@ -263,7 +268,7 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   }
   fill_parallel(r->swarms, nswarms, swa_d1_result::empty_swarm());
   std::vector<uint32_t> size(nswarms, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(swa_host_team())
   for (int64_t v = 0; v < n64; ++v) {
     const uint32_t sid = sid_of_seed[label[(size_t)v]];
     r->swarmid[(size_t)v] = sid;
@@ -278,14 +283,14 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
   }
   lap("swarm table");
   r->order.resize(n);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(swa_host_team())
   for (int64_t v = 0; v < n64; ++v) {
     auto & sw = r->swarms[r->swarmid[(size_t)v]];
     r->order[__atomic_fetch_add(&sw.end, 1u, __ATOMIC_RELAXED)] = (uint32_t)v;
   }
   lap("placement");
   uint32_t largest = 0, maxgen = 0;
-#pragma omp parallel for schedule(dynamic, 1024) reduction(max : largest) reduction(max : maxgen)
+#pragma omp parallel for schedule(dynamic, 1024) reduction(max : largest) reduction(max : maxgen) num_threads(swa_host_team())
   for (int64_t s = 0; s < (int64_t)nswarms; ++s) {
     auto & sw = r->swarms[(size_t)s];
     std::sort(r->order.begin() + sw.begin, r->order.begin() + sw.end, [&](uint32_t x, uint32_t y) {
@@ -313,7 +318,32 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
 // ---- the same result from the network that is still in HBM (cluster_gpu.hip) ------------------
 // swa_d1_network_resident left the CSR on the device; the three order-free statements above are evaluated
 // there and only swarm / generation / parent / member order come back.  The per-swarm sums stay here.
+static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
+
+// The result owns everything it returns: swarm / generation / parent are fetched and the sums made before this returns, and
+// the context may be destroyed or used for the next database afterwards.
 extern "C" int swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out) {
+  const int rc = cluster_resident(ctx, db, out);
+  if (rc != SWA_OK) { return rc; }
+  return swa_d1_result_detach(*out);
+}
+
+// The command line's form: the details stay in HBM until an accessor, the grafting or one of -i -s -u -w asks for them (a
+// plain `swarm -d 1 -o` never does: 160 MB of downloads and a pass over all members less).  The CALLER keeps `ctx` alive and
+// its clustering untouched until swa_d1_result_detach (or the result's release).
+extern "C" int swa_d1_cluster_resident_lazy(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out) {
+  return cluster_resident(ctx, db, out);
+}
+
+extern "C" int swa_d1_result_detach(swa_d1_result * r) {
+  if (r == nullptr) { return SWA_E_ARG; }
+  if (r->n == 0) { r->lazy_ctx = nullptr; return SWA_OK; }
+  return need_details(r) ? SWA_OK : details_failed(r);
+}
+
+extern "C" const char * swa_d1_result_error(const swa_d1_result * r) { return r == nullptr ? "" : r->error.c_str(); }
+
+static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out) {
   if (ctx == nullptr || db == nullptr || out == nullptr) { return SWA_E_ARG; }
   auto * r = new swa_d1_result();
   *out = r;
@@ -340,7 +370,7 @@ extern "C" int swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa
   r->details = false;
   r->swarms.resize(nswarms);
   uint32_t largest = 0;
-#pragma omp parallel for schedule(static) reduction(max : largest)
+#pragma omp parallel for schedule(static) reduction(max : largest) num_threads(swa_host_team())
   for (int64_t s = 0; s < (int64_t)nswarms; ++s) {
     auto & sw = r->swarms[(size_t)s];
     sw = swa_d1_result::empty_swarm();
@@ -375,7 +405,7 @@ extern "C" int swa_d1_cluster(const swa_hostdb * db, const uint64_t * offsets, c
     const char * mode = std::getenv("SWARM_AMD_CLUSTER");
     const bool force_parallel = mode != nullptr && std::strcmp(mode, "parallel") == 0;
     const bool force_serial = mode != nullptr && std::strcmp(mode, "serial") == 0;
-    if (force_parallel || (!force_serial && n >= 500000 && omp_get_max_threads() >= 8)) {
+    if (force_parallel || (!force_serial && n >= 500000 && swa_host_team() >= 8)) {
       cluster_by_fixed_points(db, offsets, neighbours, r);
       r->swarmcount_adjusted = r->swarms.size();
       return SWA_OK;
@@ -469,12 +499,12 @@ extern "C" const uint32_t * swa_d1_result_parent(const swa_d1_result * r) { retu
 extern "C" const uint32_t * swa_d1_result_generation(const swa_d1_result * r) { return need_details(r) ? r->generation.data() : nullptr; }
 
 // ---- fastidious bookkeeping (src/algod1.cc:1291-1328) -----------------------------------
-extern "C" void swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, uint8_t * is_light, uint64_t * stats5) {
-  (void)need_details(r);
+extern "C" int swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, uint8_t * is_light, uint64_t * stats5) {
+  if (!need_details(r) && r->n != 0) { return details_failed(r); }      // (without the masses every swarm would look light)
   uint64_t light_swarms = 0, light_amps = 0, light_nt = 0;
   const int64_t nswarms = (int64_t)r->swarms.size();
   // (every amplicon belongs to one swarm: the flags are independent writes; 3 M swarms at 10 M amplicons with 30 % light ones)
-#pragma omp parallel for schedule(static) reduction(+ : light_swarms, light_amps, light_nt) if (r->n >= kParallelOutputFrom)
+#pragma omp parallel for schedule(static) reduction(+ : light_swarms, light_amps, light_nt) if (r->n >= kParallelOutputFrom) num_threads(swa_host_team())
   for (int64_t i = 0; i < nswarms; ++i) {
     const auto & s = r->swarms[(size_t)i];
     const bool light = s.mass < (uint64_t)boundary;
@@ -486,6 +516,7 @@ extern "C" void swa_d1_light_flags(const swa_d1_result * r, int64_t boundary, ui
   stats5[2] = light_nt;
   stats5[3] = r->swarms.size() - light_swarms;
   stats5[4] = r->n - light_amps;
+  return SWA_OK;
 }
 
 // ---- grafting (src/algod1.cc:214-241 attach, 274-336 attach_candidates) -----------------
@@ -502,7 +533,7 @@ static uint32_t graft_sorted_pairs_in_parallel(swa_d1_result * r, const uint64_t
   swa_vec<uint32_t> first_pair;
   fill_parallel(first_pair, nswarms, 0xFFFFFFFFu);                       // (npairs <= n < 2^32 - 1)
   const int64_t np64 = (int64_t)npairs;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(swa_host_team())
   for (int64_t at = 0; at < np64; ++at) {
     if (at + 16 < np64) { __builtin_prefetch(&r->swarmid[(uint32_t)pairs[at + 16]]); }
     uint32_t * slot = &first_pair[r->swarmid[(uint32_t)pairs[at]]];
@@ -511,7 +542,7 @@ static uint32_t graft_sorted_pairs_in_parallel(swa_d1_result * r, const uint64_t
   }
   // the winners in pair order (a block's share goes behind the shares of the blocks before it); the losers' candidates withdrawn
   std::vector<uint64_t> before((size_t)blocks + 1, 0);
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swa_host_team())
   for (int b = 0; b < blocks; ++b) {
     uint64_t c = 0;
     for (int64_t at = np64 * b / blocks; at < np64 * (b + 1) / blocks; ++at) {
@@ -524,7 +555,7 @@ static uint32_t graft_sorted_pairs_in_parallel(swa_d1_result * r, const uint64_t
   const size_t nwin = before[(size_t)blocks];
   swa_vec<uint64_t> keyed(nwin);                                        // heavy swarm << 32 | rank among the winners
   swa_vec<uint32_t> light_of(nwin);                                     // the light swarm of every winner, by rank
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swa_host_team())
   for (int b = 0; b < blocks; ++b) {
     uint64_t rank = before[(size_t)b];
     for (int64_t at = np64 * b / blocks; at < np64 * (b + 1) / blocks; ++at) {
@@ -540,7 +571,7 @@ static uint32_t graft_sorted_pairs_in_parallel(swa_d1_result * r, const uint64_t
   // every heavy swarm's run: linked in order, summed — runs are found from their first entries, one thread per run
   uint32_t largest = r->largest;
   const int64_t nw64 = (int64_t)nwin;
-#pragma omp parallel for schedule(dynamic, 4096) reduction(max : largest)
+#pragma omp parallel for schedule(dynamic, 4096) reduction(max : largest) num_threads(swa_host_team())
   for (int64_t i = 0; i < nw64; ++i) {
     const uint32_t heavy_id = (uint32_t)(keyed[(size_t)i] >> 32);
     if (i > 0 && (uint32_t)(keyed[(size_t)i - 1] >> 32) == heavy_id) { continue; }      // (not the first of its run)
@@ -569,9 +600,9 @@ extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand)
   // (parent << 32 | child): sorting the packed pairs is the (parent, child) order of
   // src/algod1.cc:263-271, and a plain integer sort runs on all cores
   const int64_t n64 = (int64_t)r->n;
-  const int blocks = std::max(1, omp_get_max_threads());
+  const int blocks = std::max(1, swa_host_team());
   std::vector<uint64_t> before((size_t)blocks + 1, 0);        // candidates in the blocks before each block
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swa_host_team())
   for (int b = 0; b < blocks; ++b) {
     uint64_t c = 0;
     for (int64_t i = n64 * b / blocks; i < n64 * (b + 1) / blocks; ++i) {
@@ -582,7 +613,7 @@ extern "C" uint32_t swa_d1_graft(swa_d1_result * r, const uint32_t * graft_cand)
   }
   for (int b = 0; b < blocks; ++b) { before[(size_t)b + 1] += before[(size_t)b]; }
   swa_vec<uint64_t> pairs(before[(size_t)blocks]);
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) num_threads(swa_host_team())
   for (int b = 0; b < blocks; ++b) {
     uint64_t at = before[(size_t)b];
     for (int64_t i = n64 * b / blocks; i < n64 * (b + 1) / blocks; ++i) {
@@ -685,7 +716,7 @@ extern "C" int swa_d1_write_swarms(const swa_d1_result * r, const swa_hostdb * d
 
 // -s  (src/algod1.cc:1040-1062): maxgen is printed twice for d = 1
 extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  if (!need_details(r)) { return SWA_E_ARG; }
+  if (!need_details(r)) { return details_failed(r); }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   for (const auto & s : r->swarms) {
@@ -700,7 +731,7 @@ extern "C" int swa_d1_write_stats(const swa_d1_result * r, const swa_hostdb * db
 
 // -i  (src/algod1.cc:985-1037)
 extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  if (!need_details(r)) { return SWA_E_ARG; }
+  if (!need_details(r)) { return details_failed(r); }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   const std::vector<uint32_t> number = output_numbers(r);
@@ -735,7 +766,7 @@ extern "C" int swa_d1_write_structure(const swa_d1_result * r, const swa_hostdb 
 
 // -w  (src/algod1.cc:935-982 + db_fprintseq src/db.cc:925-943)
 extern "C" int swa_d1_write_seeds(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch) {
-  if (!need_details(r)) { return SWA_E_ARG; }
+  if (!need_details(r)) { return details_failed(r); }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   std::vector<uint32_t> idx(r->swarms.size());
@@ -782,7 +813,7 @@ extern "C" int swa_d1_write_network(const swa_hostdb * db, const uint64_t * offs
 // -u  (src/algod1.cc:849-932): members in swarm order, each aligned against the seed
 extern "C" int swa_d1_write_uclust(const swa_d1_result * r, const swa_hostdb * db, const char * path, int usearch,
                                    int64_t append_abundance, uint64_t mismatch, uint64_t gapopen, uint64_t gapextend) {
-  if (!need_details(r)) { return SWA_E_ARG; }
+  if (!need_details(r)) { return details_failed(r); }
   BufOut o(path);
   if (!o.ok()) { return SWA_E_ARG; }
   const std::vector<uint32_t> number = output_numbers(r);

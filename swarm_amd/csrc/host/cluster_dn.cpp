@@ -140,7 +140,7 @@ static int cluster_on_device(swa_ctx * ctx, const swa_hostdb * db, int no_cluste
   // the sums r->largest / maxgenerations are folded behind it.)
   uint64_t largest = 0, maxgenerations = 0;
   bool broken = false;
-#pragma omp parallel for schedule(dynamic, 64) reduction(max : largest, maxgenerations) reduction(|| : broken)
+#pragma omp parallel for schedule(dynamic, 64) reduction(max : largest, maxgenerations) reduction(|| : broken) num_threads(swa_host_team())
   for (uint32_t s = 0; s < nswarms; ++s) {
     std::vector<uint32_t> fill;
     swa_dn_result::Swarm & sw = r->swarms[s];

@@ -230,7 +230,9 @@ void phase(const Options &, const char * prompt) {
   stamp(prompt);
 }
 
-void check_writer(int rc, const char * what) {
+void check_writer(int rc, const char * what, const swa_d1_result * res = nullptr) {
+  // (a writer that could not fetch what it prints from the device says so: not the reference's "Unable to open")
+  if (rc == SWA_E_DEVICE && res != nullptr && swa_d1_result_error(res)[0] != '\0') { die(swa_d1_result_error(res)); }
   if (rc != SWA_OK) { die(std::string("Unable to open ") + what + " file for writing."); }
 }
 
@@ -437,7 +439,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     }
     // ---- host: greedy clustering over the neighbour lists
     swa_d1_result * res = nullptr;
-    if (resident) { if (swa_d1_cluster_resident(ctx, db, &res) != SWA_OK) { die(swa_last_error(ctx)); } }
+    if (resident) { if (swa_d1_cluster_resident_lazy(ctx, db, &res) != SWA_OK) { die(swa_last_error(ctx)); } }
     else if (swa_d1_cluster(db, offsets.data(), neighbours.data(), &res) != SWA_OK) { die("clustering failed"); }
     phase(o, "Clustering:       ");
     uint64_t sum[4];
@@ -449,7 +451,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       std::fprintf(g_log, "Largest swarm:     %" PRIu64 "\n\n", sum[1]);
       std::vector<uint8_t> is_light(n);
       uint64_t st[5];
-      swa_d1_light_flags(res, o.boundary, is_light.data(), st);
+      if (swa_d1_light_flags(res, o.boundary, is_light.data(), st) != SWA_OK) { die(swa_d1_result_error(res)); }
       phase(o, "Counting amplicons in heavy and light swarms");
       std::fprintf(g_log, "Heavy swarms: %" PRIu64 ", with %" PRIu64 " amplicons\n", st[3], st[4]);
       std::fprintf(g_log, "Light swarms: %" PRIu64 ", with %" PRIu64 " amplicons\n", st[0], st[1]);
@@ -496,16 +498,16 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       }
     }
 
-    check_writer(swa_d1_write_swarms(res, db, o.output.c_str(), o.mothur, o.usearch, o.append_abundance, o.differences), "output");
+    check_writer(swa_d1_write_swarms(res, db, o.output.c_str(), o.mothur, o.usearch, o.append_abundance, o.differences), "output", res);
     phase(o, "Writing swarms:   ");
-    if (!o.seeds.empty()) { check_writer(swa_d1_write_seeds(res, db, o.seeds.c_str(), o.usearch), "seeds"); phase(o, "Writing seeds:    "); }
-    if (!o.structure.empty()) { check_writer(swa_d1_write_structure(res, db, o.structure.c_str(), o.usearch), "internal structure"); phase(o, "Writing structure:"); }
+    if (!o.seeds.empty()) { check_writer(swa_d1_write_seeds(res, db, o.seeds.c_str(), o.usearch), "seeds", res); phase(o, "Writing seeds:    "); }
+    if (!o.structure.empty()) { check_writer(swa_d1_write_structure(res, db, o.structure.c_str(), o.usearch), "internal structure", res); phase(o, "Writing structure:"); }
     if (!o.uclust.empty()) {
       check_writer(swa_d1_write_uclust(res, db, o.uclust.c_str(), o.usearch, o.append_abundance, (uint64_t)o.pen_mismatch,
-                                       (uint64_t)o.pen_gapopen, (uint64_t)o.pen_gapextend), "uclust");
+                                       (uint64_t)o.pen_gapopen, (uint64_t)o.pen_gapextend), "uclust", res);
       phase(o, "Writing UCLUST:   ");
     }
-    if (!o.stats.empty()) { check_writer(swa_d1_write_stats(res, db, o.stats.c_str(), o.usearch), "statistics"); phase(o, "Writing stats:    "); }
+    if (!o.stats.empty()) { check_writer(swa_d1_write_stats(res, db, o.stats.c_str(), o.usearch), "statistics", res); phase(o, "Writing stats:    "); }
     swa_d1_result_summary(res, sum);
     std::fprintf(g_log, "\nNumber of swarms:  %" PRIu64 "\nLargest swarm:     %" PRIu64 "\nMax generations:   %" PRIu64 "\n", sum[0],
                  sum[1], sum[2]);

@@ -89,8 +89,20 @@ void swa_run_pieces(BufOut & o, const std::vector<size_t> & bounds, int threads,
 #pragma omp parallel num_threads(threads)
   {
     if (omp_get_thread_num() == 0) {
+      // The team the runtime GRANTED may be one thread (OMP_THREAD_LIMIT, a nested region, omp dynamic) whatever was asked
+      // for: then nobody else formats, and a writer that only waited would wait for ever — it claims pieces
+      // itself.
+      const bool alone = omp_get_num_threads() < 2;
       for (size_t p = 0; p < npieces; ++p) {
-        while (ready[p].load(std::memory_order_acquire) == 0) { std::this_thread::yield(); }
+        while (ready[p].load(std::memory_order_acquire) == 0) {
+          if (!alone) { std::this_thread::yield(); continue; }
+          const size_t q = next.fetch_add(1, std::memory_order_relaxed);
+          if (q >= npieces) { continue; }
+          BufOut sink;
+          format(sink, bounds[q], bounds[q + 1]);
+          pieces[q] = sink.take();
+          ready[q].store(1, std::memory_order_release);
+        }
         o.write(pieces[p].data(), pieces[p].size());
         std::string().swap(pieces[p]);
       }

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -42,6 +43,23 @@ inline unsigned swa_host_cpus() {
       return quota > 0.0 && period > 0.0 ? quota / period : -1.0;
     };
     double q = quota_of("/sys/fs/cgroup/cpu.max", nullptr);
+    // a quota set on a nested, non-namespaced cgroup: the process's own path ("0::/a/b" in /proc/self/cgroup) and its parents
+    if (FILE * f = std::fopen("/proc/self/cgroup", "r")) {
+      char line[512];
+      while (std::fgets(line, sizeof(line), f) != nullptr) {
+        if (std::strncmp(line, "0::", 3) != 0) { continue; }
+        std::string path(line + 3);
+        while (!path.empty() && (path.back() == '\n' || path.back() == '/')) { path.pop_back(); }
+        while (!path.empty()) {
+          const double nested = quota_of(("/sys/fs/cgroup" + path + "/cpu.max").c_str(), nullptr);
+          if (nested > 0.0 && (q <= 0.0 || nested < q)) { q = nested; }
+          const size_t cut = path.rfind('/');
+          if (cut == std::string::npos) { break; }
+          path.resize(cut);
+        }
+      }
+      std::fclose(f);
+    }
     if (q <= 0.0) { q = quota_of("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"); }
     if (q > 0.0) { const unsigned c = (unsigned)(q + 0.5); if (c >= 1 && c < n) { n = c; } }
     return n;
@@ -61,8 +79,11 @@ class swa_pool {
   template <class F>
   void run(unsigned tasks, F && fn) {
     if (tasks == 0) { return; }
-    if (tasks == 1 || workers_.empty()) { for (unsigned t = 0; t < tasks; ++t) { fn(t); } return; }
+    // a task of a running phase that starts a phase of its own (a resize inside a pooled loop, a sort reached from one):
+    // the phase mutex is not recursive and the workers are busy with the outer phase — run it here
+    if (tasks == 1 || workers_.empty() || in_phase()) { for (unsigned t = 0; t < tasks; ++t) { fn(t); } return; }
     std::lock_guard<std::mutex> one_phase(phase_);
+    struct Mark { Mark() { in_phase() = true; } ~Mark() { in_phase() = false; } } mark;
     std::function<void(unsigned)> job = std::ref(fn);
     {
       std::lock_guard<std::mutex> lk(m_);
@@ -92,6 +113,7 @@ class swa_pool {
     wake_.notify_all();
     for (auto & w : workers_) { w.join(); }
   }
+  static bool & in_phase() { static thread_local bool inside = false; return inside; }
   void work(const std::function<void(unsigned)> & job, unsigned tasks) {
     unsigned finished = 0;
     for (;;) {
@@ -121,7 +143,9 @@ class swa_pool {
         if (job == nullptr) { continue; }
         ++busy_;                                // (the phase's owner waits for every worker that picked the job up)
       }
+      in_phase() = true;
       work(*job, tasks);
+      in_phase() = false;
       {
         std::lock_guard<std::mutex> lk(m_);
         --busy_;
