@@ -317,6 +317,20 @@ def md5_of(path) -> str:
     return h.hexdigest()
 
 
+def reference_run(flags: list, fasta: Path, n: int, what: str) -> dict:
+    """The unmodified reference (oracle/_ref/swarm) on this box's host cores, whole run, once: the stated baseline of a
+    config other than the headline's.  -t 16: what the headline's baseline found best on this host."""
+    ref = ROOT / "oracle" / "_ref" / "swarm"
+    if not ref.exists():
+        return {"error": "oracle/_ref/swarm not built (no /root/reference at build time)"}
+    threads = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    subprocess.run([str(ref), *flags, "-t", str(threads), "-o", "/dev/null", "-l", "/dev/null", str(fasta)], check=True)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "amplicons/s", "cores": threads, "kind": "reference", "seconds": round(dt, 2),
+            "sample": f"reference swarm 3.1.6 {' '.join(flags)} -t {threads}, whole run, {what}"}
+
+
 def config2_fastidious(args, n: int) -> dict:
     """BASELINE configs[2]: n x 150 with 30 % light amplicons, d=1 --fastidious, whole pipeline through the
     C ABI as the command line drives it (network kept in HBM, agglomeration on the GPU, fastidious pair route);
@@ -378,6 +392,11 @@ def config2_fastidious(args, n: int) -> dict:
     cl.close()
     ctx.close()
     hdb.close()
+    if not args.no_cpu_baseline:
+        # bounded sample (13 s at -t 8 for 1 M): the same generator, 1 M amplicons with 30 % light ones
+        sample = min(n, 1_000_000)
+        res["cpu_baseline"] = reference_run(["-d", "1", "-f"], gen_fasta(sample, args.length, args.seed, 1, 0.3), sample,
+                                            f"{sample} x {args.length} bp, 30 % light")
     return res
 
 
@@ -438,6 +457,13 @@ def config3_dn(args, n: int, length: int, d: int) -> dict:
     cl.close()
     ctx.close()
     hdb.close()
+    if not args.no_cpu_baseline:
+        # The reference's d >= 2 loop is quadratic in the size of the set (20 k x 400 takes 5.7 s, 1 M x 400
+        # 1 061 s at -t 8, tests/golden/fullsize.json): a 50 k sample of the same generator keeps it inside the budget, and
+        # FLATTERS the reference — its rate at 1 M is a twentieth of the sample's.
+        sample = min(n, 50_000)
+        res["cpu_baseline"] = reference_run(["-d", str(d)], gen_fasta(sample, length, args.seed, d, 0.0), sample,
+                                            f"{sample} x {length} bp (quadratic: slower per amplicon at {n})")
     return res
 
 
@@ -1152,11 +1178,11 @@ def main() -> None:
                     out[name] = out["config"].pop(name)
             c3 = out["config"].get("configs3")
             if isinstance(c3, dict) and "qgram_comparisons_per_s" in c3:
-                out["configs3"] = {k: c3[k] for k in ("workload", "qgram_comparisons_per_s", "aligned_pairs_per_s", "clustering_seconds",
-                                                      "full_matrix_equivalent_cells_per_s", "banded_cells_per_s") if k in c3}
+                out["configs3"] = {k: c3[k] for k in ("workload", "value", "unit", "qgram_comparisons_per_s", "aligned_pairs_per_s", "clustering_seconds",
+                                                      "full_matrix_equivalent_cells_per_s", "banded_cells_per_s", "cpu_baseline") if k in c3}
             c2 = out["config"].get("configs2")
             if isinstance(c2, dict) and "pipeline_total_s" in c2:
-                out["configs2"] = {k: c2[k] for k in ("workload", "pipeline_total_s", "value", "unit", "counters_equal_reference_log") if k in c2}
+                out["configs2"] = {k: c2[k] for k in ("workload", "pipeline_total_s", "value", "unit", "counters_equal_reference_log", "cpu_baseline") if k in c2}
         elif world == 1 and not sim_world and not args.no_cpu_baseline:
             sample_n = min(n_total, 1_000_000)
             out["cpu_baseline"] = cpu_baseline(gen_fasta(sample_n, args.length, args.seed), sample_n, args.length, args.seed)
