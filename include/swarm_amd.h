@@ -85,6 +85,9 @@ int  swa_ctx_warmup(swa_ctx * ctx);
 /* The same for a caller that knows its d: 1 loads the d = 1 step's and the clustering's code objects, >= 2 those of the q-gram,
    pair-graph and alignment kernels (and the clustering's), anything else all of them. */
 int  swa_ctx_warmup_for(swa_ctx * ctx, int differences);
+/* the copy engine's first download (~7.5 ms of runtime set-up whatever the size), paid ahead: any thread, beside the
+   other warm-up calls */
+int  swa_ctx_warmup_downloads(swa_ctx * ctx);
 
 /* Per-kernel timing with HIP events on the context's stream (off by default).
    swa_timing_read: ms[0] seqhash, [1] table+Bloom build, [2] duplicate check,
@@ -124,6 +127,12 @@ typedef struct swa_db_unordered_view {
 } swa_db_unordered_view;
 int swa_db_stage_words(swa_ctx * ctx, const uint64_t * const * piece_words, const uint64_t * piece_word_count, uint32_t pieces);
 int swa_db_upload_unordered(swa_ctx * ctx, const swa_db_unordered_view * host_db);
+/* Result buffers are the caller's (as in the reference: src/algod1.cc:1104-1125).  A caller that wants its downloads — the
+   member order of swa_d1_cluster_device, the lists of swa_d1_network — at the link's speed pins them first: the copy is then
+   one DMA instead of a staged copy through the runtime's bounce buffers.  Any thread; the memory stays the caller's
+   (unpin before freeing it). */
+int  swa_host_pin(swa_ctx * ctx, void * ptr, size_t bytes);
+void swa_host_unpin(void * ptr);
 
 /* ---- B1: d = 1 network --------------------------------------------------------- */
 /* The index the network calls work on — what the reference's hash_insert loop builds (src/algod1.cc:188-208,

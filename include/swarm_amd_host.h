@@ -60,6 +60,11 @@ int  swa_d1_cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result
    swa_d1_result_detach fetches what is still on the device (SWA_E_DEVICE and swa_d1_result_error when that fails);
    after it the result does not refer to the context any more. */
 int  swa_d1_cluster_resident_lazy(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
+/* The lazy form in two steps, for a caller that has a thread to spare while the network is being built: _prepare sizes the
+   result's arrays for `db` and pins them (swa_host_pin) — any thread, any time after the context exists —, _prepared then
+   clusters into them: the member order comes home as one DMA. */
+int  swa_d1_result_prepare(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
+int  swa_d1_cluster_resident_prepared(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result * prepared);
 int  swa_d1_result_detach(swa_d1_result * res);
 const char * swa_d1_result_error(const swa_d1_result * res);
 void swa_d1_result_free(swa_d1_result * res);

@@ -72,7 +72,8 @@ class DbUnorderedView(C.Structure):
 
 EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_ctx_warmup_for", "swa_d1_anchor_windows", "swa_d1_anchor_width",
-    "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident", "swa_d1_cluster_resident_lazy", "swa_d1_result_detach", "swa_d1_result_error",
+    "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident", "swa_d1_cluster_resident_lazy", "swa_d1_result_detach", "swa_d1_result_error", "swa_d1_result_prepare",
+    "swa_d1_cluster_resident_prepared", "swa_host_pin", "swa_host_unpin", "swa_ctx_warmup_downloads",
     "swa_db_upload", "swa_db_attach", "swa_db_stage_words", "swa_db_upload_unordered", "swa_hostdb_unordered_view", "swa_hostdb_read_fasta_staged", "swa_cli_main", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
@@ -260,7 +261,7 @@ class D1Clusters:
         self.h = h
 
     @classmethod
-    def from_resident(cls, ctx: "Context", hdb: HostDb, lazy: bool = False) -> "D1Clusters":
+    def from_resident(cls, ctx: "Context", hdb: HostDb, lazy: bool = False, pinned: bool = False) -> "D1Clusters":
         """The same result from the network ctx.d1_network_resident() left in HBM: agglomeration on the GPU
         (swa_d1_cluster_device), per-swarm sums on the host.  lazy = the command line's form (swa_d1_cluster_resident_lazy):
         swarm / generation / parent stay in HBM until asked for; the result then keeps the context alive."""
@@ -268,7 +269,19 @@ class D1Clusters:
         self.lib = load_library()
         self.hdb = hdb
         self._keep = None
-        self._ctx = ctx if lazy else None
+        self._ctx = ctx if (lazy or pinned) else None
+        if pinned:
+            # the command line's two steps: result arrays sized and pinned ahead (swa_d1_result_prepare), then clustered into
+            self.lib.swa_d1_result_prepare.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+            self.lib.swa_d1_cluster_resident_prepared.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            h = C.c_void_p()
+            rc = self.lib.swa_d1_result_prepare(ctx.h, hdb.h, C.byref(h))
+            self.h = h
+            if rc == SWA_OK:
+                rc = self.lib.swa_d1_cluster_resident_prepared(ctx.h, hdb.h, h)
+            if rc != SWA_OK:
+                raise SwaError(rc, "swa_d1_cluster_resident_prepared failed: " + ctx.lib.swa_last_error(ctx.h).decode())
+            return self
         fn = self.lib.swa_d1_cluster_resident_lazy if lazy else self.lib.swa_d1_cluster_resident
         fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         h = C.c_void_p()

@@ -134,6 +134,28 @@ extern "C" int swa_ctx_warmup_for(swa_ctx * ctx, int differences) {
 
 extern "C" int swa_ctx_warmup(swa_ctx * ctx) { return swa_ctx_warmup_for(ctx, -1); }
 
+// The first download of a process into pinned memory costs the runtime ~7.5 ms whatever its size (the copy engine's queue for
+// that direction is made then: tools/experiments/d2h_cost.hip, lease r6g — 40 MB: 7.4 ms in the call + 0.8 ms of transfer the
+// first time, 0.75 ms afterwards).  A caller with a thread to spare pays it here, on a stream of its own, beside the code-object
+// loads and uploads of its start-up — not in front of the first result it waits for.
+extern "C" int swa_ctx_warmup_downloads(swa_ctx * ctx) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  constexpr size_t kBytes = 256u << 10;
+  void * d = nullptr, * h = nullptr;
+  hipStream_t s = nullptr;
+  SWA_HIP(ctx, hipMalloc(&d, kBytes));
+  if (hipHostMalloc(&h, kBytes, hipHostMallocDefault) != hipSuccess) { (void)hipFree(d); return swa_fail_msg(ctx, SWA_E_NOMEM, "swa_ctx_warmup_downloads: no pinned memory"); }
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e == hipSuccess) { e = hipMemcpyAsync(h, d, kBytes, hipMemcpyDeviceToHost, s); }
+  if (e == hipSuccess) { e = hipStreamSynchronize(s); }
+  if (s != nullptr) { (void)hipStreamDestroy(s); }
+  (void)hipHostFree(h);
+  (void)hipFree(d);
+  if (e != hipSuccess) { return swa_fail(ctx, SWA_E_DEVICE, "swa_ctx_warmup_downloads", e); }
+  return SWA_OK;
+}
+
 extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
   if (ctx == nullptr) { return; }
   (void)hipSetDevice(ctx->device);
@@ -148,7 +170,7 @@ extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
                        &ctx->d_afallback, &ctx->d_arank, &ctx->d_rank_tmp, &ctx->d_wfa, &ctx->d_long_rows, &ctx->d_seg_fill, &ctx->d_seg_base, &ctx->d_akeys[0], &ctx->d_acounts[0],
                        &ctx->d_aitems[0], &ctx->d_aitems[1],
                        &ctx->d_frole, &ctx->d_fkeys, &ctx->d_fcnt, &ctx->d_foff, &ctx->d_fslot, &ctx->d_fmembers, &ctx->d_fitems,
-                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster, &ctx->d_words_stage}) {
+                       &ctx->d_fpairs, &ctx->d_dn_keys, &ctx->d_dn_vals, &ctx->d_cluster, &ctx->d_cluster_ctl, &ctx->d_words_stage}) {
     swa_release(*b);
   }
   for (auto & b : ctx->d_stream) { swa_release(b); }
@@ -359,6 +381,17 @@ extern "C" int swa_db_upload_unordered(swa_ctx * ctx, const swa_db_unordered_vie
   invalidate(ctx);
   return SWA_OK;
 }
+
+// Host memory of the caller's, pinned: a download into it (swa_d1_cluster_device's member order, swa_d1_network's lists) is
+// one DMA at the link's speed instead of a staged copy through the runtime's bounce buffers (40 MB: ~1 ms instead of 5-8).
+// Any thread may call these; the memory stays the caller's.
+extern "C" int swa_host_pin(swa_ctx * ctx, void * ptr, size_t bytes) {
+  if (ctx == nullptr || ptr == nullptr || bytes == 0) { return SWA_E_ARG; }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return SWA_OK;
+}
+extern "C" void swa_host_unpin(void * ptr) { if (ptr != nullptr) { (void)hipHostUnregister(ptr); } }
 
 extern "C" int swa_db_attach(swa_ctx * ctx, const swa_db_view * d) {
   SWA_TRY(check_view(ctx, d));

@@ -50,6 +50,13 @@ struct swa_d1_result {
   swa_ctx * lazy_ctx = nullptr;
   const swa_hostdb * lazy_db = nullptr;
   bool details = true;
+  // swa_d1_result_prepare: order and the download area of the swarms' bounds sized ahead — and pinned, when the runtime agreed
+  swa_vec<uint32_t> begin_tmp;
+  bool prepared = false, pinned_order = false, pinned_begin = false;
+  ~swa_d1_result() {
+    if (pinned_order) { swa_host_unpin(order.data()); }
+    if (pinned_begin) { swa_host_unpin(begin_tmp.data()); }
+  }
 };
 
 namespace {
@@ -318,7 +325,35 @@ void cluster_by_fixed_points(const swa_hostdb * db, const uint64_t * offsets, co
 // ---- the same result from the network that is still in HBM (cluster_gpu.hip) ------------------
 // swa_d1_network_resident left the CSR on the device; the three order-free statements above are evaluated
 // there and only swarm / generation / parent / member order come back.  The per-swarm sums stay here.
-static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out);
+static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out, swa_d1_result * prepared = nullptr);
+
+extern "C" int swa_d1_result_prepare(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out) {
+  if (ctx == nullptr || db == nullptr || out == nullptr) { return SWA_E_ARG; }
+  auto * r = new swa_d1_result();
+  *out = r;
+  r->n = db->n;
+  r->prepared = true;
+  if (db->n == 0) { return SWA_OK; }
+  r->order.resize(db->n);
+  r->begin_tmp.resize((size_t)db->n + 1);
+  // (pinning faults the pages in and maps them for the device; when it is refused the downloads are staged copies as before)
+  const char * how = std::getenv("SWARM_AMD_PIN_RESULTS");     // (experiments: "touch" = pages faulted in, not pinned)
+  if (how != nullptr && std::strcmp(how, "touch") == 0) {
+    std::memset(r->order.data(), 0, (size_t)db->n * sizeof(uint32_t));
+    std::memset(r->begin_tmp.data(), 0, ((size_t)db->n + 1) * sizeof(uint32_t));
+    return SWA_OK;
+  }
+  r->pinned_order = swa_host_pin(ctx, r->order.data(), (size_t)db->n * sizeof(uint32_t)) == SWA_OK;
+  r->pinned_begin = swa_host_pin(ctx, r->begin_tmp.data(), ((size_t)db->n + 1) * sizeof(uint32_t)) == SWA_OK;
+  if (std::getenv("SWARM_AMD_CLUSTER_TIMING") != nullptr) { std::fprintf(stderr, "[cluster] result arrays pinned: order %d, bounds %d\n", (int)r->pinned_order, (int)r->pinned_begin); }
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_cluster_resident_prepared(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result * prepared) {
+  if (prepared == nullptr || !prepared->prepared || db == nullptr || prepared->n != db->n) { return SWA_E_ARG; }
+  swa_d1_result * same = prepared;
+  return cluster_resident(ctx, db, &same, prepared);
+}
 
 // The result owns everything it returns: swarm / generation / parent are fetched and the sums made before this returns, and
 // the context may be destroyed or used for the next database afterwards.
@@ -343,9 +378,9 @@ extern "C" int swa_d1_result_detach(swa_d1_result * r) {
 
 extern "C" const char * swa_d1_result_error(const swa_d1_result * r) { return r == nullptr ? "" : r->error.c_str(); }
 
-static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out) {
+static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result ** out, swa_d1_result * prepared) {
   if (ctx == nullptr || db == nullptr || out == nullptr) { return SWA_E_ARG; }
-  auto * r = new swa_d1_result();
+  auto * r = prepared != nullptr ? prepared : new swa_d1_result();
   *out = r;
   const uint32_t n = db->n;
   r->n = n;
@@ -358,8 +393,11 @@ static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result 
     t_last = now;
   };
   if (n == 0) { return SWA_OK; }
-  r->order.resize(n);                                       // (every entry is written by the download below)
-  swa_vec<uint32_t> begin((size_t)n + 1);
+  if (prepared == nullptr) {
+    r->order.resize(n);                                     // (every entry is written by the download below)
+    r->begin_tmp.resize((size_t)n + 1);
+  }
+  swa_vec<uint32_t> & begin = r->begin_tmp;
   lap("result arrays");
   uint32_t nswarms = 0;
   const int rc = swa_d1_cluster_device(ctx, nullptr, nullptr, nullptr, r->order.data(), begin.data(), n, &nswarms);

@@ -61,6 +61,12 @@ struct Input {
   size_t size = 0;
   bool mapped = false;
   std::vector<char> owned;
+  // A regular file is not mapped: the parser threads pread() it through buffers of a few megabytes each.  Mapped, the
+  // 1.6 GB of a 10 M-amplicon file were 400 000 page-table entries this process had to take apart again at exit (or
+  // whenever it unmapped them): a quarter of a second in the runs where the kernel does not do that on its own time
+  // (profiles/r05/NOTES.md 8-9).  SWARM_AMD_INPUT=mmap: the mapping, for comparison.
+  int fd = -1;
+  ~Input() { if (fd >= 0) { ::close(fd); } }
 };
 
 bool load_input(const char * path, Input & in, std::string & err) {
@@ -72,6 +78,14 @@ bool load_input(const char * path, Input & in, std::string & err) {
       return false;
     }
     struct stat st{};
+    const char * input_env = std::getenv("SWARM_AMD_INPUT");
+    const bool want_map = input_env != nullptr && std::strcmp(input_env, "mmap") == 0;
+    if (!want_map && ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      in.fd = fd;
+      in.size = (size_t)st.st_size;
+      (void)::posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+      return true;
+    }
     if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
       void * p = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
       if (p != MAP_FAILED) {
@@ -210,19 +224,22 @@ __attribute__((target("avx2"))) bool pack_tail_avx2(const char * q, uint32_t r, 
 }
 
 // parse records of [begin, end) — begin points at a '>' that starts a line (or at the file start)
+// (may be called again for the next stretch of the same piece — the streamed reader hands it whole records a buffer at a
+// time: line numbers, entries and pools continue; reserve_span = bytes of text the piece will hold in all, 0 = sized already)
 void parse_piece(const char * begin, const char * end, const int8_t * map, bool usearch, int64_t append_abundance,
-                 uint32_t piece_no, Piece & out) {
+                 uint32_t piece_no, Piece & out, size_t reserve_span) {
   const char * p = begin;
-  uint32_t lineno = 1;
+  uint32_t lineno = (uint32_t)out.lines + 1u;
   static const bool have_avx2 = __builtin_cpu_supports("avx2") && std::getenv("SWARM_AMD_NO_AVX2") == nullptr;
   auto line_end = [&](const char * q) { const void * nl = std::memchr(q, '\n', (size_t)(end - q)); return nl ? (const char *)nl : end; };
-  const size_t span = (size_t)(end - begin);
   auto & entries = out.data.entries;
   auto & words = out.data.words;
   auto & hdr_pool = out.data.hdr_pool;
-  entries.reserve(span / 160 + 16);
-  words.reserve(span / 28 + 16);
-  hdr_pool.reserve(span / 12 + 16);
+  if (reserve_span != 0) {
+    entries.reserve(reserve_span / 160 + 16);
+    words.reserve(reserve_span / 28 + 16);
+    hdr_pool.reserve(reserve_span / 12 + 16);
+  }
   auto fail = [&](const std::string & msg, uint32_t line, int kind) { out.error = msg; out.error_line = line; out.error_kind = kind; };
   while (p < end) {
     if (*p != '>') { fail("\nError: Illegal header line in fasta file.\n", lineno, 2); break; }   // db.cc:492-494
@@ -348,6 +365,70 @@ void parse_piece(const char * begin, const char * end, const int8_t * map, bool 
     entries.push_back(e);
   }
   out.lines = lineno - 1;
+}
+
+// bytes [pos, pos + len) of the file into dst; false when the file ends (or fails) before that
+bool pread_all(int fd, char * dst, size_t len, size_t pos) {
+  while (len != 0) {
+    const ssize_t got = ::pread(fd, dst, len, (off_t)pos);
+    if (got <= 0) { return false; }
+    dst += got; pos += (size_t)got; len -= (size_t)got;
+  }
+  return true;
+}
+
+// the first record start behind `from`: the smallest p > from with text[p - 1] == '\n' and text[p] == '>' (or the file's size)
+size_t next_record_start(int fd, size_t from, size_t size) {
+  std::vector<char> window(64 << 10);
+  bool after_newline = false;                                  // (text[from - 1] does not count: the cut lies BEHIND from)
+  for (size_t pos = from; pos < size;) {
+    const size_t len = std::min(window.size(), size - pos);
+    if (!pread_all(fd, window.data(), len, pos)) { return size; }
+    size_t k = 0;
+    if (after_newline && window[0] == '>' && pos > from) { return pos; }
+    while (k < len) {
+      const void * nl = std::memchr(window.data() + k, '\n', len - k);
+      if (nl == nullptr) { k = len; after_newline = false; break; }
+      k = (size_t)((const char *)nl - window.data()) + 1;
+      if (k < len) { if (window[k] == '>') { return pos + k; } }
+      else { after_newline = true; }
+    }
+    pos += len;
+  }
+  return size;
+}
+
+// bytes [lo, hi) of the file — whole records: lo and hi are record starts (or the file's ends) — through one buffer
+void parse_piece_streamed(int fd, size_t lo, size_t hi, const int8_t * map, bool usearch, int64_t append_abundance, uint32_t piece_no, Piece & out) {
+  const char * chunk_env = std::getenv("SWARM_AMD_READ_CHUNK_KB");     // (tests: buffers smaller than a record)
+  const size_t chunk = chunk_env != nullptr ? std::max<size_t>(1, (size_t)std::atol(chunk_env)) << 10 : size_t(4) << 20;
+  std::vector<char> buf(std::min(chunk, hi - lo) + 64);        // (+ 64: the packers may look 32 bytes ahead, never behind `end`)
+  size_t have = 0, off = lo;
+  bool first = true;
+  while (off < hi || have != 0) {
+    const size_t want = std::min(buf.size() - 64 - have, hi - off);
+    if (want != 0) {
+      if (!pread_all(fd, buf.data() + have, want, off)) { hi = off; continue; }     // (a file that shrank under the reader ends here)
+      have += want; off += want;
+    }
+    size_t b = have;                                           // records [0, b) of the buffer are whole
+    if (off < hi) {
+      b = 0;
+      for (size_t k = have; k > 1;) {                          // the last "\n>" of the buffer
+        const void * nl = ::memrchr(buf.data(), '\n', k - 1);  // a newline with a byte behind it inside [0, have)
+        if (nl == nullptr) { break; }
+        k = (size_t)((const char *)nl - buf.data()) + 1;
+        if (buf[k] == '>') { b = k; break; }
+        --k;
+      }
+      if (b == 0) { buf.resize((buf.size() - 64) * 2 + 64); continue; }   // one record fills the buffer: a larger one
+    }
+    parse_piece(buf.data(), buf.data() + b, map, usearch, append_abundance, piece_no, out, first ? hi - lo : 0);
+    first = false;
+    if (out.error_kind != 0) { return; }
+    std::memmove(buf.data(), buf.data() + b, have - b);
+    have -= b;
+  }
 }
 
 unsigned worker_count(size_t bytes) {
@@ -646,6 +727,7 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   for (unsigned t = 1; t < threads; ++t) {
     size_t pos = in.size / threads * t;
     if (pos < cuts[t - 1]) { pos = cuts[t - 1]; }
+    if (in.fd >= 0) { cuts[t] = next_record_start(in.fd, pos, in.size); continue; }
     while (pos < in.size) {
       const void * nl = std::memchr(in.data + pos, '\n', in.size - pos);
       if (nl == nullptr) { pos = in.size; break; }
@@ -657,7 +739,8 @@ extern "C" int swa_hostdb_read_fasta_staged(const char * path, int usearch, int6
   std::vector<Piece> parsed(threads);
   run_parallel(threads, [&](unsigned t) {
     if (cuts[t] < cuts[t + 1]) {
-      parse_piece(in.data + cuts[t], in.data + cuts[t + 1], map, usearch != 0, append_abundance, t, parsed[t]);
+      if (in.fd >= 0) { parse_piece_streamed(in.fd, cuts[t], cuts[t + 1], map, usearch != 0, append_abundance, t, parsed[t]); }
+      else { parse_piece(in.data + cuts[t], in.data + cuts[t + 1], map, usearch != 0, append_abundance, t, parsed[t], cuts[t + 1] - cuts[t]); }
     }
   });
   timer.lap("map + parallel parse");

@@ -300,6 +300,17 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     early = std::thread([&early_ctx, &early_rc, &words_ready, device, warm_for]() {
       early_rc = swa_ctx_create(device, nullptr, &early_ctx);
       stamp("(helper thread) context created");
+      // (the first download's set-up beside the code objects and the staging copy: SWARM_AMD_WARM_DOWNLOADS=0 leaves it to the
+      // first result's download)
+      std::thread downloads;
+      {
+        const char * wd = std::getenv("SWARM_AMD_WARM_DOWNLOADS");
+        if (early_rc == SWA_OK && (wd == nullptr || wd[0] != '0')) {
+          swa_ctx * c = early_ctx;
+          downloads = std::thread([c]() { (void)swa_ctx_warmup_downloads(c); stamp("(second helper thread) download path warm"); });
+        }
+      }
+      struct Join { std::thread & t; ~Join() { if (t.joinable()) { t.join(); } } } join_downloads{downloads};
       // (the anomaly hunt, tools/stress/cold_runs.sh: no warm-up = every code object loaded by the step's own first launch;
       // loading them on a thread of their own beside the copy below was tried: no gain — lease r5w)
       if (early_rc == SWA_OK && std::getenv("SWARM_AMD_NO_WARMUP") == nullptr) { (void)swa_ctx_warmup_for(early_ctx, warm_for); }
@@ -385,6 +396,9 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     swa_d0_result_free(res);
   } else if (o.differences == 1) {
     // ---- seam B1: the network on the GPU
+    swa_d1_result * prepared = nullptr;
+    int prepare_rc = SWA_OK;
+    std::thread preparing;
     std::vector<uint64_t> offsets;              // (the CSR only comes to the host for -j and from several GPUs)
     std::vector<uint32_t> neighbours;
     bool resident = false;
@@ -410,8 +424,20 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       phase(o, "Hashing sequences:");
       phase(o, "Building network: ");
     } else if (n > 0) {
+      // beside the index and the network (12 ms at 10 M): the result's arrays sized and pinned, so that the member order comes
+      // home as one DMA (SWARM_AMD_PIN_RESULTS=0: the staged copy of round 5)
+      {
+        const char * pin = std::getenv("SWARM_AMD_PIN_RESULTS");
+        if (pin == nullptr || pin[0] != '0') {
+          preparing = std::thread([&prepared, &prepare_rc, ctx, db]() {
+            prepare_rc = swa_d1_result_prepare(ctx, db, &prepared);
+            stamp("(helper thread) result arrays pinned");
+          });
+        }
+      }
       int dup = 0;
       rc = swa_d1_index_build(ctx, &dup);
+      if (rc != SWA_OK && preparing.joinable()) { preparing.join(); }     // (no exit under a thread that is talking to the runtime)
       if (rc == SWA_E_DUPLICATES) {
         die("some fasta entries have identical sequences.\n"
             "Swarm expects dereplicated fasta files.\n"
@@ -425,6 +451,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       // the network stays in HBM: the agglomeration runs on it there; it only comes to the host for -j
       uint64_t total = 0;
       rc = swa_d1_network_resident(ctx, o.no_break ? 1 : 0, &total);
+      if (rc != SWA_OK && preparing.joinable()) { preparing.join(); }
       if (rc != SWA_OK) { die(swa_last_error(ctx)); }
       resident = true;
       if (!o.network.empty()) {
@@ -439,7 +466,11 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
     }
     // ---- host: greedy clustering over the neighbour lists
     swa_d1_result * res = nullptr;
-    if (resident) { if (swa_d1_cluster_resident_lazy(ctx, db, &res) != SWA_OK) { die(swa_last_error(ctx)); } }
+    if (preparing.joinable()) { preparing.join(); }
+    if (resident && prepared != nullptr && prepare_rc == SWA_OK) {
+      res = prepared;
+      if (swa_d1_cluster_resident_prepared(ctx, db, res) != SWA_OK) { die(swa_last_error(ctx)); }
+    } else if (resident) { if (swa_d1_cluster_resident_lazy(ctx, db, &res) != SWA_OK) { die(swa_last_error(ctx)); } }
     else if (swa_d1_cluster(db, offsets.data(), neighbours.data(), &res) != SWA_OK) { die("clustering failed"); }
     phase(o, "Clustering:       ");
     uint64_t sum[4];

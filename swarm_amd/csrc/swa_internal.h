@@ -163,7 +163,7 @@ struct swa_ctx {
   uint32_t part_lds_opt_in = 0;    // ... and the wide-tile forms of k_part_scatter (one bit each)
   bool csr_has_diffs = false;                 // the resident network is a d >= 2 graph: one byte of differences per link behind the neighbours
   uint64_t csr_total = 0;
-  swa_dbuf d_cluster;
+  swa_dbuf d_cluster, d_cluster_ctl;
 };
 
 int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e);

@@ -422,6 +422,95 @@ def test_device_clustering_equals_the_host_walk(gpu_ctx, tmp_path, n, L, seed, n
         assert filecmp.cmp(tmp_path / f"d{name}", tmp_path / f"h{name}", shallow=False), name
 
 
+def _same_clustering(dev, host, tmp_path, tag=""):
+    import filecmp
+    assert dev.summary() == host.summary()
+    assert np.array_equal(dev.swarmid(), host.swarmid())
+    assert np.array_equal(dev.generation(), host.generation())
+    assert np.array_equal(dev.parent(), host.parent())
+    for name, fn in (("o", "write_swarms"), ("s", "write_stats"), ("i", "write_structure"), ("w", "write_seeds")):
+        getattr(dev, fn)(tmp_path / f"d{name}{tag}")
+        getattr(host, fn)(tmp_path / f"h{name}{tag}")
+        assert filecmp.cmp(tmp_path / f"d{name}{tag}", tmp_path / f"h{name}{tag}", shallow=False), name
+
+
+def test_device_clustering_of_deep_chains_and_ties(gpu_ctx, tmp_path):
+    """What the frontier walk of cluster_gpu.hip has to get right beyond the generated families: swarms a hundred generations
+    deep (more frontiers than one batch of launches holds), chains of EQUAL abundances (links in both directions: the smallest
+    id that reaches a vertex may sit in the middle of its chain), a chain that branches, members without links of their own at
+    the deepest generation — and the three forms of the result: eager, lazy, prepared (pinned arrays)."""
+    import os
+    from swarm_amd import D1Clusters, HostDb
+    rng = np.random.default_rng(5)
+    L = 150
+    recs = []
+    uid = 0
+
+    def chain(steps, abundance_of, branch_at=None):
+        nonlocal uid
+        seq = list(rng.choice(list("ACGT"), L))
+        positions = rng.permutation(L)
+        members = []
+        for k in range(steps):
+            if k > 0:
+                p = positions[k - 1]
+                seq[p] = "ACGT"[("ACGT".index(seq[p]) + 1 + int(rng.integers(0, 3))) % 4]
+            members.append("".join(seq))
+            recs.append((f"c{uid}_{abundance_of(k)}".encode(), "".join(seq)))
+            uid += 1
+            if branch_at is not None and k == branch_at:
+                side = list(seq)
+                for j in range(40):                                  # a side branch off the chain, on other positions
+                    p = positions[L - 1 - j]
+                    side[p] = "ACGT"[("ACGT".index(side[p]) + 1) % 4]
+                    recs.append((f"b{uid}_{max(1, abundance_of(k) - 1 - j)}".encode(), "".join(side)))
+                    uid += 1
+
+    chain(100, lambda k: 5000 - k)                                   # strictly falling: 100 generations
+    chain(70, lambda k: 77)                                          # all equal: links both ways
+    chain(90, lambda k: 900 - 2 * k, branch_at=30)
+    chain(45, lambda k: 300 if k % 2 == 0 else 299)
+    for _ in range(300):                                             # and company: singletons and small families
+        chain(int(rng.integers(1, 4)), lambda k: 10 - k)
+    fa = tmp_path / "chains.fa"
+    with open(fa, "wb") as fh:
+        for h, q in recs:
+            fh.write(b">" + h + b"\n" + q.encode() + b"\n")
+    if S.have_reference():                                           # the command line (prepared / pinned form) against the reference itself
+        import filecmp
+        import subprocess
+        from pathlib import Path
+        exe = Path(__file__).resolve().parents[1] / "swarm_amd" / "bin" / "swarm"
+        for extra in ([], ["-n"], ["-f"]):
+            ref_cmd, our_cmd = ["-d", "1"] + extra, [str(exe), "-d", "1"] + extra
+            for k, flag in (("o", "-o"), ("s", "-s"), ("i", "-i"), ("w", "-w")):
+                ref_cmd += [flag, str(tmp_path / f"r{k}")]
+                our_cmd += [flag, str(tmp_path / f"g{k}")]
+            r = S.run_ref_swarm(ref_cmd + ["-l", "/dev/null", str(fa)])
+            assert r.returncode == 0, r.stderr
+            g = subprocess.run(our_cmd + ["-l", "/dev/null", str(fa)], capture_output=True, text=True)
+            assert g.returncode == 0, g.stderr
+            for k in "osiw":
+                assert filecmp.cmp(tmp_path / f"r{k}", tmp_path / f"g{k}", shallow=False), (extra, k)
+    hdb = HostDb(fa)
+    gpu_ctx.upload_hostdb(hdb)
+    assert gpu_ctx.d1_index_build() is False
+    for ncb in (False, True):
+        total = gpu_ctx.d1_network_resident(ncb)
+        off, nb = gpu_ctx.d1_network_fetch(total)
+        os.environ["SWARM_AMD_CLUSTER"] = "serial"
+        try:
+            host = D1Clusters(hdb, off, nb)
+        finally:
+            del os.environ["SWARM_AMD_CLUSTER"]
+        assert host.summary()["maxgen"] >= 60
+        for form in ({}, {"lazy": True}, {"pinned": True}):
+            dev = D1Clusters.from_resident(gpu_ctx, hdb, **form)
+            _same_clustering(dev, host, tmp_path, f"_{int(ncb)}_{'_'.join(form) or 'eager'}")
+            dev.close()
+        host.close()
+
+
 def test_runs_across_the_anchor_boundary(gpu_ctx, tmp_path):
     """The passes divide a seed's microvariants by whether they keep its first 32 nucleotides (swa_aux::pb).  The cases
     that rule exists for: homopolymer runs that cross position 31 / 32 with deletions and insertions inside the run

@@ -257,6 +257,61 @@ def test_the_avx2_packer_and_the_byte_loop_pack_the_same_words(tmp_path):
     assert np.array_equal(hdb.seqs, db.seqs[:len(hdb.seqs)]) and np.array_equal(hdb.seq_off, db.seq_off)
 
 
+def test_the_streamed_reader_equals_the_mapped_one_whatever_the_buffer(tmp_path, monkeypatch):
+    """A regular file is pread() through a few megabytes of buffer per parser thread instead of being mapped (fasta_db.cpp:
+    parse_piece_streamed; the 1.6 GB mapping of a 10 M file was page tables to take apart at exit).  The same file through
+    buffers of 1 KB and 64 KB — smaller than one record: 30 000-nt sequences wrapped at 70 — and through the mapping
+    (SWARM_AMD_INPUT=mmap) must give the same database; a late error must carry the same absolute line number."""
+    import hashlib
+    rng = np.random.default_rng(23)
+    lines = []
+    for i in range(40000):
+        L = 30000 if i % 9000 == 17 else 1 + int(rng.integers(0, 400))
+        seq = "".join(rng.choice(list("ACGT"), size=L))
+        lines.append(f">rec{i}_{1 + int(rng.integers(0, 30))}\n")
+        width = 70 if L > 1000 else int(rng.choice([60, 80, 1000]))
+        lines.extend(seq[at:at + width] + "\n" for at in range(0, L, width))
+    text = "".join(lines)
+    assert len(text) > 6 << 20                                 # (several parser threads, several buffers each)
+    fa = tmp_path / "streamed.fa"
+    fa.write_text(text)
+
+    def digest():
+        hdb = HostDb(fa)
+        d = hashlib.md5(hdb.seqs.tobytes() + hdb.seq_off.tobytes() + hdb.seqlen.tobytes() + hdb.abundance.tobytes()
+                        + b"".join(hdb.header(k) for k in range(0, hdb.n, 37))).hexdigest()
+        return hdb.n, d
+
+    monkeypatch.setenv("SWARM_AMD_INPUT", "mmap")
+    mapped = digest()
+    assert mapped[0] == 40000
+    monkeypatch.delenv("SWARM_AMD_INPUT")
+    assert digest() == mapped
+    for kb in ("1", "64"):
+        monkeypatch.setenv("SWARM_AMD_READ_CHUNK_KB", kb)
+        assert digest() == mapped, kb
+    db = S.db_from_fasta(fa)                                   # ... and the independent Python packer's
+    hdb = HostDb(fa)
+    assert np.array_equal(hdb.seqs, db.seqs[:len(hdb.seqs)]) and np.array_equal(hdb.seq_off, db.seq_off)
+    # an illegal character near the end: line number and text as the mapped reader gives them (which the tests above pin
+    # against the compiled reference)
+    bad = tmp_path / "bad.fa"
+    cut = text.rfind("\n>", 0, len(text) - 200000)
+    at = text.index("\n", cut + 2) + 5
+    bad.write_text(text[:at] + "!" + text[at + 1:])
+    errors = []
+    for env in ({"SWARM_AMD_INPUT": "mmap"}, {"SWARM_AMD_READ_CHUNK_KB": "1"}, {"SWARM_AMD_READ_CHUNK_KB": "64"}, {}):
+        monkeypatch.delenv("SWARM_AMD_INPUT", raising=False)
+        monkeypatch.delenv("SWARM_AMD_READ_CHUNK_KB", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pytest.raises(Exception) as e:
+            HostDb(bad)
+        errors.append(str(e.value))
+    assert "Illegal character '!'" in errors[0] and " on line " in errors[0]
+    assert all(x == errors[0] for x in errors), errors
+
+
 def test_repeated_sequences_in_a_large_file_for_d_above_one(tmp_path):
     """The d > 1 duplicate-sequence check (src/db.cc:763-790) goes through the same partitioned tables as the identifier check:
     a large file with three copies of one sequence and two of another ends in the reference's text (SWA_E_DUPLICATES), the
