@@ -773,10 +773,11 @@ def main() -> None:
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="development aid: run rank 0's share of an N-GPU job on this one GPU (no collectives); "
                          "the JSON line is marked simulated and is not a result")
-    ap.add_argument("--build", default="routed", choices=["routed", "streamed"],
-                    help="N > 1, owned sharding: 'routed' = every rank keys its own slice and the ids travel all-to-all to the "
-                         "owners of their keys (swa_d1_route_slice + swa_d1_index_build_routed); 'streamed' = every rank walks the "
-                         "whole replicated database for the keys it owns")
+    ap.add_argument("--build", default="records", choices=["records", "routed", "streamed"],
+                    help="N > 1, owned sharding: 'records' = every rank keys its own slice and the finished KEY RECORDS travel all-to-all "
+                         "to the owners, whose build starts at the partition (swa_d1_route_slice_records + swa_d1_index_build_records); "
+                         "'routed' = the ids travel and the owners key what they receive (rounds 4-5: swa_d1_route_slice + "
+                         "swa_d1_index_build_routed); 'streamed' = every rank walks the whole replicated database for the keys it owns")
     ap.add_argument("--shard", default="owned", choices=["owned", "range"],
                     help="N > 1: 'owned' = every rank serves the anchor groups it owns (swa_d1_set_ownership) and the "
                          "links are exchanged all-to-all by seed range; 'range' = every rank answers its contiguous query slice "
@@ -857,14 +858,27 @@ def main() -> None:
 
     # routed index build (owned sharding): a rank keys only its own slice, the ids travel all-to-all to the owners of
     # their keys, every rank builds its indexes from what it received — no rank walks the whole database
-    routed = owned and args.build == "routed"
+    routed = owned and args.build in ("routed", "records")
+    by_records = routed and args.build == "records"
     if routed:
         w_all = sim_world or world
         route_cap = 3 * count // (2 * w_all) + 1024
-        d_route = torch.zeros(2 * w_all * route_cap, dtype=torch.int32, device=dev)
+        d_route = torch.zeros(2 * w_all * route_cap, dtype=torch.int64 if by_records else torch.int32, device=dev)
+        d_route_fp = torch.zeros(w_all * route_cap, dtype=torch.int32, device=dev) if by_records else None
         d_route_counts = torch.zeros(2 * w_all + 1, dtype=torch.int32, device=dev)
         sim_lists = None
-        if sim_world:
+        if sim_world and by_records:
+            inbox, inbox_fp = ([], []), []
+            for r, (f_r, c_r) in enumerate(parts):
+                ctx.d1_route_slice_records(f_r, c_r, w_all, d_route, d_route_fp, route_cap, d_route_counts)
+                cts = d_route_counts.tolist()
+                assert cts[2 * w_all] == 0
+                for index in range(2):
+                    k = index * w_all + rank
+                    inbox[index].append(d_route[k * route_cap: k * route_cap + cts[k]].clone())
+                inbox_fp.append(d_route_fp[rank * route_cap: rank * route_cap + cts[rank]].clone())
+            sim_lists = (torch.cat(inbox[0]).contiguous(), torch.cat(inbox_fp).contiguous(), torch.cat(inbox[1]).contiguous())
+        elif sim_world:
             # one GPU playing rank 0 of N: what the other ranks would send does not change from step to step — made once,
             # outside the timed region; the timed step routes rank 0's own slice and builds from the lists
             inbox = ([], [])
@@ -879,7 +893,12 @@ def main() -> None:
 
     def step(record: bool) -> None:
         # every rank checks its own slice for duplicate sequences; the flags are OR-ed below
-        if routed:
+        if by_records:
+            ctx.d1_route_slice_records(first, count, sim_world or world, d_route, d_route_fp, route_cap, d_route_counts)
+            rec_p, fp_p, rec_s = sim_lists if sim_world else sharding.exchange_routed_records(d_route, d_route_fp, d_route_counts, route_cap)
+            torch.cuda.current_stream(dev).synchronize()      # (the lists are torch's work; the context runs on its own stream)
+            dup = ctx.d1_index_build_records(rec_p, fp_p, rec_s)
+        elif routed:
             ctx.d1_route_slice(first, count, sim_world or world, d_route, route_cap, d_route_counts)
             ids_p, ids_s = sim_lists if sim_world else sharding.exchange_routed_ids(d_route, d_route_counts, route_cap)
             torch.cuda.current_stream(dev).synchronize()      # (the lists are torch's work; the context runs on its own stream)
@@ -1016,7 +1035,8 @@ def main() -> None:
                 "step": "swa_d1_index_build + swa_d1_network_device (B1 seam), db and CSR resident in HBM"
                         + ("; ownership by anchor group, links exchanged all-to-all by seed range, RCCL all-gather of CSR slices"
                            if world > 1 and owned else "; RCCL all-gather of CSR slices" if world > 1 else ""),
-                "build": ("routed index build (swa_d1_route_slice, all-to-all to the owners, swa_d1_index_build_routed)" if routed else "local"),
+                "build": ("key records routed to their owners (swa_d1_route_slice_records, all-to-all, swa_d1_index_build_records)" if by_records else
+                          "ids routed to their owners (swa_d1_route_slice, all-to-all, swa_d1_index_build_routed)" if routed else "local"),
                 "route": "streaming (d1_stream.inc)" if streaming else "table (round 2)",
                 "sharding": ("owned" if owned else "range") if (sim_world or world) > 1 else "none",
                 "neighbour_links": int(hits_seen[0]),

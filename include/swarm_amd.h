@@ -191,6 +191,16 @@ int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t w
                        uint32_t * d_counts);
 int swa_d1_index_build_routed(swa_ctx * ctx, const uint32_t * d_ids_prefix, uint32_t n_prefix, const uint32_t * d_ids_suffix,
                               uint32_t n_suffix, int * has_duplicates);
+/* The same three steps with the KEY RECORDS travelling instead of the ids (round 6; what the multi-GPU drivers use): the rank
+   that holds an amplicon's slice computes its key record (record key << 32 | id: 8 bytes) per index and, for the prefix
+   index, the 4-byte fingerprint of its sequence — a streaming pass over its own share of the packed database —, and the owner
+   of the key starts at the partition: it no longer fetches one random 64-byte line per received id out of a line array N
+   times its share.  d_records[(index * world + owner) * cap + ..], d_fingerprints[owner * cap + ..] (prefix index; same
+   places), d_counts as above.  12 + 8 bytes per amplicon through the exchange instead of 4 + 4. */
+int swa_d1_route_slice_records(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint64_t * d_records,
+                               uint32_t * d_fingerprints, uint64_t cap, uint32_t * d_counts);
+int swa_d1_index_build_records(swa_ctx * ctx, const uint64_t * d_records_prefix, const uint32_t * d_fingerprints_prefix, uint32_t n_prefix,
+                               const uint64_t * d_records_suffix, uint32_t n_suffix, int * has_duplicates);
 
 /* Neighbour lists of amplicons [first, first+count) as CSR: offsets[count+1],
    neighbours[offsets[count]]; row k = { j != first+k : seq_j is a microvariant of

@@ -74,7 +74,7 @@ EXPORTS = [
     "swa_abi_version", "swa_ctx_create", "swa_ctx_destroy", "swa_last_error", "swa_ctx_synchronize", "swa_ctx_warmup", "swa_ctx_warmup_for", "swa_d1_anchor_windows", "swa_d1_anchor_width",
     "swa_d1_network_resident", "swa_d1_network_fetch", "swa_d1_cluster_device", "swa_d1_cluster_fetch", "swa_d1_cluster_maxgen", "swa_d1_cluster_resident", "swa_d1_cluster_resident_lazy", "swa_d1_result_detach", "swa_d1_result_error", "swa_d1_result_prepare",
     "swa_d1_cluster_resident_prepared", "swa_host_pin", "swa_host_unpin", "swa_ctx_warmup_downloads",
-    "swa_db_upload", "swa_db_attach", "swa_db_stage_words", "swa_db_upload_unordered", "swa_hostdb_unordered_view", "swa_hostdb_read_fasta_staged", "swa_cli_main", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
+    "swa_db_upload", "swa_db_attach", "swa_db_stage_words", "swa_db_upload_unordered", "swa_hostdb_unordered_view", "swa_hostdb_read_fasta_staged", "swa_cli_main", "swa_d1_index_build", "swa_d1_index_build_range", "swa_d1_set_ownership", "swa_d1_route_slice", "swa_d1_index_build_routed", "swa_d1_route_slice_records", "swa_d1_index_build_records", "swa_d1_network", "swa_d1_network_edges_device", "swa_d1_network_device", "swa_d1_guard_retries",
     "swa_d1_debug_read", "swa_d1_table_size", "swa_search_uses_wavefront", "swa_d1_fastidious", "swa_d1_fastidious_shard", "swa_qgram_build", "swa_qgram_diff",
     "swa_qgram_debug_read", "swa_search_begin", "swa_search_do", "swa_timing_enable", "swa_timing_read",
     "swa_hostdb_read_fasta", "swa_hostdb_free", "swa_hostdb_error", "swa_hostdb_view", "swa_hostdb_nucleotides",
@@ -121,6 +121,8 @@ def load_library() -> C.CDLL:
     lib.swa_d1_set_ownership.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.swa_d1_route_slice.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.swa_d1_index_build_routed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+    lib.swa_d1_route_slice_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.swa_d1_index_build_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
     lib.swa_d1_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.swa_d1_table_size.argtypes = [C.c_void_p]
     lib.swa_d1_table_size.restype = C.c_uint64
@@ -475,6 +477,22 @@ class Context:
         dup = C.c_int(0)
         self._check(self.lib.swa_d1_index_build_routed(self.h, C.c_void_p(d_ids_prefix.data_ptr() if n_prefix else 0), n_prefix,
                                                        C.c_void_p(d_ids_suffix.data_ptr() if n_suffix else 0), n_suffix, C.byref(dup)),
+                    allow=(SWA_E_DUPLICATES,))
+        return bool(dup.value)
+
+    def d1_route_slice_records(self, first: int, count: int, world: int, d_records, d_fingerprints, cap: int, d_counts) -> None:
+        """Routed multi-GPU index build with the key records travelling, step 1 (swa_d1_route_slice_records): torch tensors
+        d_records int64 [2 * world * cap], d_fingerprints int32 [world * cap], d_counts int32 [2 * world + 1]."""
+        self._check(self.lib.swa_d1_route_slice_records(self.h, first, count, world, C.c_void_p(d_records.data_ptr()),
+                                                        C.c_void_p(d_fingerprints.data_ptr()), cap, C.c_void_p(d_counts.data_ptr())))
+
+    def d1_index_build_records(self, rec_prefix, fp_prefix, rec_suffix) -> bool:
+        """Step 3 (swa_d1_index_build_records): this rank's indexes from the key records (and the prefix side's fingerprints)
+        it received; ownership must be set.  Returns the duplicate flag of this rank's groups."""
+        dup = C.c_int(0)
+        n_p, n_s = int(rec_prefix.numel()), int(rec_suffix.numel())
+        self._check(self.lib.swa_d1_index_build_records(self.h, C.c_void_p(rec_prefix.data_ptr() if n_p else 0), C.c_void_p(fp_prefix.data_ptr() if n_p else 0), n_p,
+                                                        C.c_void_p(rec_suffix.data_ptr() if n_s else 0), n_s, C.byref(dup)),
                     allow=(SWA_E_DUPLICATES,))
         return bool(dup.value)
 

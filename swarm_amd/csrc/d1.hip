@@ -961,6 +961,7 @@ static int launch_abundance_rank(swa_ctx * ctx) {
 }
 
 __global__ void k_set_flags(uint32_t * flags, uint32_t unserved, uint32_t shortest_code) { flags[3] = unserved; flags[6] = shortest_code; }
+__global__ void k_set_guard_made(unsigned long long * guard, uint32_t made0, uint32_t made1) { guard[0] = made0; guard[1] = made1; }
 
 // ---- the streaming build (d1_stream.inc) ------------------------------------------------------
 enum { kSbLines = 0, kSbRec = 1, kSbFp = 5, kSbCnt = 8, kSbTile = 10, kSbStart = 12, kSbPartial = 14, kSbScal = 16,
@@ -1167,7 +1168,8 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   const uint32_t lq = ctx->lines_quads;
   uint64_t item_room = 0;
   const ListRegions regions = list_regions(ctx, &item_room);
-  const bool routed = ctx->route_ids[0] != nullptr;
+  const bool by_rec = ctx->route_rec[0] != nullptr;           // routed, and the key records themselves arrived: no k_keys pass
+  const bool routed = ctx->route_ids[0] != nullptr || by_rec;
   const uint64_t records = routed ? std::max<uint64_t>(std::max(ctx->route_m[0], ctx->route_m[1]), 1) : n;
   // buckets of ~10 000 records for k_group1: ONE partition level of up to 10 bits at 10 M amplicons
   const uint32_t target = kG1Target, level_bits = 10u;
@@ -1234,7 +1236,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   k.seqs = ctx->db.seqs; k.seq_off = ctx->db.seq_off;
   k.n = n;
   for (int i = 0; i < 2; ++i) {
-    k.list[i] = routed ? ctx->route_ids[i] : nullptr;
+    k.list[i] = routed && !by_rec ? ctx->route_ids[i] : nullptr;
     k.list_count[i] = routed ? ctx->route_m[i] : 0;
     k.rec[i] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i + 1].ptr);
   }
@@ -1256,12 +1258,16 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     hipLaunchKernelGGL(k_set_flags, dim3(1), dim3(1), 0, ctx->stream, dflags,
                        ctx->db_shortest < minlen ? 1u : 0u, 0xFFFFFFFFu - ctx->db_shortest);
   }
+  if (by_rec) {   // (the records were made by the ranks that hold the amplicons' slices: what k_keys would have counted)
+    hipLaunchKernelGGL(k_set_guard_made, dim3(1), dim3(1), 0, ctx->stream, k.guard, ctx->route_m[0], ctx->route_m[1]);
+  }
   // the first partition level's histogram is taken on the way (one read pass over the records less: 0.07 ms at 10 M);
   // not for routed id lists (their length is the device's to know), SWA_D1_KEYS_HIST=0: comparison switch
   const char * env_kh = getenv("SWA_D1_KEYS_HIST");
   const bool keys_hist = !routed && !(env_kh != nullptr && env_kh[0] == '0');
   swa_t0(ctx, 8);
-  if (keys_hist) {
+  if (by_rec) { /* nothing to key */ }
+  else if (keys_hist) {
     const uint32_t ntiles = (uint32_t)((records + j.tile - 1) / j.tile);
     for (int i = 0; i < 2; ++i) { k.hist_cnt[i] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt + i].ptr); }
     k.hist_bits = j.plan.bits[0]; k.hist_tile = j.tile; k.hist_ntiles = ntiles;
@@ -1279,7 +1285,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   for (int i = 0; i < 2; ++i) {
     j.buf[i][0] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i].ptr);
     j.buf[i][1] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i + 1].ptr);
-    j.in[i] = j.buf[i][1];
+    j.in[i] = by_rec ? ctx->route_rec[i] : j.buf[i][1];
     j.cstart0[i] = nullptr; j.cstride0[i] = routed ? ctx->route_m[i] : n;   // (one chunk: [0, records of this index))
     j.cnt[i] = static_cast<uint32_t *>(ctx->d_stream[kSbCnt + i].ptr);
     j.ctile[i] = static_cast<uint32_t *>(ctx->d_stream[kSbTile + i].ptr);
@@ -1290,7 +1296,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   // (the fingerprints travel with the prefix index only: index 1 has no second payload)
   j.buf_f[0][0] = static_cast<uint32_t *>(ctx->d_stream[kSbFp].ptr);
   j.buf_f[0][1] = static_cast<uint32_t *>(ctx->d_stream[kSbFp + 1].ptr);
-  j.in_f[0] = j.buf_f[0][1];
+  j.in_f[0] = by_rec ? ctx->route_fp : j.buf_f[0][1];
   j.starts_stride = e_start + 2;
   swa_t0(ctx, 9);
   SWA_TRY(run_partition(ctx, j));
@@ -1302,7 +1308,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     SWA_HIP(ctx, hipMemsetAsync(gsum, 0, 8 * sizeof(uint64_t), ctx->stream));
     GuardDbArgs gd{};
     gd.seqs = ctx->db.seqs; gd.seq_off = ctx->db.seq_off; gd.seqlen = ctx->db.seqlen; gd.n = n;
-    for (int i = 0; i < 2; ++i) { gd.list[i] = k.list[i]; gd.list_count[i] = k.list_count[i]; }
+    for (int i = 0; i < 2; ++i) { gd.list[i] = k.list[i]; gd.list_count[i] = routed ? ctx->route_m[i] : 0; gd.list_rec[i] = by_rec ? ctx->route_rec[i] : nullptr; }
     gd.owner_rank = k.owner_rank; gd.owner_world = k.owner_world; gd.win_a = win_a; gd.win_b = win_b; gd.nwin = k.nwin;
     gd.out = gsum;
     hipLaunchKernelGGL(k_guard_db, dim3((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u), dim3(256), 0, ctx->stream, gd);
@@ -1842,7 +1848,7 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
   // (groups left to the plain kernel — and, on a single GPU, sequences too short for two windows — are the ONLY reason: a
   // table of their members alone serves it — build_member_index)
   ctx->only_oversized = flags[1] == 0 && (flags[4] != 0 || flags[3] != 0) &&
-                        (flags[3] == 0 || (ctx->owner_world == 1u && ctx->route_ids[0] == nullptr && member_index_enabled()));
+                        (flags[3] == 0 || (ctx->owner_world == 1u && ctx->route_ids[0] == nullptr && ctx->route_rec[0] == nullptr && member_index_enabled()));
   ctx->over_mass = flags[5];
   return SWA_OK;
 }
@@ -1853,7 +1859,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   if (first > ctx->db.n || count > ctx->db.n - first) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_range: bad range"); }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   const uint32_t n = ctx->db.n;
-  ctx->index_first = first; ctx->index_count = count; ctx->index_routed = ctx->route_ids[0] != nullptr;   // (network_run_guarded repeats it)
+  ctx->index_first = first; ctx->index_count = count; ctx->index_routed = ctx->route_ids[0] != nullptr || ctx->route_rec[0] != nullptr;   // (network_run_guarded repeats it)
   ctx->d1_ready = false;
   ctx->csr_ready = false;                                   // (a resident network belongs to the index it was made from)
   ctx->anchor_ready = false;
@@ -1891,7 +1897,7 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
     uint32_t mass = 0, shortest = 0;
     SWA_TRY(ensure_anchor_windows(ctx));
     const uint32_t sampled = ctx->anchor_a;
-    const bool routed = ctx->route_ids[0] != nullptr;        // (the lists were made under these windows: no second thoughts)
+    const bool routed = ctx->route_ids[0] != nullptr || ctx->route_rec[0] != nullptr;        // (the lists were made under these windows: no second thoughts)
     SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &group_dups, &mass, &shortest));
     // Conserved flanks: when a noticeable part of the database sits in groups too large for LDS (everybody shares
     // the first or last 32 nt), the anchor windows move inwards, 32 nt at a time, as far as the shortest sequence
@@ -2331,6 +2337,52 @@ extern "C" int swa_d1_index_build_routed(swa_ctx * ctx, const uint32_t * d_ids_p
   ctx->route_ids[1] = n_suffix != 0 ? d_ids_suffix : &nothing; ctx->route_m[1] = n_suffix;
   const int rc = swa_d1_index_build_range(ctx, 0, ctx->db.n, has_duplicates);
   ctx->route_ids[0] = ctx->route_ids[1] = nullptr;
+  ctx->route_m[0] = ctx->route_m[1] = 0;
+  return rc;
+}
+
+// The same exchange with the KEY RECORDS travelling (d1_stream.inc: k_anchor_route_records): 8 bytes per amplicon and index and
+// 4 more for the prefix index's fingerprint; the owner's build starts at the partition.
+extern "C" int swa_d1_route_slice_records(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint64_t * d_records, uint32_t * d_fingerprints,
+                                          uint64_t cap, uint32_t * d_counts) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice_records: no database"); }
+  if (first > ctx->db.n || count > ctx->db.n - first) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice_records: bad range"); }
+  if (world == 0 || world > kRouteMaxWorld || d_records == nullptr || d_fingerprints == nullptr || d_counts == nullptr || cap == 0) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice_records: bad argument (1..64 ranks)");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
+  SWA_TRY(ensure_anchor_windows(ctx));
+  SWA_HIP(ctx, hipMemsetAsync(d_counts, 0, (2ull * world + 1) * sizeof(uint32_t), ctx->stream));
+  if (count != 0) {
+    hipLaunchKernelGGL(k_anchor_route_records, dim3(grid_for(ctx, (count + 3) / 4, 256, 8)), dim3(256), 0, ctx->stream,
+                       ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, first, count, world, ctx->anchor_a, ctx->anchor_b, ctx->anchor_w / 32u,
+                       reinterpret_cast<unsigned long long *>(d_records), d_fingerprints, cap, d_counts);
+  }
+  SWA_HIP(ctx, hipGetLastError());
+  SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the caller reads the counts next, maybe from another stream)
+  return SWA_OK;
+}
+
+extern "C" int swa_d1_index_build_records(swa_ctx * ctx, const uint64_t * d_rec_prefix, const uint32_t * d_fp_prefix, uint32_t n_prefix,
+                                          const uint64_t * d_rec_suffix, uint32_t n_suffix, int * has_duplicates) {
+  if (ctx == nullptr) { return SWA_E_ARG; }
+  if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_records: no database"); }
+  if (ctx->owner_world <= 1) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_records: call swa_d1_set_ownership(rank, world > 1) first"); }
+  if ((n_prefix != 0 && (d_rec_prefix == nullptr || d_fp_prefix == nullptr)) || (n_suffix != 0 && d_rec_suffix == nullptr)) {
+    return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_records: null list");
+  }
+  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  SWA_TRY(ensure_db_lengths(ctx));
+  static const unsigned long long nothing = 0;               // (an empty list still marks the build as routed)
+  static const uint32_t no_fp = 0;
+  ctx->route_rec[0] = n_prefix != 0 ? reinterpret_cast<const unsigned long long *>(d_rec_prefix) : &nothing; ctx->route_m[0] = n_prefix;
+  ctx->route_rec[1] = n_suffix != 0 ? reinterpret_cast<const unsigned long long *>(d_rec_suffix) : &nothing; ctx->route_m[1] = n_suffix;
+  ctx->route_fp = n_prefix != 0 ? d_fp_prefix : &no_fp;
+  const int rc = swa_d1_index_build_range(ctx, 0, ctx->db.n, has_duplicates);
+  ctx->route_rec[0] = ctx->route_rec[1] = nullptr;
+  ctx->route_fp = nullptr;
   ctx->route_m[0] = ctx->route_m[1] = 0;
   return rc;
 }

@@ -348,6 +348,9 @@ class DeviceArray:
     def data_ptr(self) -> int:
         return self.ptr.value
 
+    def numel(self) -> int:
+        return self.count
+
     def to_host(self, count: int | None = None) -> np.ndarray:
         out = np.empty(self.count if count is None else count, dtype=self.dtype)
         assert self.hip.hipDeviceSynchronize() == 0

@@ -21,10 +21,11 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("build", ["routed", "streamed"])
+@pytest.mark.parametrize("build", ["records", "routed", "streamed"])
 def test_two_ranks_gather_the_whole_network(build):
-    """build = routed: every rank keys its own slice, the ids travel all-to-all (sharding.exchange_routed_ids), the
-    indexes come from the lists; streamed: every rank walks the whole database for the keys it owns."""
+    """build = records (the default): every rank keys its own slice, the finished key records travel all-to-all
+    (sharding.exchange_routed_records), the owners start at the partition; routed: the ids travel (exchange_routed_ids) and
+    the owners key them again; streamed: every rank walks the whole database for the keys it owns."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(S.ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",

@@ -740,6 +740,118 @@ def test_pair_kernels_against_the_oracle_on_random_families(gpu_ctx, seed):
 
 
 @pytest.mark.parametrize("which,world", [("generated", 2), ("generated", 5), ("length_mix", 3), ("giant_groups", 2), ("flanks", 3)])
+def test_record_routed_index_build_equals_the_network(tmp_path, which, world):
+    """swa_d1_route_slice_records + swa_d1_index_build_records (round 6: what the multi-GPU drivers use): the rank that holds
+    an amplicon's slice makes its key records — and the prefix side's fingerprints —, they travel to the owners of their
+    keys (here: through the host, one context playing the ranks in turn), every owner starts at the partition.  The
+    records are the ones the owner's own k_keys would have made (the id-routed build of rounds 4-5, below, is the same
+    network); over the ranks every link appears exactly once; identical sequences are found by the one rank that owns
+    their prefix group, from the fingerprints that travelled."""
+    from swarm_amd import Context
+    if which == "generated":
+        fa = tmp_path / "in.fa"
+        S.gen_fasta(fa, 20000, 150, 43)
+        db = S.db_from_fasta(fa)
+    elif which == "flanks":
+        fa = tmp_path / "flank.fa"
+        _conserved_flank_set(fa, 20000, 77)
+        db = S.db_from_fasta(fa)
+    else:
+        db = _giant_group_db() if which == "giant_groups" else _length_mix_db()
+    woff, wnb, _ = _oracle_sorted_rows(db)
+    whole = _link_keys(woff, wnb)
+    ctx = Context(0)
+    try:
+        _upload(ctx, db)
+        n = db.n
+        cap = 3 * n // (2 * world) + 1024
+        bounds = [n * r // world for r in range(world + 1)]
+        inbox = [[[], [], []] for _ in range(world)]           # per owner: prefix records, suffix records, prefix fingerprints
+        d_rec, d_fp, d_counts = S.DeviceArray(2 * world * cap, np.uint64), S.DeviceArray(world * cap), S.DeviceArray(2 * world + 1)
+        for r in range(world):
+            ctx.d1_route_slice_records(bounds[r], bounds[r + 1] - bounds[r], world, d_rec, d_fp, cap, d_counts)
+            counts = d_counts.to_host()
+            assert counts[2 * world] == 0
+            rec, fp = d_rec.to_host(), d_fp.to_host()
+            for owner in range(world):
+                for index in range(2):
+                    k = index * world + owner
+                    inbox[owner][index].append(rec[k * cap: k * cap + counts[k]])
+                inbox[owner][2].append(fp[owner * cap: owner * cap + counts[owner]])
+        d_rec.free(); d_fp.free(); d_counts.free()
+        for index in range(2):                                 # every amplicon long enough went to exactly one owner per index
+            ids = np.sort(np.concatenate([np.concatenate(inbox[o][index]) for o in range(world)]) & np.uint64(0xFFFFFFFF))
+            assert (np.diff(ids.astype(np.int64)) > 0).all() and len(ids) <= n
+            for r in range(world):                             # ... and came from the slice that holds it
+                got = np.concatenate(inbox[r][index]) & np.uint64(0xFFFFFFFF)
+                assert len(got) == sum(len(x) for x in inbox[r][index])
+        parts = []
+        for rank in range(world):
+            lists = [np.concatenate(inbox[rank][0]).astype(np.uint64), np.concatenate(inbox[rank][2]).astype(np.uint32),
+                     np.concatenate(inbox[rank][1]).astype(np.uint64)]
+            assert len(lists[0]) == len(lists[1])
+            bufs = [S.DeviceArray(len(lists[0]), np.uint64), S.DeviceArray(len(lists[1])), S.DeviceArray(len(lists[2]), np.uint64)]
+            for b, l in zip(bufs, lists):
+                if len(l):
+                    b.from_host(l)
+            ctx.d1_set_ownership(rank, world)
+            assert ctx.d1_index_build_records(bufs[0], bufs[1], bufs[2]) is False
+            poff, pnb = ctx.d1_network()
+            parts.append(_link_keys(poff, pnb))
+            for b in bufs:
+                b.free()
+        merged = np.sort(np.concatenate(parts))
+        assert np.array_equal(merged, whole), (which, world)
+        if which in ("generated", "flanks"):
+            assert sum(len(p) > 0 for p in parts) == world
+    finally:
+        ctx.close()
+
+
+def test_record_routed_build_finds_identical_sequences(tmp_path):
+    """The duplicate check of a record-routed build rests on the fingerprints that travelled with the prefix-side records:
+    two identical sequences in DIFFERENT slices must be reported by the one rank that owns their prefix group."""
+    from swarm_amd import Context
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 6000, 150, 9)
+    recs = S.read_fasta(fa)
+    twin = (b"twin_1", recs[17][1])
+    db = S.build_db(recs + [twin])
+    world = 3
+    ctx = Context(0)
+    try:
+        _upload(ctx, db)
+        n = db.n
+        cap = 3 * n // (2 * world) + 1024
+        bounds = [n * r // world for r in range(world + 1)]
+        inbox = [[[], [], []] for _ in range(world)]
+        d_rec, d_fp, d_counts = S.DeviceArray(2 * world * cap, np.uint64), S.DeviceArray(world * cap), S.DeviceArray(2 * world + 1)
+        for r in range(world):
+            ctx.d1_route_slice_records(bounds[r], bounds[r + 1] - bounds[r], world, d_rec, d_fp, cap, d_counts)
+            counts, rec, fp = d_counts.to_host(), d_rec.to_host(), d_fp.to_host()
+            for owner in range(world):
+                for index in range(2):
+                    k = index * world + owner
+                    inbox[owner][index].append(rec[k * cap: k * cap + counts[k]])
+                inbox[owner][2].append(fp[owner * cap: owner * cap + counts[owner]])
+        found = []
+        for rank in range(world):
+            lists = [np.concatenate(inbox[rank][0]).astype(np.uint64), np.concatenate(inbox[rank][2]).astype(np.uint32),
+                     np.concatenate(inbox[rank][1]).astype(np.uint64)]
+            bufs = [S.DeviceArray(len(lists[0]), np.uint64), S.DeviceArray(len(lists[1])), S.DeviceArray(len(lists[2]), np.uint64)]
+            for b, l in zip(bufs, lists):
+                if len(l):
+                    b.from_host(l)
+            ctx.d1_set_ownership(rank, world)
+            found.append(ctx.d1_index_build_records(bufs[0], bufs[1], bufs[2]))
+            for b in bufs:
+                b.free()
+        assert sum(found) == 1, found
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("which,world", [("generated", 2), ("length_mix", 3), ("flanks", 3)])
 def test_routed_index_build_equals_the_network(tmp_path, which, world):
     """swa_d1_route_slice + swa_d1_index_build_routed: every rank keys only its slice, the ids travel to the owners of
     their keys (here: through the host, one context playing the ranks in turn), every rank builds its indexes from the
