@@ -26,6 +26,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
+#include <thread>
 
 namespace {
 
@@ -2749,17 +2751,33 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
   if (m < 64) { m = 64; }
 
   // role of every amplicon: 0 light, 1 heavy and in this shard's contiguous slice of the heavy ones, 2 neither
-  std::vector<uint8_t> role(n);
+  // (by blocks on a few threads: two serial passes over 10 M flags were 15 ms of this call, lease r6j)
+  std::unique_ptr<uint8_t[]> role(new uint8_t[n]);
   uint64_t n_light = 0, n_heavy_all = 0;
-  for (uint32_t i = 0; i < n; ++i) { if (is_light[i] != 0) { ++n_light; } else { ++n_heavy_all; } }
+  const unsigned blocks = n >= (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  std::vector<uint64_t> heavy_before(blocks + 1, 0);
+  auto in_blocks = [&](auto && body) {
+    std::vector<std::thread> team;
+    for (unsigned b = 1; b < blocks; ++b) { team.emplace_back([&, b] { body(b); }); }
+    body(0u);
+    for (auto & t : team) { t.join(); }
+  };
+  in_blocks([&](unsigned b) {
+    uint64_t heavy = 0;
+    for (uint64_t i = (uint64_t)n * b / blocks; i < (uint64_t)n * (b + 1) / blocks; ++i) { heavy += is_light[i] == 0 ? 1u : 0u; }
+    heavy_before[b + 1] = heavy;
+  });
+  for (unsigned b = 0; b < blocks; ++b) { heavy_before[b + 1] += heavy_before[b]; }
+  n_heavy_all = heavy_before[blocks];
+  n_light = n - n_heavy_all;
   const uint64_t lo = n_heavy_all * shard / nshards, hi = n_heavy_all * (shard + 1ull) / nshards;
-  {
-    uint64_t seen = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+  in_blocks([&](unsigned b) {
+    uint64_t seen = heavy_before[b];
+    for (uint64_t i = (uint64_t)n * b / blocks; i < (uint64_t)n * (b + 1) / blocks; ++i) {
       if (is_light[i] != 0) { role[i] = 0; }
       else { role[i] = (seen >= lo && seen < hi) ? 1 : 2; ++seen; }
     }
-  }
+  });
   const uint64_t n_heavy = hi - lo;
 
   // which pairs the pair route can take: k_fast_count's LDS set must hold the microvariants of the longest sequence
@@ -2778,7 +2796,7 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
   SWA_TRY(swa_reserve(ctx, ctx->d_list_b, (uint64_t(n) + 1) * sizeof(uint32_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_fcounters, 16 * sizeof(uint64_t)));
   SWA_TRY(swa_reserve(ctx, ctx->d_flags, 16 * sizeof(uint32_t)));
-  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_frole.ptr, role.data(), n, hipMemcpyHostToDevice, ctx->stream));
+  SWA_HIP(ctx, hipMemcpyAsync(ctx->d_frole.ptr, role.get(), n, hipMemcpyHostToDevice, ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_graft.ptr, 0xFF, uint64_t(n) * sizeof(uint32_t), ctx->stream));
   SWA_HIP(ctx, hipMemsetAsync(ctx->d_fcounters.ptr, 0, 16 * sizeof(uint64_t), ctx->stream));
   auto * fc = static_cast<unsigned long long *>(ctx->d_fcounters.ptr);

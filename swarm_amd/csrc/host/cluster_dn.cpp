@@ -29,9 +29,10 @@ struct swa_dn_result {
     uint32_t link_begin = 0, link_end = 0;   // this swarm's accepted pairs inside links[]
   };
   struct Link { uint32_t parent, child, diff, swarm, generation; };
-  std::vector<Member> order;
+  // (swa_vec: sized without a serial fill — the device route writes every entry from all threads, hostdb.h)
+  swa_vec<Member> order;
   std::vector<Swarm> swarms;
-  std::vector<Link> links;                // the -i lines, in acceptance order
+  swa_vec<Link> links;                    // the -i lines, in acceptance order
   uint64_t largest = 0, maxgenerations = 0;
   int64_t differences = 0;
   uint64_t pen_mismatch = 18, pen_gapopen = 24, pen_gapextend = 13;
@@ -123,15 +124,24 @@ static int cluster_on_device(swa_ctx * ctx, const swa_hostdb * db, int no_cluste
   int rc = swa_dn_graph_resident(ctx, no_cluster_breaking, &total);
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
   dn_stamp("graph: resident");
-  std::vector<uint32_t> swarmid(n), generation(n), parent(n), order(n), begins((size_t)n + 1);
-  std::vector<uint8_t> pdiff(n);
+  // (no serial zero fill of arrays the downloads overwrite: 40 MB of them at 1 M amplicons were a third of the 11 ms the
+  // tables below took, lease r6j; their pages faulted in by the team instead of the copying thread)
+  swa_vec<uint32_t> swarmid(n), generation(n), parent(n), order(n), begins((size_t)n + 1);
+  swa_vec<uint8_t> pdiff(n);
+  {
+    char * const arrays[] = {reinterpret_cast<char *>(swarmid.data()), reinterpret_cast<char *>(generation.data()), reinterpret_cast<char *>(parent.data()),
+                             reinterpret_cast<char *>(order.data())};
+    const int64_t pages = (int64_t)(((size_t)n * sizeof(uint32_t) + 4095) / 4096);
+#pragma omp parallel for schedule(static) num_threads(swa_host_team()) if (pages >= 256)
+    for (int64_t k = 0; k < pages; ++k) { for (char * a : arrays) { a[k * 4096] = 0; } }
+  }
   uint32_t nswarms = 0;
   rc = swa_d1_cluster_device(ctx, swarmid.data(), generation.data(), parent.data(), order.data(), begins.data(), n, &nswarms);
   dn_stamp("walk on the device: labels, generations, parents, order");
   if (rc == SWA_OK) { rc = swa_dn_parent_diffs(ctx, pdiff.data()); }
   if (rc != SWA_OK) { r->error = swa_last_error(ctx); return rc; }
   dn_stamp("parent differences");
-  std::vector<uint32_t> radius(n, 0), pos_of(n, 0);
+  swa_vec<uint32_t> radius(n), pos_of(n);                   // (both written for a member before any of its children reads them)
   r->order.resize(n);
   r->swarms.resize(nswarms);
   r->links.resize((size_t)n - nswarms);
@@ -337,15 +347,25 @@ extern "C" int swa_dn_write_swarms(const swa_dn_result * r, const swa_hostdb * d
   if (!o.ok()) { return SWA_E_ARG; }
   if (!r->order.empty()) {
     if (mothur) { o.str("swarm_"); o.u64((uint64_t)r->differences); o.put('\t'); o.u64(r->swarms.size()); o.put('\t'); }
-    bool first_swarm = true;
-    for (const auto & s : r->swarms) {
-      if (!first_swarm) { o.put(mothur ? '\t' : '\n'); }
-      first_swarm = false;
-      for (uint32_t k = s.begin; k < s.end; ++k) {
-        if (k != s.begin) { o.put(mothur ? ',' : ' '); }
-        swa_out::id(o, db, r->order[k].id, usearch != 0, append_abundance);
+    // Pieces of equal member counts, formatted by the team, written in order (out.h) — a member's identifier is three
+    // dependent random reads away (its entry pointer, the entry, the header text), asked for 24 / 16 / 8 members ahead:
+    // 1 M members took one thread 86 ms (lease r6j); the bytes are those of the serial loop.
+    const auto * order = r->order.data();
+    const size_t total = r->order.size();
+    auto format_range = [&](BufOut & sink, size_t begin, size_t end) {
+      for (size_t si = begin; si < end; ++si) {
+        const auto & s = r->swarms[si];
+        if (si != 0) { sink.put(mothur ? '\t' : '\n'); }
+        for (uint32_t k = s.begin; k < s.end; ++k) {
+          if ((size_t)k + 24 < total) { __builtin_prefetch(&db->ent[order[k + 24].id]); }
+          if ((size_t)k + 16 < total) { __builtin_prefetch(db->ent[order[k + 16].id]); }
+          if ((size_t)k + 8 < total) { __builtin_prefetch(db->hdr(order[k + 8].id)); }
+          if (k != s.begin) { sink.put(mothur ? ',' : ' '); }
+          swa_out::id(sink, db, order[k].id, usearch != 0, append_abundance);
+        }
       }
-    }
+    };
+    swa_format_in_weighted_pieces(o, r->swarms.size(), total >= 200000, [&](size_t k) { return (uint64_t)(r->swarms[k].end - r->swarms[k].begin); }, format_range);
     o.put('\n');
   }
   return SWA_OK;

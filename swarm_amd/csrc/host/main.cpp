@@ -15,6 +15,7 @@
 #include "../../../include/swarm_amd.h"
 #include "../../../include/swarm_amd_host.h"
 #include "pool.h"
+#include "hostdb.h"
 
 #include <getopt.h>
 #include <sys/resource.h>
@@ -480,7 +481,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       std::fprintf(g_log, "\nResults before fastidious processing:\n");
       std::fprintf(g_log, "Number of swarms:  %" PRIu64 "\n", sum[0]);
       std::fprintf(g_log, "Largest swarm:     %" PRIu64 "\n\n", sum[1]);
-      std::vector<uint8_t> is_light(n);
+      swa_vec<uint8_t> is_light(n);                         // (every entry is written by swa_d1_light_flags: each amplicon is in one swarm)
       uint64_t st[5];
       if (swa_d1_light_flags(res, o.boundary, is_light.data(), st) != SWA_OK) { die(swa_d1_result_error(res)); }
       phase(o, "Counting amplicons in heavy and light swarms");
@@ -502,7 +503,13 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
             bits = new_bits;
           }
         }
-        std::vector<uint32_t> graft(n);
+        swa_vec<uint32_t> graft(n);                         // (the download writes every entry; its pages are faulted in by all threads first:
+        {                                                   //  one thread's fill of 40 MB was 10 ms of this phase)
+          char * gp = reinterpret_cast<char *>(graft.data());
+          const int64_t pages = (int64_t)(((size_t)n * sizeof(uint32_t) + 4095) / 4096);
+#pragma omp parallel for schedule(static)
+          for (int64_t k = 0; k < pages; ++k) { gp[k * 4096] = 0; }
+        }
         uint64_t counters[8] = {};
         // the log line needs m and k before the passes run: same arithmetic as the library
         unsigned k = (unsigned)(0.4 * (double)bits);
