@@ -352,11 +352,11 @@ extern "C" int swa_d1_result_prepare(swa_ctx * ctx, const swa_hostdb * db, swa_d
   const char * how = std::getenv("SWARM_AMD_PIN_RESULTS");     // (experiments: "touch" = pages faulted in, not pinned)
   if (how != nullptr && std::strcmp(how, "touch") == 0) {
     std::memset(r->order.data(), 0, (size_t)db->n * sizeof(uint32_t));
-    std::memset(r->begin_tmp.data(), 0, ((size_t)db->n + 1) * sizeof(uint32_t));
     return SWA_OK;
   }
   r->pinned_order = swa_host_pin(ctx, r->order.data(), (size_t)db->n * sizeof(uint32_t)) == SWA_OK;
-  r->pinned_begin = swa_host_pin(ctx, r->begin_tmp.data(), ((size_t)db->n + 1) * sizeof(uint32_t)) == SWA_OK;
+  // (the swarms' bounds are a few hundred kilobytes of an array sized for the worst case: not pinned, not touched — 40 MB of
+  // pages this process would otherwise fault in and take apart again)
   if (std::getenv("SWARM_AMD_CLUSTER_TIMING") != nullptr) { std::fprintf(stderr, "[cluster] result arrays pinned: order %d, bounds %d\n", (int)r->pinned_order, (int)r->pinned_begin); }
   return SWA_OK;
 }
