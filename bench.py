@@ -616,16 +616,16 @@ def measured_ceilings() -> dict | None:
 
 def step_byte_model(n: int, links: int, index_levels: int, link_levels: int) -> dict:
     """Algorithmic bytes of the kernel groups of one streaming step: what each group has to read
-    and write given its inputs and outputs — 64-byte amplicon lines, 8-byte key records (+ 4-byte fingerprints on the
-    prefix index), 4-byte member ids, 8-byte links."""
+    and write given its inputs and outputs — 64-byte amplicon lines, 8-byte key records (round 6: no fingerprints travel
+    with the prefix index any more), 4-byte member ids, 8-byte links."""
     n, e = float(n), float(links)
     return {
-        "keys": 64 * n + 20 * n,                                   # lines in; two record arrays + fingerprints out
-        # per level: scatter in / out (two record sets + fingerprints) + a histogram pass over the records — which the first level
+        "keys": 64 * n + 16 * n,                                   # lines in; two record arrays out
+        # per level: scatter in / out (two record sets) + a histogram pass over the records — which the first level
         # does not have: k_keys takes its histogram on the way
-        "partition_keys": index_levels * (2 * 20 * n) + (index_levels - (0 if os.environ.get("SWA_D1_KEYS_HIST", "")[:1] == "0" else 1)) * 16 * n,
+        "partition_keys": index_levels * (2 * 16 * n) + (index_levels - (0 if os.environ.get("SWA_D1_KEYS_HIST", "")[:1] == "0" else 1)) * 16 * n,
         "partition_links": link_levels * (8 * e + 2 * 8 * e),
-        "groups": 20 * n + 8 * n,                                  # records + fingerprints in, members out (work items: a few %)
+        "groups": 16 * n + 8 * n,                                  # records in, members out (work items: a few %)
         "pairs0": 68 * n + 4 * e,                                  # id + line per member; half the links out
         "pairs1": 68 * n + 4 * e,
         "csr_rows": 8 * e + 4 * e + 8 * n,                         # links in; targets + offsets out
@@ -864,20 +864,18 @@ def main() -> None:
         w_all = sim_world or world
         route_cap = 3 * count // (2 * w_all) + 1024
         d_route = torch.zeros(2 * w_all * route_cap, dtype=torch.int64 if by_records else torch.int32, device=dev)
-        d_route_fp = torch.zeros(w_all * route_cap, dtype=torch.int32, device=dev) if by_records else None
         d_route_counts = torch.zeros(2 * w_all + 1, dtype=torch.int32, device=dev)
         sim_lists = None
         if sim_world and by_records:
-            inbox, inbox_fp = ([], []), []
+            inbox = ([], [])
             for r, (f_r, c_r) in enumerate(parts):
-                ctx.d1_route_slice_records(f_r, c_r, w_all, d_route, d_route_fp, route_cap, d_route_counts)
+                ctx.d1_route_slice_records(f_r, c_r, w_all, d_route, route_cap, d_route_counts)
                 cts = d_route_counts.tolist()
                 assert cts[2 * w_all] == 0
                 for index in range(2):
                     k = index * w_all + rank
                     inbox[index].append(d_route[k * route_cap: k * route_cap + cts[k]].clone())
-                inbox_fp.append(d_route_fp[rank * route_cap: rank * route_cap + cts[rank]].clone())
-            sim_lists = (torch.cat(inbox[0]).contiguous(), torch.cat(inbox_fp).contiguous(), torch.cat(inbox[1]).contiguous())
+            sim_lists = (torch.cat(inbox[0]).contiguous(), torch.cat(inbox[1]).contiguous())
         elif sim_world:
             # one GPU playing rank 0 of N: what the other ranks would send does not change from step to step — made once,
             # outside the timed region; the timed step routes rank 0's own slice and builds from the lists
@@ -894,10 +892,10 @@ def main() -> None:
     def step(record: bool) -> None:
         # every rank checks its own slice for duplicate sequences; the flags are OR-ed below
         if by_records:
-            ctx.d1_route_slice_records(first, count, sim_world or world, d_route, d_route_fp, route_cap, d_route_counts)
-            rec_p, fp_p, rec_s = sim_lists if sim_world else sharding.exchange_routed_records(d_route, d_route_fp, d_route_counts, route_cap)
+            ctx.d1_route_slice_records(first, count, sim_world or world, d_route, route_cap, d_route_counts)
+            rec_p, rec_s = sim_lists if sim_world else sharding.exchange_routed_records(d_route, d_route_counts, route_cap)
             torch.cuda.current_stream(dev).synchronize()      # (the lists are torch's work; the context runs on its own stream)
-            dup = ctx.d1_index_build_records(rec_p, fp_p, rec_s)
+            dup = ctx.d1_index_build_records(rec_p, rec_s)
         elif routed:
             ctx.d1_route_slice(first, count, sim_world or world, d_route, route_cap, d_route_counts)
             ids_p, ids_s = sim_lists if sim_world else sharding.exchange_routed_ids(d_route, d_route_counts, route_cap)
@@ -905,16 +903,26 @@ def main() -> None:
             dup = ctx.d1_index_build_routed(ids_p, int(ids_p.numel()), ids_s, int(ids_s.numel()))
         else:
             dup = ctx.d1_index_build(first, count)
+        # identical sequences are reported by whichever call meets them (include/swarm_amd.h): the index build when it builds a
+        # table, else the network call's prefix pass (SwaError SWA_E_DUPLICATES); the ranks' findings are OR-ed AFTER both,
+        # so that no rank leaves the others alone in a collective
+        from swarm_amd.capi import SWA_E_DUPLICATES, SwaError
+        total = 0
+        try:
+            if owned and (world > 1 or sim_world):
+                # (a rank of an ownership-sharded job hands its links on as a flat list: no CSR over every source of the job)
+                total = ctx.d1_network_edges_device(d_links, cap, False, q_first, q_count)
+            else:
+                total = ctx.d1_network_device(d_offsets, d_nb, cap, False, q_first, q_count)
+        except SwaError as e:
+            if e.code != SWA_E_DUPLICATES:
+                raise
+            dup = True
         if world > 1:
             dup_flag.fill_(1 if dup else 0)
             dist.all_reduce(dup_flag, op=dist.ReduceOp.MAX)
             dup = bool(dup_flag.item())
-        assert not dup
-        if owned and (world > 1 or sim_world):
-            # (a rank of an ownership-sharded job hands its links on as a flat list: no CSR over every source of the job)
-            total = ctx.d1_network_edges_device(d_links, cap, False, q_first, q_count)
-        else:
-            total = ctx.d1_network_device(d_offsets, d_nb, cap, False, q_first, q_count)
+        assert not dup, "identical sequences in the synthetic set"
         hits_seen[0] = total
         if world > 1:
             if owned:

@@ -136,19 +136,25 @@ void swa_host_unpin(void * ptr);
 
 /* ---- B1: d = 1 network --------------------------------------------------------- */
 /* The index the network calls work on — what the reference's hash_insert loop builds (src/algod1.cc:188-208,
-   1122-1150) — and its duplicate check: *has_duplicates != 0 (and SWA_E_DUPLICATES returned) when two amplicons have
-   identical sequences.  What is built depends on the database: sequences of 65..256 nt in abundance order get the two
-   anchor indexes of the streaming build (amplicons grouped by their first / last w nt, w = 32, 64 or 128: swa_d1_anchor_width; members, work lists and the
-   identical-sequence check in one pass over the amplicon lines: swarm_amd/csrc/d1_stream.inc) and nothing else; the
+   1122-1150).  IDENTICAL SEQUENCES (the reference: fatal inside that loop, src/algod1.cc:1131-1150) are reported with
+   SWA_E_DUPLICATES by whichever call meets them (round 6): the index build when it builds a table (*has_duplicates != 0:
+   the database-wide table, or the table of the members left to the plain kernel) — and otherwise the NETWORK call, whose
+   prefix pass compares the members of every group with one another anyway and sees two whose every word agrees for two
+   instructions a pair (rounds 3-5 ran a second hash table over sequence fingerprints inside the index build for that: a
+   quarter of its largest kernel).  A binding checks both return codes; the message is the reference's either way.
+   What is built depends on the database: sequences of 65..256 nt in abundance order get the two
+   anchor indexes of the streaming build (amplicons grouped by their first / last w nt, w = 32, 64 or 128: swa_d1_anchor_width; members and work lists
+   in one pass over the amplicon lines: swarm_amd/csrc/d1_stream.inc) and nothing else; the
    database-wide structures of the reference — Zobrist table (bit-identical, src/zobrist.cc:49-80), seqhash[]
    (src/db.cc:761), amplicon hash table + Bloom filter (src/hashtable.cc, src/bloompat.cc) — are built only for what
    needs them: sequences under 65 nt, groups too large for the pair kernels, a database not in abundance order, the
    debug readers. */
 int swa_d1_index_build(swa_ctx * ctx, int * has_duplicates);
-/* Multi-GPU form: the index covers the whole database as above, but only the amplicons of
-   [first, first + count) are checked for an identical twin (anywhere in the database).  A job
-   that gives every rank its slice and ORs the flags detects every duplicate exactly once more
-   cheaply than every rank checking everything.  Returns SWA_E_DUPLICATES like the above. */
+/* Range form: the index covers the whole database as above; a table-based duplicate check looks only at the amplicons of
+   [first, first + count) (their twin may be anywhere in the database).  On the pair route the network call reports a
+   pair of identical sequences when one of the two is a seed of that call — [first, first + count) of swa_d1_network*,
+   or, under swa_d1_set_ownership, any member of a group the rank owns: over the ranks every such pair is met by exactly
+   one of them; OR the codes. */
 int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t count, int * has_duplicates);
 /* Where the last index build put the two anchor windows that group the amplicons: out2 = {nt from the start, nt from
    the end}; (0, 0) = the first / last w nt, moved inwards (32-nt windows then) when those are (nearly) the same for everybody. */
@@ -192,21 +198,22 @@ int swa_d1_route_slice(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t w
 int swa_d1_index_build_routed(swa_ctx * ctx, const uint32_t * d_ids_prefix, uint32_t n_prefix, const uint32_t * d_ids_suffix,
                               uint32_t n_suffix, int * has_duplicates);
 /* The same three steps with the KEY RECORDS travelling instead of the ids (round 6; what the multi-GPU drivers use): the rank
-   that holds an amplicon's slice computes its key record (record key << 32 | id: 8 bytes) per index and, for the prefix
-   index, the 4-byte fingerprint of its sequence — a streaming pass over its own share of the packed database —, and the owner
-   of the key starts at the partition: it no longer fetches one random 64-byte line per received id out of a line array N
-   times its share.  d_records[(index * world + owner) * cap + ..], d_fingerprints[owner * cap + ..] (prefix index; same
-   places), d_counts as above.  12 + 8 bytes per amplicon through the exchange instead of 4 + 4. */
+   that holds an amplicon's slice computes its key record (record key << 32 | id: 8 bytes) per index — a streaming pass over
+   its own share of the packed database —, and the owner of the key starts at the partition: it no longer fetches one random
+   64-byte line per received id out of a line array N times its share.  d_records[(index * world + owner) * cap + ..],
+   d_counts as above.  8 + 8 bytes per amplicon through the exchange instead of 4 + 4. */
 int swa_d1_route_slice_records(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint64_t * d_records,
-                               uint32_t * d_fingerprints, uint64_t cap, uint32_t * d_counts);
-int swa_d1_index_build_records(swa_ctx * ctx, const uint64_t * d_records_prefix, const uint32_t * d_fingerprints_prefix, uint32_t n_prefix,
+                               uint64_t cap, uint32_t * d_counts);
+int swa_d1_index_build_records(swa_ctx * ctx, const uint64_t * d_records_prefix, uint32_t n_prefix,
                                const uint64_t * d_records_suffix, uint32_t n_suffix, int * has_duplicates);
 
 /* Neighbour lists of amplicons [first, first+count) as CSR: offsets[count+1],
    neighbours[offsets[count]]; row k = { j != first+k : seq_j is a microvariant of
    seq_(first+k) and (no_cluster_breaking or abundance[first+k] >= abundance[j]) },
    each neighbour once, ascending.  cap = capacity of `neighbours` in entries;
-   *total = entries needed.  SWA_E_CAPACITY if total > cap (offsets still valid). */
+   *total = entries needed.  SWA_E_CAPACITY if total > cap (offsets still valid).
+   SWA_E_DUPLICATES: two identical sequences among the seeds' groups (see swa_d1_index_build): like the reference, no
+   network then. */
 int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, uint32_t count,
                    uint64_t * offsets, uint32_t * neighbours, uint64_t cap, uint64_t * total);
 /* same, results left in HBM: d_offsets / d_neighbours are device pointers; only

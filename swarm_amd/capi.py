@@ -121,8 +121,8 @@ def load_library() -> C.CDLL:
     lib.swa_d1_set_ownership.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.swa_d1_route_slice.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.swa_d1_index_build_routed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
-    lib.swa_d1_route_slice_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-    lib.swa_d1_index_build_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+    lib.swa_d1_route_slice_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.swa_d1_index_build_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
     lib.swa_d1_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     lib.swa_d1_table_size.argtypes = [C.c_void_p]
     lib.swa_d1_table_size.restype = C.c_uint64
@@ -480,24 +480,39 @@ class Context:
                     allow=(SWA_E_DUPLICATES,))
         return bool(dup.value)
 
-    def d1_route_slice_records(self, first: int, count: int, world: int, d_records, d_fingerprints, cap: int, d_counts) -> None:
+    def d1_route_slice_records(self, first: int, count: int, world: int, d_records, cap: int, d_counts) -> None:
         """Routed multi-GPU index build with the key records travelling, step 1 (swa_d1_route_slice_records): torch tensors
-        d_records int64 [2 * world * cap], d_fingerprints int32 [world * cap], d_counts int32 [2 * world + 1]."""
-        self._check(self.lib.swa_d1_route_slice_records(self.h, first, count, world, C.c_void_p(d_records.data_ptr()),
-                                                        C.c_void_p(d_fingerprints.data_ptr()), cap, C.c_void_p(d_counts.data_ptr())))
+        d_records int64 [2 * world * cap], d_counts int32 [2 * world + 1]."""
+        self._check(self.lib.swa_d1_route_slice_records(self.h, first, count, world, C.c_void_p(d_records.data_ptr()), cap,
+                                                        C.c_void_p(d_counts.data_ptr())))
 
-    def d1_index_build_records(self, rec_prefix, fp_prefix, rec_suffix) -> bool:
-        """Step 3 (swa_d1_index_build_records): this rank's indexes from the key records (and the prefix side's fingerprints)
-        it received; ownership must be set.  Returns the duplicate flag of this rank's groups."""
+    def d1_index_build_records(self, rec_prefix, rec_suffix) -> bool:
+        """Step 3 (swa_d1_index_build_records): this rank's indexes from the key records it received; ownership must be set.
+        Returns the duplicate flag of the build (identical sequences inside the rank's prefix groups are met by the
+        network call: SwaError SWA_E_DUPLICATES there)."""
         dup = C.c_int(0)
         n_p, n_s = int(rec_prefix.numel()), int(rec_suffix.numel())
-        self._check(self.lib.swa_d1_index_build_records(self.h, C.c_void_p(rec_prefix.data_ptr() if n_p else 0), C.c_void_p(fp_prefix.data_ptr() if n_p else 0), n_p,
+        self._check(self.lib.swa_d1_index_build_records(self.h, C.c_void_p(rec_prefix.data_ptr() if n_p else 0), n_p,
                                                         C.c_void_p(rec_suffix.data_ptr() if n_s else 0), n_s, C.byref(dup)),
                     allow=(SWA_E_DUPLICATES,))
         return bool(dup.value)
 
+    def d1_has_duplicates(self, first: int = 0, count: int | None = None) -> bool:
+        """The reference's duplicate check over both calls that can meet identical sequences (include/swarm_amd.h): the
+        index build when it builds a table, else the network call's prefix pass.  (A test helper: index build + network.)"""
+        if self.d1_index_build(first, count):
+            return True
+        try:
+            self.d1_network(False, first, self.n - first if count is None else count)
+        except SwaError as e:
+            if e.code == SWA_E_DUPLICATES:
+                return True
+            raise
+        return False
+
     def d1_network(self, no_cluster_breaking: bool = False, first: int = 0, count: int | None = None):
-        """CSR over [first, first+count): (offsets u64[count+1], neighbours u32[total]), rows ascending."""
+        """CSR over [first, first+count): (offsets u64[count+1], neighbours u32[total]), rows ascending.
+        SwaError(SWA_E_DUPLICATES): identical sequences among the seeds' groups."""
         if count is None:
             count = self.n - first
         offsets = np.zeros(count + 1, dtype=np.uint64)

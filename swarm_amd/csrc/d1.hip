@@ -1108,16 +1108,16 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
         }                                                                                                                             \
         hipLaunchKernelGGL((k_part_scatter<M, 8192, B, 1024>), grid_t, dim3(1024), lds, ctx->stream, a);                              \
       } while (0)
-      if (j.buf_f[0][0] == nullptr && j.tile == 8192 && !bins1024) {
+      const bool payload = j.buf_f[0][0] != nullptr;           // (a second array travels with index 0's records: nobody's since round 6)
+      if (!payload && j.tile == 8192 && !bins1024) {
         if (last_level && j.out32[0] != nullptr) { SWA_SCATTER_WIDE(2, 512, 1); } else { SWA_SCATTER_WIDE(0, 512, 2); }
       }
       else if (last_level && j.out32[0] != nullptr) { SWA_SCATTER(2, 4096, 512); }
-      else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 8192) { SWA_SCATTER_WIDE(1, 1024, 0); }
-      else if (false) {
-      }
-      else if (j.buf_f[0][0] != nullptr && bins1024 && j.tile == 4096) { SWA_SCATTER(1, 4096, 1024); }
-      else if (j.buf_f[0][0] != nullptr && bins1024) { SWA_SCATTER(1, 2048, 1024); }
-      else if (j.buf_f[0][0] != nullptr) { SWA_SCATTER(1, 2048, 512); }
+      else if (bins1024 && j.tile == 8192) { if (payload) { SWA_SCATTER_WIDE(1, 1024, 0); } else { SWA_SCATTER_WIDE(0, 1024, 3); } }
+      else if (bins1024 && j.tile == 4096) { if (payload) { SWA_SCATTER(1, 4096, 1024); } else { SWA_SCATTER(0, 4096, 1024); } }
+      else if (bins1024) { if (payload) { SWA_SCATTER(1, 2048, 1024); } else { SWA_SCATTER(0, 2048, 1024); } }
+      else if (payload) { SWA_SCATTER(1, 2048, 512); }
+      else if (j.tile == 2048) { SWA_SCATTER(0, 2048, 512); }
       else { SWA_SCATTER(0, 4096, 512); }
 #undef SWA_SCATTER
 #undef SWA_SCATTER_WIDE
@@ -1205,7 +1205,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   e_partial = std::max<uint64_t>(e_partial, ((uint64_t)kListsPerIndex * buckets + 1) / kFlatChunk + 2);
   for (int i = 0; i < 2; ++i) {
     for (int h = 0; h < 2; ++h) { SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbRec + 2 * i + h], (records + 1) * sizeof(uint64_t))); }
-    SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbFp + i], (records + 1) * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbCnt + i], e_cnt * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbTile + i], e_tile * sizeof(uint32_t)));
     SWA_TRY(swa_reserve(ctx, ctx->d_stream[kSbStart + i], (2 * e_start + 4) * sizeof(uint64_t)));
@@ -1234,7 +1233,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   // ---- keys: records into the PONG halves (level 0 reads them from there), fingerprints likewise
   KeyArgs k{};
   k.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
-  k.line_quads = lq; k.reg_words = lq == 4u ? 5u : 7u;
+  k.line_quads = lq;
   k.seqs = ctx->db.seqs; k.seq_off = ctx->db.seq_off;
   k.n = n;
   for (int i = 0; i < 2; ++i) {
@@ -1242,7 +1241,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     k.list_count[i] = routed ? ctx->route_m[i] : 0;
     k.rec[i] = static_cast<unsigned long long *>(ctx->d_stream[kSbRec + 2 * i + 1].ptr);
   }
-  k.fp = static_cast<uint32_t *>(ctx->d_stream[kSbFp + 1].ptr);
   k.owner_rank = ctx->owner_rank; k.owner_world = ctx->owner_world;
   k.win_a = win_a; k.win_b = win_b; k.minlen = minlen; k.window_mode = window_mode;
   k.nwin = ctx->anchor_w / 32u;
@@ -1295,10 +1293,8 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     j.partial[i] = static_cast<uint32_t *>(ctx->d_stream[kSbPartial + i].ptr);
     j.total[i] = reinterpret_cast<uint32_t *>(scal + 8 + i);
   }
-  // (the fingerprints travel with the prefix index only: index 1 has no second payload)
-  j.buf_f[0][0] = static_cast<uint32_t *>(ctx->d_stream[kSbFp].ptr);
-  j.buf_f[0][1] = static_cast<uint32_t *>(ctx->d_stream[kSbFp + 1].ptr);
-  j.in_f[0] = by_rec ? ctx->route_fp : j.buf_f[0][1];
+  // (no second array travels with the records: the fingerprints of rounds 3-5 served k_group1's search for identical
+  // sequences, which the prefix pass of the pair kernels now does on the sequences themselves)
   j.starts_stride = e_start + 2;
   swa_t0(ctx, 9);
   SWA_TRY(run_partition(ctx, j));
@@ -1316,7 +1312,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     hipLaunchKernelGGL(k_guard_db, dim3((unsigned)grid_for(ctx, records, 256, 8), routed ? 2u : 1u), dim3(256), 0, ctx->stream, gd);
     GuardRecArgs gr{};
     for (int i = 0; i < 2; ++i) { gr.rec[i] = j.out[i]; gr.total[i] = j.total[i]; }
-    gr.fp = j.out_f[0];
     gr.out = gsum + 3;
     hipLaunchKernelGGL(k_guard_records, dim3((unsigned)grid_for(ctx, records, 256, 8), 2u), dim3(256), 0, ctx->stream, gr);
     ctx->guard_keys_pending = true;
@@ -1327,7 +1322,6 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   for (int i = 0; i < 2; ++i) {
     GroupIdx & x = g.g[i];
     x.rec = const_cast<unsigned long long *>(j.out[i]);
-    x.fp = i == 0 ? j.out_f[0] : nullptr;
     x.bstart = j.bstart[i];
     x.buckets = j.buckets;
     x.members = static_cast<uint32_t *>(ctx->d_stream[kSbMembers + i].ptr);
@@ -1337,12 +1331,8 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   g.pair_big = pair_big_limit(); g.group_cap = kStreamGroupCap;   // (the tiled pair kernel serves every group up to that)
   if (const char * env_cap = getenv("SWA_D1_GROUP_CAP")) { g.group_cap = std::max<uint32_t>(g.pair_big, (uint32_t)atoi(env_cap)); }   // (experiments)
   g.flags = dflags;
-  if (const char * e = getenv("SWA_D1_NO_DUP")) { g.no_dups = e[0] == '1' ? 1u : 0u; }   // (experiment)
   g.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
   g.over = static_cast<uint8_t *>(ctx->d_stream[kSbOver].ptr);
-  g.dup_first = dup_first; g.dup_count = dup_count;
-  g.lines = k.lines; g.line_quads = lq;
-  g.seqs = ctx->db.seqs; g.seq_off = ctx->db.seq_off; g.seqlen = ctx->db.seqlen;
   swa_t0(ctx, 10);
   {
     if (!ctx->g1_lds_opt_in) {
@@ -1555,6 +1545,7 @@ static int launch_network_anchored(swa_ctx * ctx, int ncb, uint32_t first, uint3
     a.window_mode = window_mode ? 1u : 0u;
     a.seg_staged = static_cast<uint32_t *>(ctx->d_seg_fill.ptr) + (uint64_t)(1 + pass) * seg_count(ctx);
     a.guard = static_cast<unsigned long long *>(ctx->d_guard.ptr);
+    a.flags = static_cast<uint32_t *>(ctx->d_flags.ptr);
     a.batch = pair_batch; a.shard_bits = shard_bits; a.sched_stride = sched_stride;
     a.ids = static_cast<const uint32_t *>(ctx->d_stream[kSbMembers + pass].ptr);
     a.lines = static_cast<const uint4 *>(ctx->d_stream[kSbLines].ptr);
@@ -2051,10 +2042,10 @@ static int guard_check(swa_ctx * ctx, const uint64_t * g, const uint64_t * got, 
   }
   if (ctx->stream_index && ctx->guard_keys_pending) {
     ctx->guard_keys_pending = false;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 2; ++i) {
       if (g[16 + i] != g[19 + i]) {
         snprintf(msg, sizeof(msg), "d=1 guard: the %s derived from the amplicon lines are not the ones the packed database gives (%016llx / %016llx)",
-                 i == 2 ? "sequence fingerprints" : (i == 0 ? "prefix-side key records" : "suffix-side key records"), (unsigned long long)g[19 + i],
+                 i == 0 ? "prefix-side key records" : "suffix-side key records", (unsigned long long)g[19 + i],
                  (unsigned long long)g[16 + i]);
         return swa_fail_msg(ctx, SWA_E_INTERNAL, msg);
       }
@@ -2107,6 +2098,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
   uint64_t n_edges = 0;
   uint64_t stream_link_cap = 0;
   bool clean = false;                                        // the last attempt ran to the end without a retry condition
+  bool twins = false;                                        // the prefix pass of the pair kernels met identical sequences
   for (int attempt = 0; attempt < 8 && !clean; ++attempt) {
     SWA_TRY(swa_reserve(ctx, ctx->d_edges, uint64_t(nseg) * ctx->seg_cap * sizeof(uint64_t)));
     // (the segment fills start at zero: the anchored route clears them with its other counters — one launch —, the plain one here)
@@ -2215,6 +2207,7 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     if (got[1] <= ctx->seg_cap) {
       clean = true;
       if (guarded) { SWA_TRY(guard_check(ctx, guard, got, csr_stream, csr_end, links_sorted, n_edges)); }
+      twins = guarded && reinterpret_cast<const uint32_t *>(status)[0] != 0u;     // (flags[0]: the prefix pass met two identical sequences)
       break;
     }
     // one wave found more hits than its segment holds: grow the segments and run again (rare).
@@ -2227,6 +2220,9 @@ static int network_run(swa_ctx * ctx, int no_cluster_breaking, uint32_t first, u
     return swa_fail_msg(ctx, SWA_E_DEVICE, "swa_d1_network: per-wave link segments still overflowed after 8 attempts");
   }
   *total = n_edges;
+  // Identical sequences (the reference: fatal while it fills its table, src/algod1.cc:1131-1150).  On the pair route they are
+  // met here — two members of a prefix group whose sequences agree word for word — not by the index build (round 6).
+  if (twins) { return swa_fail_msg(ctx, SWA_E_DUPLICATES, "some fasta entries have identical sequences"); }
   if (n_edges > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network: neighbour buffer too small"); }
   return SWA_OK;
 }
@@ -2343,14 +2339,14 @@ extern "C" int swa_d1_index_build_routed(swa_ctx * ctx, const uint32_t * d_ids_p
   return rc;
 }
 
-// The same exchange with the KEY RECORDS travelling (d1_stream.inc: k_anchor_route_records): 8 bytes per amplicon and index and
-// 4 more for the prefix index's fingerprint; the owner's build starts at the partition.
-extern "C" int swa_d1_route_slice_records(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint64_t * d_records, uint32_t * d_fingerprints,
-                                          uint64_t cap, uint32_t * d_counts) {
+// The same exchange with the KEY RECORDS travelling (d1_stream.inc: k_anchor_route_records): 8 bytes per amplicon and index;
+// the owner's build starts at the partition.
+extern "C" int swa_d1_route_slice_records(swa_ctx * ctx, uint32_t first, uint32_t count, uint32_t world, uint64_t * d_records, uint64_t cap,
+                                          uint32_t * d_counts) {
   if (ctx == nullptr) { return SWA_E_ARG; }
   if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice_records: no database"); }
   if (first > ctx->db.n || count > ctx->db.n - first) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice_records: bad range"); }
-  if (world == 0 || world > kRouteMaxWorld || d_records == nullptr || d_fingerprints == nullptr || d_counts == nullptr || cap == 0) {
+  if (world == 0 || world > kRouteMaxWorld || d_records == nullptr || d_counts == nullptr || cap == 0) {
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_route_slice_records: bad argument (1..64 ranks)");
   }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
@@ -2360,31 +2356,28 @@ extern "C" int swa_d1_route_slice_records(swa_ctx * ctx, uint32_t first, uint32_
   if (count != 0) {
     hipLaunchKernelGGL(k_anchor_route_records, dim3(grid_for(ctx, (count + 3) / 4, 256, 8)), dim3(256), 0, ctx->stream,
                        ctx->db.seqs, ctx->db.seq_off, ctx->db.seqlen, first, count, world, ctx->anchor_a, ctx->anchor_b, ctx->anchor_w / 32u,
-                       reinterpret_cast<unsigned long long *>(d_records), d_fingerprints, cap, d_counts);
+                       reinterpret_cast<unsigned long long *>(d_records), cap, d_counts);
   }
   SWA_HIP(ctx, hipGetLastError());
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the caller reads the counts next, maybe from another stream)
   return SWA_OK;
 }
 
-extern "C" int swa_d1_index_build_records(swa_ctx * ctx, const uint64_t * d_rec_prefix, const uint32_t * d_fp_prefix, uint32_t n_prefix,
-                                          const uint64_t * d_rec_suffix, uint32_t n_suffix, int * has_duplicates) {
+extern "C" int swa_d1_index_build_records(swa_ctx * ctx, const uint64_t * d_rec_prefix, uint32_t n_prefix, const uint64_t * d_rec_suffix, uint32_t n_suffix,
+                                          int * has_duplicates) {
   if (ctx == nullptr) { return SWA_E_ARG; }
   if (ctx->db.n == 0) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_records: no database"); }
   if (ctx->owner_world <= 1) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_records: call swa_d1_set_ownership(rank, world > 1) first"); }
-  if ((n_prefix != 0 && (d_rec_prefix == nullptr || d_fp_prefix == nullptr)) || (n_suffix != 0 && d_rec_suffix == nullptr)) {
+  if ((n_prefix != 0 && d_rec_prefix == nullptr) || (n_suffix != 0 && d_rec_suffix == nullptr)) {
     return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_index_build_records: null list");
   }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
   SWA_TRY(ensure_db_lengths(ctx));
   static const unsigned long long nothing = 0;               // (an empty list still marks the build as routed)
-  static const uint32_t no_fp = 0;
   ctx->route_rec[0] = n_prefix != 0 ? reinterpret_cast<const unsigned long long *>(d_rec_prefix) : &nothing; ctx->route_m[0] = n_prefix;
   ctx->route_rec[1] = n_suffix != 0 ? reinterpret_cast<const unsigned long long *>(d_rec_suffix) : &nothing; ctx->route_m[1] = n_suffix;
-  ctx->route_fp = n_prefix != 0 ? d_fp_prefix : &no_fp;
   const int rc = swa_d1_index_build_range(ctx, 0, ctx->db.n, has_duplicates);
   ctx->route_rec[0] = ctx->route_rec[1] = nullptr;
-  ctx->route_fp = nullptr;
   ctx->route_m[0] = ctx->route_m[1] = 0;
   return rc;
 }

@@ -453,6 +453,7 @@ extern "C" int swa_cli_main(int argc, char ** argv) {
       uint64_t total = 0;
       rc = swa_d1_network_resident(ctx, o.no_break ? 1 : 0, &total);
       if (rc != SWA_OK && preparing.joinable()) { preparing.join(); }
+      if (rc == SWA_E_DUPLICATES) { die(dup_text); }        // (identical sequences met by the prefix pass of the pair kernels)
       if (rc != SWA_OK) { die(swa_last_error(ctx)); }
       resident = true;
       if (!o.network.empty()) {

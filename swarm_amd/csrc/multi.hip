@@ -234,10 +234,10 @@ extern "C" int swa_multi_db_upload(swa_multi * m, const swa_db_view * host) {
 }
 
 // Index build of all ranks WITHOUT any of them walking the whole database (swa_d1_route_slice_records /
-// swa_d1_index_build_records): every rank keys its own slice, the finished key records (and the prefix side's fingerprints)
-// travel all-to-all — grouped ncclSend / ncclRecv over RCCL, device-to-device copies when the ranks share a device —, every
-// rank builds its indexes from what it received, starting at the partition (round 6: rounds 4-5 sent the ids and keyed them
-// again at the owner, one random line fetch each).
+// swa_d1_index_build_records): every rank keys its own slice, the finished key records travel all-to-all — grouped
+// ncclSend / ncclRecv over RCCL, device-to-device copies when the ranks share a device —, every rank builds its indexes
+// from what it received, starting at the partition (round 6: rounds 4-5 sent the ids and keyed them again at the owner,
+// one random line fetch each).
 // *routed = false when a destination region overflowed (never with hashed ownership): the caller builds the other way.
 static int routed_index_build(swa_multi * m, std::vector<int> & dup, bool * routed) {
   const int world = (int)m->ctx.size();
@@ -247,63 +247,46 @@ static int routed_index_build(swa_multi * m, std::vector<int> & dup, bool * rout
   for (int r = 0; r <= world; ++r) { first[(size_t)r] = (uint32_t)((uint64_t)n * (uint64_t)r / (uint64_t)world); }
   const uint64_t cap = 3ull * ((uint64_t)n / (uint64_t)world + 1) / (2ull * (uint64_t)world) + 1024;
   const size_t lists = 2 * (size_t)world;
-  // outbox of a rank: records of all (index, owner) regions, then the fingerprints of the prefix-side regions
-  const uint64_t out_fp_at = lists * cap * sizeof(uint64_t);
   std::vector<std::vector<uint32_t>> cnt((size_t)world, std::vector<uint32_t>(lists + 1, 0));
   int rc = on_all(m, [&](int r) {
     swa_ctx * c = m->ctx[(size_t)r];
     SWA_HIP(c, hipSetDevice(c->device));
     SWA_TRY(swa_d1_set_ownership(c, (uint32_t)r, (uint32_t)world));
-    SWA_TRY(swa_reserve(c, m->routed[(size_t)r], out_fp_at + (uint64_t)world * cap * sizeof(uint32_t)));
+    SWA_TRY(swa_reserve(c, m->routed[(size_t)r], lists * cap * sizeof(uint64_t)));
     SWA_TRY(swa_reserve(c, m->routed_counts[(size_t)r], (lists + 1) * sizeof(uint32_t)));
-    auto * base = static_cast<char *>(m->routed[(size_t)r].ptr);
     SWA_TRY(swa_d1_route_slice_records(c, first[(size_t)r], first[(size_t)r + 1] - first[(size_t)r], (uint32_t)world,
-                                       reinterpret_cast<uint64_t *>(base), reinterpret_cast<uint32_t *>(base + out_fp_at), cap,
-                                       static_cast<uint32_t *>(m->routed_counts[(size_t)r].ptr)));
+                                       static_cast<uint64_t *>(m->routed[(size_t)r].ptr), cap, static_cast<uint32_t *>(m->routed_counts[(size_t)r].ptr)));
     SWA_HIP(c, hipMemcpy(cnt[(size_t)r].data(), m->routed_counts[(size_t)r].ptr, (lists + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return (int)SWA_OK;
   });
   if (rc != SWA_OK) { return rc; }
   for (int r = 0; r < world; ++r) { if (cnt[(size_t)r][lists] != 0) { return SWA_OK; } }
-  // rank r receives, per index, the lists of the sources in rank order: inbox[r] = records [index 0: s = 0, 1, ..][index 1: ..],
-  // then the fingerprints of index 0 in the same order
+  // rank r receives, per index, the lists of the sources in rank order: inbox[r] = [index 0: s = 0, 1, ..][index 1: ..]
   std::vector<uint32_t> m0((size_t)world, 0), m1((size_t)world, 0);
-  std::vector<uint64_t> in_fp_at((size_t)world, 0);
   for (int r = 0; r < world; ++r) {
     for (int s2 = 0; s2 < world; ++s2) { m0[(size_t)r] += cnt[(size_t)s2][(size_t)r]; m1[(size_t)r] += cnt[(size_t)s2][(size_t)world + (size_t)r]; }
     swa_ctx * c = m->ctx[(size_t)r];
     if (hipSetDevice(c->device) != hipSuccess) { return fail(m, SWA_E_DEVICE, "hipSetDevice"); }
-    in_fp_at[(size_t)r] = ((uint64_t)m0[(size_t)r] + m1[(size_t)r] + 1) * sizeof(uint64_t);
-    rc = swa_reserve(c, m->inbox[(size_t)r], in_fp_at[(size_t)r] + ((uint64_t)m0[(size_t)r] + 1) * sizeof(uint32_t));
+    rc = swa_reserve(c, m->inbox[(size_t)r], ((uint64_t)m0[(size_t)r] + m1[(size_t)r] + 1) * sizeof(uint64_t));
     if (rc != SWA_OK) { return fail(m, rc, swa_last_error(c)); }
   }
   if (!m->comms.empty()) { NCCL_OK(m, swa_rccl().GroupStart()); }
   for (int r = 0; r < world; ++r) {
-    uint64_t at[2] = {0, m0[(size_t)r]}, fp_at = 0;
+    uint64_t at[2] = {0, m0[(size_t)r]};
     for (int s2 = 0; s2 < world; ++s2) {
       for (int index = 0; index < 2; ++index) {
         const size_t list = (size_t)index * (size_t)world + (size_t)r;
         const uint32_t count = cnt[(size_t)s2][list];
         if (count == 0) { continue; }
-        const auto * out = static_cast<const char *>(m->routed[(size_t)s2].ptr);
-        auto * in = static_cast<char *>(m->inbox[(size_t)r].ptr);
-        const uint64_t * src = reinterpret_cast<const uint64_t *>(out) + list * cap;
-        uint64_t * dst = reinterpret_cast<uint64_t *>(in) + at[index];
+        const uint64_t * src = static_cast<const uint64_t *>(m->routed[(size_t)s2].ptr) + list * cap;
+        uint64_t * dst = static_cast<uint64_t *>(m->inbox[(size_t)r].ptr) + at[index];
         at[index] += count;
-        const uint32_t * fsrc = reinterpret_cast<const uint32_t *>(out + out_fp_at) + (size_t)r * cap;
-        uint32_t * fdst = reinterpret_cast<uint32_t *>(in + in_fp_at[(size_t)r]) + fp_at;
-        if (index == 0) { fp_at += count; }
         if (!m->comms.empty()) {
           NCCL_OK(m, swa_rccl().Send(src, count, ncclUint64, r, m->comms[(size_t)s2], m->ctx[(size_t)s2]->stream));
           NCCL_OK(m, swa_rccl().Recv(dst, count, ncclUint64, s2, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
-          if (index == 0) {
-            NCCL_OK(m, swa_rccl().Send(fsrc, count, ncclUint32, r, m->comms[(size_t)s2], m->ctx[(size_t)s2]->stream));
-            NCCL_OK(m, swa_rccl().Recv(fdst, count, ncclUint32, s2, m->comms[(size_t)r], m->ctx[(size_t)r]->stream));
-          }
         } else {
           if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess ||
-              hipMemcpyAsync(dst, src, (size_t)count * sizeof(uint64_t), hipMemcpyDefault, m->ctx[(size_t)r]->stream) != hipSuccess ||
-              (index == 0 && hipMemcpyAsync(fdst, fsrc, (size_t)count * sizeof(uint32_t), hipMemcpyDefault, m->ctx[(size_t)r]->stream) != hipSuccess)) {
+              hipMemcpyAsync(dst, src, (size_t)count * sizeof(uint64_t), hipMemcpyDefault, m->ctx[(size_t)r]->stream) != hipSuccess) {
             return fail(m, SWA_E_DEVICE, "device-to-device copy of a routed record list failed");
           }
         }
@@ -319,10 +302,8 @@ static int routed_index_build(swa_multi * m, std::vector<int> & dup, bool * rout
   *routed = true;
   return on_all(m, [&](int r) {
     swa_ctx * c = m->ctx[(size_t)r];
-    const auto * in = static_cast<const char *>(m->inbox[(size_t)r].ptr);
-    const uint64_t * rec = reinterpret_cast<const uint64_t *>(in);
-    return swa_d1_index_build_records(c, rec, reinterpret_cast<const uint32_t *>(in + in_fp_at[(size_t)r]), m0[(size_t)r], rec + m0[(size_t)r], m1[(size_t)r],
-                                      &dup[(size_t)r]);
+    const uint64_t * in = static_cast<const uint64_t *>(m->inbox[(size_t)r].ptr);
+    return swa_d1_index_build_records(c, in, m0[(size_t)r], in + m0[(size_t)r], m1[(size_t)r], &dup[(size_t)r]);
   });
 }
 
@@ -359,6 +340,7 @@ extern "C" int swa_multi_d1_network(swa_multi * m, int no_cluster_breaking, uint
       rc2 = swa_d1_network_edges_device(c, no_cluster_breaking, 0, n, static_cast<uint64_t *>(m->links[(size_t)r].ptr),
                                         m->link_cap[(size_t)r], &count[(size_t)r]);
       if (rc2 == SWA_E_CAPACITY) { m->link_cap[(size_t)r] = count[(size_t)r] + 1024; continue; }
+      if (rc2 == SWA_E_DUPLICATES) { dup[(size_t)r] = 1; }     // (identical sequences inside a prefix group this rank owns: the pair pass met them)
       return rc2;
     }
   });

@@ -73,7 +73,6 @@ struct swa_ctx {
   // of the uploaded database rather than of one index build, kept until the next upload
   const uint32_t * route_ids[2] = {nullptr, nullptr};
   const unsigned long long * route_rec[2] = {nullptr, nullptr};   // routed by key records (swa_d1_index_build_records): no k_keys pass
-  const uint32_t * route_fp = nullptr;
   uint32_t route_m[2] = {0, 0};
   bool rank_ready = false;       // d_arank holds the abundance ranks of this database
   bool db_unordered = false;     // ... which is not in abundance order (the anchored passes are then not used)

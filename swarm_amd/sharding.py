@@ -162,15 +162,15 @@ def exchange_routed_ids(d_ids: torch.Tensor, d_counts: torch.Tensor, cap: int, g
     return torch.cat(pieces[0]).contiguous(), torch.cat(pieces[1]).contiguous()
 
 
-def exchange_routed_records(d_rec: torch.Tensor, d_fp: torch.Tensor, d_counts: torch.Tensor, cap: int, group=None):
+def exchange_routed_records(d_rec: torch.Tensor, d_counts: torch.Tensor, cap: int, group=None):
     """Routed index build with the KEY RECORDS travelling, step 2: what swa_d1_route_slice_records left on every rank — per
-    anchor index and owning rank the finished key records of the rank's own slice, d_rec[(index * world + owner) * cap + ..],
-    for the prefix index their fingerprints at the same places of d_fp — travels all-to-all; every rank gets back the
-    records of the groups it owns and starts its build at the partition (no keying pass over received ids).
+    anchor index and owning rank the finished key records of the rank's own slice, d_rec[(index * world + owner) * cap + ..]
+    — travels all-to-all; every rank gets back the records of the groups it owns and starts its build at the partition (no
+    keying pass over received ids).
 
-    Returns (records_prefix int64 [m0], fingerprints_prefix int32 [m0], records_suffix int64 [m1]): the arguments of
-    swa_d1_index_build_records.  Collectives: all-to-all of the 2 counts per pair of ranks, ONE all-to-all of the records of
-    both indexes (8 bytes each), one of the fingerprints (4 bytes, prefix index): 20 bytes per amplicon in all."""
+    Returns (records_prefix int64 [m0], records_suffix int64 [m1]): the arguments of swa_d1_index_build_records.
+    Collectives: all-to-all of the 2 counts per pair of ranks, ONE all-to-all of the records of both indexes (8 bytes each:
+    16 bytes per amplicon in all)."""
     world = dist.get_world_size(group)
     dev = d_rec.device
     assert int(d_counts[2 * world]) == 0, "swa_d1_route_slice_records: a destination region overflowed"
@@ -179,19 +179,15 @@ def exchange_routed_records(d_rec: torch.Tensor, d_fp: torch.Tensor, d_counts: t
     dist.all_to_all_single(recv, send, group=group)
     send_h, recv_h = send.tolist(), recv.tolist()
     regions = d_rec.view(2 * world, cap)
-    fregions = d_fp.view(world, cap)
     out_rec = torch.cat([regions[index * world + owner, :send_h[owner][index]] for owner in range(world) for index in range(2)])
-    out_fp = torch.cat([fregions[owner, :send_h[owner][0]] for owner in range(world)])
     got = torch.empty(sum(a + b for a, b in recv_h), dtype=d_rec.dtype, device=dev)
     dist.all_to_all_single(got, out_rec, output_split_sizes=[a + b for a, b in recv_h], input_split_sizes=[a + b for a, b in send_h],
                            group=group)
-    got_fp = torch.empty(sum(a for a, _ in recv_h), dtype=d_fp.dtype, device=dev)
-    dist.all_to_all_single(got_fp, out_fp, output_split_sizes=[a for a, _ in recv_h], input_split_sizes=[a for a, _ in send_h], group=group)
     pieces, at = ([], []), 0
     for a, b in recv_h:
         pieces[0].append(got[at: at + a]); pieces[1].append(got[at + a: at + a + b])
         at += a + b
-    return torch.cat(pieces[0]).contiguous(), got_fp.contiguous(), torch.cat(pieces[1]).contiguous()
+    return torch.cat(pieces[0]).contiguous(), torch.cat(pieces[1]).contiguous()
 
 
 def combine_grafts(graft_cand, counters, device=None, group=None):

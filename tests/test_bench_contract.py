@@ -110,6 +110,6 @@ def test_bench_defaults_without_a_gpu():
     import bench
     m = bench.step_byte_model(10_000_000, 17_000_000, 1, 2)
     assert set(m) == {"keys", "partition_keys", "partition_links", "groups", "pairs0", "pairs1", "csr_rows"}
-    assert m["keys"] == 84 * 10_000_000 and m["groups"] == 28 * 10_000_000
+    assert m["keys"] == 80 * 10_000_000 and m["groups"] == 24 * 10_000_000
     assert all(v > 0 for v in m.values())
     assert bench.VALU_PEAK_WAVE_INSTR_S == 256 * 4 * 0.5 * 2.4e9 and bench.HBM_PEAK_GBS == 8000.0

@@ -63,7 +63,36 @@ def test_duplicates_are_reported(gpu_ctx, tmp_path):
     fa.write_text(">a_3\nACGTACGTACGTAAAC\n>b_2\nACGTACGTACGTAAAC\n>c_1\nACGTACGTACGTAAAG\n")
     db = S.db_from_fasta(fa)
     _upload(gpu_ctx, db)
-    assert gpu_ctx.d1_index_build() is True
+    assert gpu_ctx.d1_has_duplicates() is True            # (16-nt reads: too short for windows, the table route's own check)
+
+
+def test_duplicates_are_reported_by_the_call_that_meets_them(gpu_ctx, tmp_path):
+    """Round 6: on the pair route identical sequences are met by the NETWORK call's prefix pass (two members of a prefix
+    group whose every word agrees), not by the index build (which ran a second hash table over fingerprints for them until
+    round 5): swa_d1_index_build is clean, swa_d1_network* returns SWA_E_DUPLICATES — equal lengths only, whatever the
+    position of the twin in its group, in groups of every size kind."""
+    from swarm_amd.capi import SWA_E_DUPLICATES, SwaError
+    fa = tmp_path / "in.fa"
+    S.gen_fasta(fa, 6000, 150, 12)
+    recs = S.read_fasta(fa)
+    clean = S.build_db(recs)
+    _upload(gpu_ctx, clean)
+    assert gpu_ctx.d1_index_build() is False
+    gpu_ctx.d1_network()                                           # no error
+    for victim in (0, 17, 2999, 5999):
+        dirty = S.build_db(recs + [(b"twin_1", recs[victim][1])])
+        _upload(gpu_ctx, dirty)
+        assert gpu_ctx.d1_index_build() is False                   # (nothing here builds a table)
+        with pytest.raises(SwaError) as e:
+            gpu_ctx.d1_network()
+        assert e.value.code == SWA_E_DUPLICATES
+        with pytest.raises(SwaError):
+            gpu_ctx.d1_network_resident()
+    # a sequence and its one-nucleotide-longer sibling whose extra nucleotide is an A (code 0: the packed words agree): not twins
+    base = recs[5][1].decode()
+    longer = S.build_db(recs + [(b"longer_1", (base + "A").encode())])
+    _upload(gpu_ctx, longer)
+    assert gpu_ctx.d1_has_duplicates() is False
 
 
 def test_star_with_many_neighbours(gpu_ctx, tmp_path):
@@ -288,8 +317,8 @@ def test_results_do_not_depend_on_stale_device_memory(tmp_path):
 
 
 def test_duplicate_check_by_slices(gpu_ctx, tmp_path):
-    """swa_d1_index_build_range: each slice reports the duplicates it contains (a twin anywhere in
-    the database counts), the OR over slices equals the whole-database answer."""
+    """Index build + network of a slice [first, first + count): the slice reports the duplicates it contains (a twin anywhere
+    in the database counts), the OR over slices equals the whole-database answer."""
     fa = tmp_path / "in.fa"
     S.gen_fasta(fa, 3000, 60, 81)
     recs = S.read_fasta(fa)
@@ -297,17 +326,17 @@ def test_duplicate_check_by_slices(gpu_ctx, tmp_path):
     recs.append((b"twin_1", dup_of))                       # identical to an amplicon in the middle of the db
     db = S.build_db(recs)
     _upload(gpu_ctx, db)
-    assert gpu_ctx.d1_index_build() is True
+    assert gpu_ctx.d1_has_duplicates() is True
     where = [i for i in range(db.n) if db.seq_str(i) == dup_of.decode().upper()]
     assert len(where) == 2
     flags = []
     for first, count in [(0, 1000), (1000, 1000), (2000, db.n - 2000)]:
-        got = gpu_ctx.d1_index_build(first, count)
+        got = gpu_ctx.d1_has_duplicates(first, count)            # (index build + network of that slice: whichever meets the twins)
         flags.append(got)
         assert got == any(first <= w < first + count for w in where)
     assert any(flags)
     _upload(gpu_ctx, S.db_from_fasta(fa))
-    assert [gpu_ctx.d1_index_build(f, c) for f, c in [(0, 1500), (1500, 1500)]] == [False, False]
+    assert [gpu_ctx.d1_has_duplicates(f, c) for f, c in [(0, 1500), (1500, 1500)]] == [False, False]
 
 
 def _link_keys(off, nb):
@@ -365,8 +394,8 @@ def test_ownership_partials_add_up_to_the_network(tmp_path, which, plain):
 
 
 def test_owner_ranks_find_duplicates_without_the_table(tmp_path):
-    """Index build under ownership: identical sequences share a prefix group, so exactly the rank
-    that owns it reports them; a clean database is clean on every rank."""
+    """Index build + network under ownership: identical sequences share a prefix group, so exactly the rank
+    that owns it meets them (its prefix pass); a clean database is clean on every rank."""
     from swarm_amd import Context
     fa = tmp_path / "in.fa"
     S.gen_fasta(fa, 5000, 150, 44)
@@ -381,9 +410,9 @@ def test_owner_ranks_find_duplicates_without_the_table(tmp_path):
             for rank in range(world):
                 ctx.d1_set_ownership(rank, world)
                 _upload(ctx, clean)
-                assert ctx.d1_index_build() is False
+                assert ctx.d1_has_duplicates() is False
                 _upload(ctx, dirty)
-                found.append(ctx.d1_index_build())
+                found.append(ctx.d1_has_duplicates())
             assert sum(found) == 1, found
     finally:
         ctx.close()
@@ -742,11 +771,10 @@ def test_pair_kernels_against_the_oracle_on_random_families(gpu_ctx, seed):
 @pytest.mark.parametrize("which,world", [("generated", 2), ("generated", 5), ("length_mix", 3), ("giant_groups", 2), ("flanks", 3)])
 def test_record_routed_index_build_equals_the_network(tmp_path, which, world):
     """swa_d1_route_slice_records + swa_d1_index_build_records (round 6: what the multi-GPU drivers use): the rank that holds
-    an amplicon's slice makes its key records — and the prefix side's fingerprints —, they travel to the owners of their
-    keys (here: through the host, one context playing the ranks in turn), every owner starts at the partition.  The
-    records are the ones the owner's own k_keys would have made (the id-routed build of rounds 4-5, below, is the same
-    network); over the ranks every link appears exactly once; identical sequences are found by the one rank that owns
-    their prefix group, from the fingerprints that travelled."""
+    an amplicon's slice makes its key records, they travel to the owners of their keys (here: through the host, one context
+    playing the ranks in turn), every owner starts at the partition.  The records are the ones the owner's own k_keys would
+    have made (the id-routed build of rounds 4-5, below, is the same network); over the ranks every link appears exactly
+    once."""
     from swarm_amd import Context
     if which == "generated":
         fa = tmp_path / "in.fa"
@@ -763,43 +791,16 @@ def test_record_routed_index_build_equals_the_network(tmp_path, which, world):
     ctx = Context(0)
     try:
         _upload(ctx, db)
-        n = db.n
-        cap = 3 * n // (2 * world) + 1024
-        bounds = [n * r // world for r in range(world + 1)]
-        inbox = [[[], [], []] for _ in range(world)]           # per owner: prefix records, suffix records, prefix fingerprints
-        d_rec, d_fp, d_counts = S.DeviceArray(2 * world * cap, np.uint64), S.DeviceArray(world * cap), S.DeviceArray(2 * world + 1)
-        for r in range(world):
-            ctx.d1_route_slice_records(bounds[r], bounds[r + 1] - bounds[r], world, d_rec, d_fp, cap, d_counts)
-            counts = d_counts.to_host()
-            assert counts[2 * world] == 0
-            rec, fp = d_rec.to_host(), d_fp.to_host()
-            for owner in range(world):
-                for index in range(2):
-                    k = index * world + owner
-                    inbox[owner][index].append(rec[k * cap: k * cap + counts[k]])
-                inbox[owner][2].append(fp[owner * cap: owner * cap + counts[owner]])
-        d_rec.free(); d_fp.free(); d_counts.free()
+        inbox = _route_records(ctx, db.n, world)
         for index in range(2):                                 # every amplicon long enough went to exactly one owner per index
             ids = np.sort(np.concatenate([np.concatenate(inbox[o][index]) for o in range(world)]) & np.uint64(0xFFFFFFFF))
-            assert (np.diff(ids.astype(np.int64)) > 0).all() and len(ids) <= n
-            for r in range(world):                             # ... and came from the slice that holds it
-                got = np.concatenate(inbox[r][index]) & np.uint64(0xFFFFFFFF)
-                assert len(got) == sum(len(x) for x in inbox[r][index])
+            assert (np.diff(ids.astype(np.int64)) > 0).all() and len(ids) <= db.n
         parts = []
         for rank in range(world):
-            lists = [np.concatenate(inbox[rank][0]).astype(np.uint64), np.concatenate(inbox[rank][2]).astype(np.uint32),
-                     np.concatenate(inbox[rank][1]).astype(np.uint64)]
-            assert len(lists[0]) == len(lists[1])
-            bufs = [S.DeviceArray(len(lists[0]), np.uint64), S.DeviceArray(len(lists[1])), S.DeviceArray(len(lists[2]), np.uint64)]
-            for b, l in zip(bufs, lists):
-                if len(l):
-                    b.from_host(l)
             ctx.d1_set_ownership(rank, world)
-            assert ctx.d1_index_build_records(bufs[0], bufs[1], bufs[2]) is False
+            assert _build_from_records(ctx, inbox[rank]) is False
             poff, pnb = ctx.d1_network()
             parts.append(_link_keys(poff, pnb))
-            for b in bufs:
-                b.free()
         merged = np.sort(np.concatenate(parts))
         assert np.array_equal(merged, whole), (which, world)
         if which in ("generated", "flanks"):
@@ -808,44 +809,64 @@ def test_record_routed_index_build_equals_the_network(tmp_path, which, world):
         ctx.close()
 
 
+def _route_records(ctx, n, world):
+    """steps 1 + 2 through the host: every slice routed, the record lists collected per owner: inbox[owner][index]"""
+    cap = 3 * n // (2 * world) + 1024
+    bounds = [n * r // world for r in range(world + 1)]
+    inbox = [[[], []] for _ in range(world)]
+    d_rec, d_counts = S.DeviceArray(2 * world * cap, np.uint64), S.DeviceArray(2 * world + 1)
+    for r in range(world):
+        ctx.d1_route_slice_records(bounds[r], bounds[r + 1] - bounds[r], world, d_rec, cap, d_counts)
+        counts = d_counts.to_host()
+        assert counts[2 * world] == 0
+        rec = d_rec.to_host()
+        for owner in range(world):
+            for index in range(2):
+                k = index * world + owner
+                got = rec[k * cap: k * cap + counts[k]]
+                assert ((got & np.uint64(0xFFFFFFFF)) >= bounds[r]).all() and ((got & np.uint64(0xFFFFFFFF)) < bounds[r + 1]).all()
+                inbox[owner][index].append(got)
+    d_rec.free(); d_counts.free()
+    return inbox
+
+
+def _build_from_records(ctx, lists) -> bool:
+    recs = [np.concatenate(lists[index]).astype(np.uint64) for index in range(2)]
+    bufs = [S.DeviceArray(len(r), np.uint64) for r in recs]
+    for b, r in zip(bufs, recs):
+        if len(r):
+            b.from_host(r)
+    try:
+        return ctx.d1_index_build_records(bufs[0], bufs[1])
+    finally:
+        for b in bufs:
+            b.free()
+
+
 def test_record_routed_build_finds_identical_sequences(tmp_path):
-    """The duplicate check of a record-routed build rests on the fingerprints that travelled with the prefix-side records:
-    two identical sequences in DIFFERENT slices must be reported by the one rank that owns their prefix group."""
+    """Two identical sequences in DIFFERENT slices of a record-routed job: the one rank that owns their prefix group meets them
+    in its network call (SWA_E_DUPLICATES), nobody else does."""
     from swarm_amd import Context
+    from swarm_amd.capi import SWA_E_DUPLICATES, SwaError
     fa = tmp_path / "in.fa"
     S.gen_fasta(fa, 6000, 150, 9)
     recs = S.read_fasta(fa)
-    twin = (b"twin_1", recs[17][1])
-    db = S.build_db(recs + [twin])
+    db = S.build_db(recs + [(b"twin_1", recs[17][1])])
     world = 3
     ctx = Context(0)
     try:
         _upload(ctx, db)
-        n = db.n
-        cap = 3 * n // (2 * world) + 1024
-        bounds = [n * r // world for r in range(world + 1)]
-        inbox = [[[], [], []] for _ in range(world)]
-        d_rec, d_fp, d_counts = S.DeviceArray(2 * world * cap, np.uint64), S.DeviceArray(world * cap), S.DeviceArray(2 * world + 1)
-        for r in range(world):
-            ctx.d1_route_slice_records(bounds[r], bounds[r + 1] - bounds[r], world, d_rec, d_fp, cap, d_counts)
-            counts, rec, fp = d_counts.to_host(), d_rec.to_host(), d_fp.to_host()
-            for owner in range(world):
-                for index in range(2):
-                    k = index * world + owner
-                    inbox[owner][index].append(rec[k * cap: k * cap + counts[k]])
-                inbox[owner][2].append(fp[owner * cap: owner * cap + counts[owner]])
+        inbox = _route_records(ctx, db.n, world)
         found = []
         for rank in range(world):
-            lists = [np.concatenate(inbox[rank][0]).astype(np.uint64), np.concatenate(inbox[rank][2]).astype(np.uint32),
-                     np.concatenate(inbox[rank][1]).astype(np.uint64)]
-            bufs = [S.DeviceArray(len(lists[0]), np.uint64), S.DeviceArray(len(lists[1])), S.DeviceArray(len(lists[2]), np.uint64)]
-            for b, l in zip(bufs, lists):
-                if len(l):
-                    b.from_host(l)
             ctx.d1_set_ownership(rank, world)
-            found.append(ctx.d1_index_build_records(bufs[0], bufs[1], bufs[2]))
-            for b in bufs:
-                b.free()
+            dup = _build_from_records(ctx, inbox[rank])
+            try:
+                ctx.d1_network()
+            except SwaError as e:
+                assert e.code == SWA_E_DUPLICATES
+                dup = True
+            found.append(dup)
         assert sum(found) == 1, found
     finally:
         ctx.close()

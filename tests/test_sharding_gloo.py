@@ -236,12 +236,10 @@ RECORD_WORKER = textwrap.dedent('''
     n = 10007
     owner = lambda ids, index: (ids * (2654435761 if index == 0 else 40503) >> 7) % world        # stands in for the key's owner
     key = lambda ids, index: (ids * 0x9E3779B1 + index) & 0xFFFFFFF8                              # ... for the record key
-    fp_of = lambda ids: ((ids * 2246822519) ^ (ids >> 3)) & 0x7FFFFFFF                            # ... for the fingerprint
     parts = sharding.partition_even(n, world)
     first, count = parts[rank]
     cap = 3 * count // (2 * world) + 1024
     d_rec = torch.zeros(2 * world * cap, dtype=torch.int64)
-    d_fp = torch.zeros(world * cap, dtype=torch.int32)
     d_counts = torch.zeros(2 * world + 1, dtype=torch.int32)
     mine = np.arange(first, first + count, dtype=np.int64)
     for index in range(2):
@@ -250,16 +248,12 @@ RECORD_WORKER = textwrap.dedent('''
             sel = mine[own == o]
             k = index * world + o
             d_rec[k * cap: k * cap + len(sel)] = torch.from_numpy((key(sel, index) << 32) | sel)
-            if index == 0:
-                d_fp[o * cap: o * cap + len(sel)] = torch.from_numpy(fp_of(sel).astype(np.int32))
             d_counts[k] = len(sel)
-    rec_p, fp_p, rec_s = sharding.exchange_routed_records(d_rec, d_fp, d_counts, cap)
+    rec_p, rec_s = sharding.exchange_routed_records(d_rec, d_counts, cap)
     everybody = np.arange(n, dtype=np.int64)
     for index, got in ((0, rec_p), (1, rec_s)):
         want = everybody[owner(everybody, index) == rank]                      # sources in rank order, ids ascending inside
         assert np.array_equal(got.numpy(), (key(want, index) << 32) | want), (rank, index)
-    want = everybody[owner(everybody, 0) == rank]
-    assert np.array_equal(fp_p.numpy().astype(np.int64), fp_of(want)), rank    # the fingerprints at their records' places
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
@@ -269,8 +263,7 @@ RECORD_WORKER = textwrap.dedent('''
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_routed_records_reach_their_owners(tmp_path, world):
     """sharding.exchange_routed_records: what swa_d1_route_slice_records leaves on every rank (key records of its slice by
-    owning rank and index, the prefix side's fingerprints beside them) arrives, all-to-all, as the arguments of
-    swa_d1_index_build_records — records and fingerprints in step."""
+    owning rank and index) arrives, all-to-all, as the arguments of swa_d1_index_build_records."""
     script = tmp_path / "record_worker.py"
     script.write_text(RECORD_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
