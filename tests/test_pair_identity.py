@@ -137,6 +137,7 @@ def kernel_pair_near(a: str, b: str, W: int, NW: int, PASS: int):
     apart = max(len(a), len(b)) - n
     total = min(f >> 1, n) + min(l >> 1, n)
     near = (total + 1 == n) if apart == 0 else (apart == 1 and total >= n)
+    kernel_pair_near.identical = PASS == 0 and apart == 0 and f == 0xFFFFFFFF and same       # (round 6: pair_near's fourth result)
     return ok and near and (same if PASS == 0 else not same)
 
 
@@ -196,3 +197,30 @@ def test_members_of_a_colliding_suffix_group_are_not_paired(NW):
         assert one_edit_apart(a, b)
         assert not kernel_pair_near(a, b, W, NW, 1)          # would be a pair of the suffix group by position, but the windows differ
         assert kernel_pair_near(a, b, W, NW, 0)              # the prefix group has it
+
+
+@pytest.mark.parametrize("W,NW", [(5, 1), (5, 2), (8, 2), (13, 4)])
+def test_the_prefix_pass_meets_identical_sequences_and_nothing_else(W, NW):
+    """Round 6: the reference's duplicate check (src/algod1.cc:1131-1150) as the prefix pass of the pair kernels sees it —
+    `identical` of pair_near<0>: equal lengths, the window dwords equal, no differing bit in the rest of the forward words.
+    True for a sequence and its copy; false for every pair that differs anywhere: one edit, an edit inside the window, an edit
+    in the LAST nucleotide, and a sequence against itself plus trailing A (code 0: the packed words agree, the lengths do not)."""
+    w = 32 * NW
+    rng = np.random.default_rng(7 * W + NW)
+    for trial in range(1500):
+        length = int(rng.integers(2 * w + 1, 32 * W))
+        alphabet = ["A", "AC", "ACGT"][trial % 3]
+        a = "".join(rng.choice(list(alphabet), length))
+        assert kernel_pair_near(a, a, W, NW, 0) is False and kernel_pair_near.identical is True
+        kernel_pair_near(a, a + "A", W, NW, 0)
+        assert kernel_pair_near.identical is False
+        b = _edit(rng, a)
+        if len(b) > 32 * W or len(b) < 2 * w or b == a:
+            continue
+        kernel_pair_near(a, b, W, NW, 0)
+        assert kernel_pair_near.identical is False, (a, b)
+        last = a[:-1] + ("C" if a[-1] != "C" else "G")
+        kernel_pair_near(a, last, W, NW, 0)
+        assert kernel_pair_near.identical is False
+        kernel_pair_near(a, a, W, NW, 1)                       # PASS 1 never reports identity (the prefix pass has)
+        assert kernel_pair_near.identical is False
