@@ -1165,8 +1165,11 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   ctx->stream_index = false;
   ctx->list_counts_ready = false;
   const uint32_t n = ctx->db.n;
+  swa_lap(ctx, "(build starts)");
   SWA_TRY(ensure_db_lengths(ctx));
+  swa_lap(ctx, "db lengths");
   SWA_TRY(ensure_lines(ctx));
+  swa_lap(ctx, "amplicon lines");
   const uint32_t lq = ctx->lines_quads;
   uint64_t item_room = 0;
   const ListRegions regions = list_regions(ctx, &item_room);
@@ -1225,6 +1228,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     for (int i = 0; i < 2; ++i) { clear_add(c, static_cast<uint32_t *>(ctx->d_stream[kSbKind + i].ptr) + (uint64_t)kListsPerIndex * buckets, sizeof(uint32_t)); }
     SWA_TRY(clear_launch(ctx, c));
   }
+  swa_lap(ctx, "buffers reserved, counters cleared");
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);                // (cleared by the caller: index build, or the retry)
   auto * scal = static_cast<uint64_t *>(ctx->d_stream[kSbScal].ptr);      // [0..3] level-0 chunk tables, [8 + i] totals (u32)
   const uint32_t win_a = ctx->anchor_a, win_b = ctx->anchor_b;
@@ -1280,6 +1284,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     hipLaunchKernelGGL(k_keys<false>, kgrid, dim3(256), 0, ctx->stream, k);
   }
   swa_t1(ctx, 8);
+  swa_lap(ctx, "k_keys");
 
   // ---- partition by the top bits of the key
   for (int i = 0; i < 2; ++i) {
@@ -1299,6 +1304,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   swa_t0(ctx, 9);
   SWA_TRY(run_partition(ctx, j));
   swa_t1(ctx, 9);
+  swa_lap(ctx, "key partition");
   if (!ctx->guard_keys_done) {
     // the guard's second opinion on the key records, once per uploaded database: from the packed database against what the
     // partition holds (k_guard_db / k_guard_records); compared at the next guard_check
@@ -1317,6 +1323,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
     ctx->guard_keys_pending = true;
   }
 
+  swa_lap(ctx, "guard: second opinion");
   // ---- groups
   GroupArgs g{};
   for (int i = 0; i < 2; ++i) {
@@ -1364,6 +1371,7 @@ static int build_stream_index(swa_ctx * ctx, uint32_t dup_first, uint32_t dup_co
   hipLaunchKernelGGL(k_flat_apply, grid_k, dim3(256), 0, ctx->stream, f);
   hipLaunchKernelGGL(k_group_lists, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, (uint64_t)ctx->num_cus * 8), 2), dim3(256), 0, ctx->stream, la);
   SWA_HIP(ctx, hipGetLastError());
+  swa_lap(ctx, "groups + work lists");
   ctx->list_regions_items = item_room;
   ctx->anchor_ready = true;
   ctx->stream_index = true;
@@ -1807,8 +1815,11 @@ static int build_owned_index(swa_ctx * ctx, uint32_t first, uint32_t count, bool
                              uint32_t * shortest = nullptr) {
   const uint32_t n = ctx->db.n;
   auto * dflags = static_cast<uint32_t *>(ctx->d_flags.ptr);
-  SWA_TRY(prepare_hashing(ctx));
+  swa_lap(ctx, "(owned index starts)");
+  // (no Zobrist table, no hash / XOR-stream arrays here: the pair route needs none of them — 240 MB of HBM at 10 M and an
+  // upload with its synchronisation per build; the member table and the database-wide table prepare them when they are built)
   SWA_TRY(launch_abundance_rank(ctx));
+  swa_lap(ctx, "abundance ranks");
   // a rank of a multi-GPU job answers for the groups it owns, whichever slice their members lie in (each pair of
   // identical sequences is seen by exactly one rank); a single GPU honours the slice it was asked about
   const uint32_t dup_first = ctx->owner_world > 1 ? 0u : first, dup_count = ctx->owner_world > 1 ? n : count;
@@ -1888,7 +1899,9 @@ extern "C" int swa_d1_index_build_range(swa_ctx * ctx, uint32_t first, uint32_t 
   if (ctx->anchor_usable && owned_index_enabled()) {
     bool needs_table = false;
     uint32_t mass = 0, shortest = 0;
+    swa_lap(ctx, "(index build: before the windows)");
     SWA_TRY(ensure_anchor_windows(ctx));
+    swa_lap(ctx, "anchor windows");
     const uint32_t sampled = ctx->anchor_a;
     const bool routed = ctx->route_ids[0] != nullptr || ctx->route_rec[0] != nullptr;        // (the lists were made under these windows: no second thoughts)
     SWA_TRY(build_owned_index(ctx, first, count, &needs_table, &group_dups, &mass, &shortest));

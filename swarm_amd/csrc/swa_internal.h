@@ -169,6 +169,10 @@ struct swa_ctx {
 
 int swa_fail(swa_ctx * ctx, int code, const char * what, hipError_t e);
 int swa_fail_msg(swa_ctx * ctx, int code, const std::string & msg);
+// SWARM_AMD_STEP_TIMING=1: wall-clock laps between the host-visible points of the d = 1 index build and network call, on
+// stderr (what a first step in a fresh process is made of; the device is synchronised at each lap, so the numbers are
+// not the pipelined step's)
+inline void swa_lap(swa_ctx * ctx, const char * what);
 int swa_reserve(swa_ctx * ctx, swa_dbuf & buf, size_t bytes);   // grow-only hipMalloc
 void swa_release(swa_dbuf & buf);
 int swa_hash_sequences(swa_ctx * ctx);                           // d1.hip: Zobrist table + d_seqhash + d_aux
@@ -267,3 +271,14 @@ __device__ __forceinline__ uint64_t swa_variant_word(const uint64_t * seed, uint
 }
 
 #endif  // __HIPCC__
+
+#include <chrono>
+inline void swa_lap(swa_ctx * ctx, const char * what) {
+  static const bool on = std::getenv("SWARM_AMD_STEP_TIMING") != nullptr;
+  if (!on) { return; }
+  static auto last = std::chrono::steady_clock::now();
+  (void)hipStreamSynchronize(ctx->stream);
+  const auto now = std::chrono::steady_clock::now();
+  std::fprintf(stderr, "[step] %-34s %8.3f ms\n", what, 1e3 * std::chrono::duration<double>(now - last).count());
+  last = std::chrono::steady_clock::now();
+}
