@@ -140,20 +140,20 @@ extern "C" int swa_ctx_warmup(swa_ctx * ctx) { return swa_ctx_warmup_for(ctx, -1
 // loads and uploads of its start-up — not in front of the first result it waits for.
 extern "C" int swa_ctx_warmup_downloads(swa_ctx * ctx) {
   if (ctx == nullptr) { return SWA_E_ARG; }
-  SWA_HIP(ctx, hipSetDevice(ctx->device));
+  // (called beside the context's owner at work: the status comes back, the context's error text is not touched from here)
+  if (hipSetDevice(ctx->device) != hipSuccess) { return SWA_E_DEVICE; }
   constexpr size_t kBytes = 256u << 10;
   void * d = nullptr, * h = nullptr;
   hipStream_t s = nullptr;
-  SWA_HIP(ctx, hipMalloc(&d, kBytes));
-  if (hipHostMalloc(&h, kBytes, hipHostMallocDefault) != hipSuccess) { (void)hipFree(d); return swa_fail_msg(ctx, SWA_E_NOMEM, "swa_ctx_warmup_downloads: no pinned memory"); }
+  if (hipMalloc(&d, kBytes) != hipSuccess) { return SWA_E_NOMEM; }
+  if (hipHostMalloc(&h, kBytes, hipHostMallocDefault) != hipSuccess) { (void)hipFree(d); return SWA_E_NOMEM; }
   hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   if (e == hipSuccess) { e = hipMemcpyAsync(h, d, kBytes, hipMemcpyDeviceToHost, s); }
   if (e == hipSuccess) { e = hipStreamSynchronize(s); }
   if (s != nullptr) { (void)hipStreamDestroy(s); }
   (void)hipHostFree(h);
   (void)hipFree(d);
-  if (e != hipSuccess) { return swa_fail(ctx, SWA_E_DEVICE, "swa_ctx_warmup_downloads", e); }
-  return SWA_OK;
+  return e == hipSuccess ? SWA_OK : SWA_E_DEVICE;
 }
 
 extern "C" void swa_ctx_destroy(swa_ctx * ctx) {
@@ -387,9 +387,10 @@ extern "C" int swa_db_upload_unordered(swa_ctx * ctx, const swa_db_unordered_vie
 // Any thread may call these; the memory stays the caller's.
 extern "C" int swa_host_pin(swa_ctx * ctx, void * ptr, size_t bytes) {
   if (ctx == nullptr || ptr == nullptr || bytes == 0) { return SWA_E_ARG; }
-  SWA_HIP(ctx, hipSetDevice(ctx->device));
-  SWA_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-  return SWA_OK;
+  // (a helper thread's call, beside the context's owner at work: the status comes back, the context's error text is not
+  // touched from here)
+  if (hipSetDevice(ctx->device) != hipSuccess) { return SWA_E_DEVICE; }
+  return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? SWA_OK : SWA_E_DEVICE;
 }
 extern "C" void swa_host_unpin(void * ptr) { if (ptr != nullptr) { (void)hipHostUnregister(ptr); } }
 
