@@ -166,6 +166,8 @@ extern "C" int swa_d1_network_fetch(swa_ctx * ctx, uint64_t * offsets, uint32_t 
   if (!ctx->csr_ready) { return swa_fail_msg(ctx, SWA_E_ARG, "swa_d1_network_fetch: no resident network"); }
   if (ctx->csr_total > cap) { return swa_fail_msg(ctx, SWA_E_CAPACITY, "swa_d1_network_fetch: neighbour buffer too small"); }
   SWA_HIP(ctx, hipSetDevice(ctx->device));
+  swa_touch_pages(offsets, ((uint64_t)ctx->db.n + 1) * sizeof(uint64_t));
+  swa_touch_pages(neighbours, ctx->csr_total * sizeof(uint32_t));
   SWA_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_offsets_tmp.ptr, ((uint64_t)ctx->db.n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   if (ctx->csr_total != 0) {
     SWA_HIP(ctx, hipMemcpyAsync(neighbours, ctx->d_nb_tmp.ptr, ctx->csr_total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -282,6 +284,7 @@ extern "C" int swa_d1_cluster_device(swa_ctx * ctx, uint32_t * swarmid, uint32_t
   if (parent != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(parent, par, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
   SWA_HIP(ctx, hipGetLastError());
   if (timing) { SWA_HIP(ctx, hipStreamSynchronize(ctx->stream)); lap("keys, sort, bounds", gbits + sbits); }
+  for (uint32_t * out : {swarmid, generation, parent, order}) { swa_touch_pages(out, (uint64_t)n * sizeof(uint32_t)); }   // (pinned pages: nothing to do)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   if (timing) { for (auto & e : ev) { (void)hipEventCreate(&e); } (void)hipEventRecord(ev[0], ctx->stream); }
   SWA_HIP(ctx, hipMemcpyAsync(order, ids_out, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -312,6 +315,7 @@ extern "C" int swa_d1_cluster_fetch(swa_ctx * ctx, uint32_t * swarmid, uint32_t 
   const uint32_t n = ctx->db.n;
   const auto * label = static_cast<const uint32_t *>(ctx->d_cluster.ptr);
   const uint32_t * gen = label + n, * par = gen + n, * sid = par + n;
+  for (uint32_t * out : {swarmid, generation, parent}) { swa_touch_pages(out, (uint64_t)n * sizeof(uint32_t)); }
   if (swarmid != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(swarmid, sid, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
   if (generation != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(generation, gen, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
   if (parent != nullptr) { SWA_HIP(ctx, hipMemcpyAsync(parent, par, (uint64_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }

@@ -2419,6 +2419,8 @@ extern "C" int swa_d1_network(swa_ctx * ctx, int no_cluster_breaking, uint32_t f
                                        static_cast<uint64_t *>(ctx->d_offsets_tmp.ptr),
                                        static_cast<uint32_t *>(ctx->d_nb_tmp.ptr), cap, total);
   if (rc != SWA_OK && rc != SWA_E_CAPACITY) { return rc; }
+  swa_touch_pages(offsets, (uint64_t(count) + 1) * sizeof(uint64_t));
+  if (rc == SWA_OK) { swa_touch_pages(neighbours, *total * sizeof(uint32_t)); }
   SWA_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_offsets_tmp.ptr, (uint64_t(count) + 1) * sizeof(uint64_t),
                               hipMemcpyDeviceToHost, ctx->stream));
   if (rc == SWA_OK && *total > 0) {
@@ -2827,6 +2829,7 @@ extern "C" int swa_d1_fastidious_shard(swa_ctx * ctx, const uint8_t * is_light, 
 
   uint64_t host_fc[8] = {};
   SWA_HIP(ctx, hipMemcpyAsync(host_fc, fc, sizeof(host_fc), hipMemcpyDeviceToHost, ctx->stream));
+  swa_touch_pages(graft_cand, uint64_t(n) * sizeof(uint32_t));
   SWA_HIP(ctx, hipMemcpyAsync(graft_cand, ctx->d_graft.ptr, uint64_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   counters[0] = host_fc[0];

@@ -70,17 +70,6 @@ void fill_parallel(V & v, size_t n, T value) {
   for (int64_t i = 0; i < (int64_t)n; ++i) { p[i] = value; }
 }
 
-// Pages of a freshly sized array faulted in by all threads (one byte a page), before a download lands in it: the runtime's
-// copy into pages that do not exist yet faults them one by one on its own thread — 40 MB: 3-5 ms instead of 1
-// (tools/experiments/d2h_cost.hip, lease r6g).
-template <class V>
-void touch_pages_parallel(V & v) {
-  char * p = reinterpret_cast<char *>(v.data());
-  const int64_t pages = (int64_t)((v.size() * sizeof(v[0]) + 4095) / 4096);
-#pragma omp parallel for schedule(static) num_threads(swa_host_team()) if (pages >= 1024)
-  for (int64_t k = 0; k < pages; ++k) { p[k * 4096] = 0; }
-}
-
 template <typename F>
 void for_each_member(const swa_d1_result * r, const swa_d1_result::Swarm & s, F && f) {
   for (uint32_t k = s.begin; k < s.end; ++k) { f(r->order[k]); }
@@ -118,7 +107,7 @@ bool need_details(const swa_d1_result * cr) {
   const uint32_t n = r->n;
   const swa_hostdb * db = r->lazy_db;
   r->swarmid.resize(n); r->parent.resize(n); r->generation.resize(n);
-  touch_pages_parallel(r->swarmid); touch_pages_parallel(r->parent); touch_pages_parallel(r->generation);
+  // (the fetch faults the arrays' pages in on the library's worker threads before the copies land: swa_touch_pages)
   fill_parallel(r->graft_cand, n, (uint32_t)SWA_NO_AMPLICON);
   if (swa_d1_cluster_fetch(r->lazy_ctx, r->swarmid.data(), r->generation.data(), r->parent.data()) != SWA_OK) {
     r->error = swa_last_error(r->lazy_ctx);
@@ -408,7 +397,6 @@ static int cluster_resident(swa_ctx * ctx, const swa_hostdb * db, swa_d1_result 
   if (prepared == nullptr) {
     r->order.resize(n);                                     // (every entry is written by the download below)
     r->begin_tmp.resize((size_t)n + 1);
-    touch_pages_parallel(r->order);
   }
   swa_vec<uint32_t> & begin = r->begin_tmp;
   lap("result arrays");
