@@ -297,9 +297,12 @@ __device__ __forceinline__ uint64_t window_at(const uint64_t * seq, uint32_t p) 
 
 // Lanes: as in k_align, lane t of a 32-lane group owns diagonal k = t - 1 - W (column - row),
 // lanes 0 and > 2W+1 are guards that stay invalid.  Offsets are columns (query positions).
+// G = lanes of a pair's group: 32, or — round 6 — 16 where the band fits (2 W + 3 <= 16: the default penalties up to d = 3
+// with the band cut to the diagonals a score <= T can reach): four pairs a wave instead of two.  The kernel waits on
+// dependent LDS round trips of a few active lanes; what a wave gets done per round trip is its pairs.
+template <int G>
 __global__ __launch_bounds__(128) void k_align_wfa(const WfaArgs w) {
   extern __shared__ uint64_t lds[];
-  constexpr int G = 32;
   constexpr int kGroups = 128 / G;
   const AlignArgs & a = w.a;
   const int group = threadIdx.x / G;
@@ -386,8 +389,8 @@ __global__ __launch_bounds__(128) void k_align_wfa(const WfaArgs w) {
       // finished when the end diagonal's furthest point is the last column (then row = dl too)
       const bool at_end = running && lane_in_band && k == kend && M == ql;
       const uint64_t endmask = __ballot(at_end);
-      // (a 64-lane wave holds two groups: look at this group's half only)
-      const uint64_t mine = (endmask >> ((threadIdx.x & 32u))) & 0xFFFFFFFFull;
+      // (a 64-lane wave holds 64 / G groups: look at this group's lanes only)
+      const uint64_t mine = (endmask >> ((threadIdx.x & 63u) & ~(uint32_t)(G - 1))) & ((1ull << G) - 1ull);
       if (running && mine != 0ull) { found = (int)i; running = false; }
       // (a lane only ever reads back the history it wrote itself: no synchronisation needed)
     }
@@ -629,11 +632,20 @@ int swa_align_launch(swa_ctx * ctx, uint32_t query, const uint32_t * d_queries, 
     w.steps = static_cast<const swa_wfa_step *>(ctx->d_wfa.ptr);
     w.nsteps = ctx->wfa_steps;
     w.ring = std::min<uint32_t>(ctx->wfa_ring != 0 ? ctx->wfa_ring : ctx->wfa_steps, ctx->wfa_steps);
-    uint64_t wblocks = ((uint64_t)max_count + 3) / 4;
+    // the diagonals a score <= T can reach: a gap of g columns costs open + g extend, so |k| <= (T - open) / extend — the band
+    // of the wavefront kernel (the banded kernels keep the wider T / extend + 1).  Where band + guards fit 16 lanes, a wave
+    // takes four pairs (SWA_ALIGN_WFA_LANES=32: two, as until round 5)
+    const uint64_t wfa_w = T >= go + ge ? (T - go) / ge : 0;
+    static const bool lanes32 = [] { const char * e = std::getenv("SWA_ALIGN_WFA_LANES"); return e != nullptr && std::atoi(e) == 32; }();
+    const bool narrow = !lanes32 && 2 * wfa_w + 3 <= 16;
+    const uint32_t per_block = narrow ? 8u : 4u;
+    if (narrow) { w.a.W = (int)wfa_w; }
+    uint64_t wblocks = ((uint64_t)max_count + per_block - 1) / per_block;
     if (wblocks > 2 * cap) { wblocks = 2 * cap; }
     if (wblocks < 1) { wblocks = 1; }
-    const size_t wlds = sizeof(uint64_t) * (size_t)a.maxwords * 8 + sizeof(uint16_t) * 4 * (size_t)w.ring * 3 * 32;
-    hipLaunchKernelGGL(k_align_wfa, dim3((unsigned)wblocks), dim3(128), wlds, ctx->stream, w);
+    const size_t wlds = sizeof(uint64_t) * (size_t)a.maxwords * 2 * per_block + sizeof(uint16_t) * per_block * (size_t)w.ring * 3 * (narrow ? 16 : 32);
+    if (narrow) { hipLaunchKernelGGL(k_align_wfa<16>, dim3((unsigned)wblocks), dim3(128), wlds, ctx->stream, w); }
+    else { hipLaunchKernelGGL(k_align_wfa<32>, dim3((unsigned)wblocks), dim3(128), wlds, ctx->stream, w); }
   } else if (generic) {
     a.W = W64 > 0x3FFFFFFF ? 0x3FFFFFFF : (int)W64;
     const uint32_t qcap = ctx->db.longest + 1u;
