@@ -407,6 +407,7 @@ __global__ __launch_bounds__(256) void k_dg_pairs_lds(const PairArgs a) {
         bool earlier = false, here = false;
 #pragma unroll
         for (int k2 = 0; k2 <= D; ++k2) {
+          if ((uint32_t)k2 > K) { continue; }                  // (wave-uniform: the windows behind this launch's are nobody's business here)
           const uint64_t wq = qrec[j].win[k2];
           bool hit = false;
 #pragma unroll
