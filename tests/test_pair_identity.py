@@ -114,10 +114,9 @@ def test_division_between_the_passes_covers_every_link_once():
 
 
 # ---- round 4: anchor windows of 32 NW nucleotides (NW = 1, 2, 4) --------------------------------------------------------
-def kernel_pair_near(a: str, b: str, W: int, NW: int, PASS: int):
-    """pair_near<PASS, W, NW> with `ends` (d1_anchor.inc), dword for dword: the first 2 NW forward dwords (PASS 0) / the top
-    2 NW end-aligned dwords (PASS 1) are compared for equality only, `same` is the equality of the head (PASS 0) or read off
-    the forward chain (PASS 1: first difference at or beyond nucleotide 32 NW)."""
+def kernel_pair_near_full(a: str, b: str, W: int, NW: int, PASS: int):
+    """pair_near<PASS, W, NW> with `ends` as rounds 4-5 had it: the window dwords for equality only, both chains over every
+    other dword.  Kept as the yardstick of the shortened chains below."""
     wa, ta = pack(a, W)
     wb, tb = pack(b, W)
     f = l = 0xFFFFFFFF
@@ -133,6 +132,39 @@ def kernel_pair_near(a: str, b: str, W: int, NW: int, PASS: int):
             l = min(l, ffbh(ta[k] ^ tb[k]) | (32 * (2 * W - 1 - k)))
     ok = tail == 0 if PASS == 1 else True
     same = head == 0 if PASS == 0 else f >= 64 * NW
+    n = min(len(a), len(b))
+    apart = max(len(a), len(b)) - n
+    total = min(f >> 1, n) + min(l >> 1, n)
+    near = (total + 1 == n) if apart == 0 else (apart == 1 and total >= n)
+    kernel_pair_near_full.identical = PASS == 0 and apart == 0 and f == 0xFFFFFFFF and same
+    return ok and near and (same if PASS == 0 else not same)
+
+
+def kernel_pair_near(a: str, b: str, W: int, NW: int, PASS: int):
+    """pair_near<PASS, W, NW> with `ends` (d1_anchor.inc), dword for dword, as round 6 has it.  PASS 0: the first 2 NW forward
+    dwords for equality only (`same`), the forward chain over the rest, the suffix chain WITHOUT the lowest 2 NW end-aligned
+    dwords.  PASS 1: the top 2 NW end-aligned dwords for equality only, the suffix chain over the rest, the forward chain
+    over the first 2 NW dwords ONLY (an empty chain = equal first windows = `same`)."""
+    wa, ta = pack(a, W)
+    wb, tb = pack(b, W)
+    f = l = 0xFFFFFFFF
+    head = tail = 0
+    for k in range(2 * W):
+        if PASS == 0:
+            if k < 2 * NW:
+                head |= wa[k] ^ wb[k]
+            else:
+                f = min(f, ffbl(wa[k] ^ wb[k]) | (32 * k))
+                l = min(l, ffbh(ta[k] ^ tb[k]) | (32 * (2 * W - 1 - k)))
+        else:
+            if k < 2 * NW:
+                f = min(f, ffbl(wa[k] ^ wb[k]) | (32 * k))
+            if k >= 2 * W - 2 * NW:
+                tail |= ta[k] ^ tb[k]
+            else:
+                l = min(l, ffbh(ta[k] ^ tb[k]) | (32 * (2 * W - 1 - k)))
+    ok = tail == 0 if PASS == 1 else True
+    same = head == 0 if PASS == 0 else f == 0xFFFFFFFF
     n = min(len(a), len(b))
     apart = max(len(a), len(b)) - n
     total = min(f >> 1, n) + min(l >> 1, n)
@@ -224,3 +256,43 @@ def test_the_prefix_pass_meets_identical_sequences_and_nothing_else(W, NW):
         assert kernel_pair_near.identical is False
         kernel_pair_near(a, a, W, NW, 1)                       # PASS 1 never reports identity (the prefix pass has)
         assert kernel_pair_near.identical is False
+
+
+@pytest.mark.parametrize("W,NW", [(5, 1), (5, 2), (8, 2), (15, 4), (21, 4)])
+def test_shortened_chains_answer_as_the_full_chains(W, NW):
+    """Round 6: the chains of pair_near leave out the dwords that cannot change the answer (the lowest 2 NW end-aligned dwords
+    in PASS 0, every forward dword beyond the first window in PASS 1).  Same answer and same `identical` as the full chains for
+    ANY two members a group may hold — every length from 2 w up to 32 W (members of a wide group may be much shorter than
+    the group's width), 0-3 edits anywhere, edits placed at the seams (around nucleotide w, around n - w, the last
+    nucleotide), unrelated sequences (a colliding key), runs and low-complexity alphabets."""
+    w = 32 * NW
+    rng = np.random.default_rng(1000 * W + NW)
+    checked = linked = 0
+    for trial in range(6000):
+        length = int(rng.integers(2 * w, 32 * W + 1)) if trial % 4 else int(rng.integers(2 * w, min(32 * W, 2 * w + 6) + 1))
+        alphabet = ["A", "AC", "ACGT", "ACGT"][trial % 4]
+        a = "".join(rng.choice(list(alphabet), length))
+        kind = trial % 5
+        if kind == 0:                                             # unrelated (only the lengths are close)
+            b = "".join(rng.choice(list(alphabet), max(2 * w, length + int(rng.integers(-1, 2)))))
+        elif kind == 1:                                           # one edit at a seam
+            at = [w - 1, w, w + 1, len(a) - w - 1, len(a) - w, len(a) - w + 1, len(a) - 1, 0][int(rng.integers(0, 8))]
+            at = min(max(at, 0), len(a) - 1)
+            how = int(rng.integers(0, 3))
+            ch = str(rng.choice(list("ACGT")))
+            b = a[:at] + ch + a[at + 1:] if how == 0 else (a[:at] + a[at + 1:] if how == 1 else a[:at] + ch + a[at:])
+        else:
+            b = a
+            for _ in range(int(rng.integers(0, 4))):
+                b = _edit(rng, b)
+        if not (2 * w <= len(b) <= 32 * W) or abs(len(a) - len(b)) > 1:
+            continue
+        for PASS in (0, 1):
+            for x, y in ((a, b), (b, a)):
+                full = kernel_pair_near_full(x, y, W, NW, PASS)
+                short = kernel_pair_near(x, y, W, NW, PASS)
+                assert short == full, (x, y, PASS)
+                assert kernel_pair_near.identical == kernel_pair_near_full.identical, (x, y, PASS)
+                linked += int(short)
+        checked += 1
+    assert checked > 3000 and linked > 500
