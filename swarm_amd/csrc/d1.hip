@@ -25,6 +25,7 @@
 #include "swa_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <memory>
 #include <thread>
@@ -1015,7 +1016,7 @@ static void part_scratch(const PartJob & j, uint64_t * cnt, uint64_t * ctile, ui
   for (uint32_t l = 0; l < j.plan.levels; ++l) {
     const uint64_t tiles = (l == 0 ? j.max_tiles0 : j.max_records / j.tile + chunks + 1);
     c_max = std::max(c_max, (tiles << j.plan.bits[l]) + 2);
-    t_max = std::max(t_max, chunks + 2);
+    t_max = std::max(t_max, chunks + 2 + tiles + 2);              // (the tile table of the chunks, and behind it the chunk of every tile)
     chunks = (single ? 1 : chunks) << j.plan.bits[l];
     single = false;
     s_max = std::max(s_max, chunks + 2);
@@ -1042,6 +1043,12 @@ static int clear_launch(swa_ctx * ctx, const ClearList & c) {
   return SWA_OK;
 }
 
+// (experiment: SWA_D1_LINK_SPAN=0 cuts the first level's tiles chunk by chunk, as rounds 3-5 did)
+static bool part_span_enabled() {
+  static const bool on = [] { const char * e = getenv("SWA_D1_LINK_SPAN"); return !(e != nullptr && e[0] == '0'); }();
+  return on;
+}
+
 static int run_partition(swa_ctx * ctx, PartJob & j) {
   uint64_t chunks = j.chunks0;
   bool single = j.single0;
@@ -1053,6 +1060,8 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
     const bool last_level = l + 1 == j.plan.levels;
     PartArgs a{};
     a.single_seg = single ? 1u : 0u; a.bits = bits; a.shift = j.top_bit - used_bits; a.bias = j.bias; a.tile = j.tile;
+    // (the link segments: tiles over the chunks laid end to end — the kernels of the usual link tile have that form)
+    a.span = (single && l == 0 && chunks > 1 && !j.hist0_done && j.tile == 4096 && bits <= kPartMaxBits && j.buf_f[0][0] == nullptr && part_span_enabled()) ? 1u : 0u;
     // runs of 16 consecutive tiles per XCD (xcd_tile; measured at 10 M amplicons: key partition 0.44 -> 0.33 ms, link partition
     // 0.39 -> 0.36, the same for runs of 8 .. 64) — unless there are fewer tiles than workgroups in flight, where the runs
     // would leave XCDs without work
@@ -1072,16 +1081,19 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
       p.csize_cap = j.csize_cap;
       p.chunks = (uint32_t)chunks;
       p.ctile = j.ctile[i]; p.cnt = j.cnt[i];
+      p.tchunk = j.ctile[i] + chunks + 1; p.tchunk_cap = (uint32_t)std::min<uint64_t>(tiles + 1, 0xFFFFFFFFu);
       p.next_start = j.starts[i] + (l & 1u) * j.starts_stride;
       p.total = j.total[i];
     }
     // (a multiple of 8 workgroups: turn v of the tile loops then stays on XCD v mod 8 — xcd_tile)
     const dim3 grid_t((unsigned)((std::min<uint64_t>(std::max<uint64_t>(tiles, 1), (uint64_t)cu_grid) + 7) & ~7ull), j.nidx);
-    hipLaunchKernelGGL(k_part_tiles, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a);
+    if (chunks > 2048) { hipLaunchKernelGGL(k_part_tiles<1024>, dim3(1, j.nidx), dim3(1024), 0, ctx->stream, a); }
+    else { hipLaunchKernelGGL(k_part_tiles<256>, dim3(1, j.nidx), dim3(256), 0, ctx->stream, a); }
     const bool bins1024 = bits > kPartMaxBits;                 // (the key records of the one-level form: 10 bits)
     if (l == 0 && j.hist0_done) { /* (k_keys has left the counts) */ }
     else if (bins1024) { hipLaunchKernelGGL((k_part_hist<1024, kPartTileMax, 256>), grid_t, dim3(256), 0, ctx->stream, a); }
     else if (j.tile == 8192) { hipLaunchKernelGGL((k_part_hist<512, 8192, 512>), grid_t, dim3(512), 0, ctx->stream, a); }
+    else if (a.span != 0u) { hipLaunchKernelGGL((k_part_hist<512, kPartTileMax, 256, true>), grid_t, dim3(256), 0, ctx->stream, a); }
     else { hipLaunchKernelGGL((k_part_hist<512, kPartTileMax, 256>), grid_t, dim3(256), 0, ctx->stream, a); }
     FlatScanArgs f{};
     f.unit_bits = bits;
@@ -1111,6 +1123,12 @@ static int run_partition(swa_ctx * ctx, PartJob & j) {
       const bool payload = j.buf_f[0][0] != nullptr;           // (a second array travels with index 0's records: nobody's since round 6)
       if (!payload && j.tile == 8192 && !bins1024) {
         if (last_level && j.out32[0] != nullptr) { SWA_SCATTER_WIDE(2, 512, 1); } else { SWA_SCATTER_WIDE(0, 512, 2); }
+      }
+      else if (a.span != 0u) {
+        // (4096 x 512, 512 threads: the form the link partition runs in; SWA_D1_PART_THREADS keeps the chunk-by-chunk kernels)
+        constexpr size_t lds = part_scatter_lds(0, 4096, 512);
+        if (last_level && j.out32[0] != nullptr) { hipLaunchKernelGGL((k_part_scatter<2, 4096, 512, 512, true>), grid_t, dim3(512), lds, ctx->stream, a); }
+        else { hipLaunchKernelGGL((k_part_scatter<0, 4096, 512, 512, true>), grid_t, dim3(512), lds, ctx->stream, a); }
       }
       else if (last_level && j.out32[0] != nullptr) { SWA_SCATTER(2, 4096, 512); }
       else if (bins1024 && j.tile == 8192) { if (payload) { SWA_SCATTER_WIDE(1, 1024, 0); } else { SWA_SCATTER_WIDE(0, 1024, 3); } }
