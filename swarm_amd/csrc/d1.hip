@@ -1458,7 +1458,12 @@ static int csr_from_chunks(swa_ctx * ctx, uint32_t first, uint32_t count, const 
   c.end_copy = extra;
   SWA_HIP(ctx, hipMemsetAsync(c.heavy_count, 0, sizeof(uint32_t), ctx->stream));
   swa_t0(ctx, 14);
-  const dim3 cgrid((unsigned)std::min<uint64_t>(((uint64_t)j.buckets + 3) / 4, (uint64_t)ctx->num_cus * 8));
+  // (as many workgroups as are resident together — every wave walks its share of the buckets; a grid of 8 a CU ran a second,
+  // partly empty round behind the first)
+  static const int csr_per_cu[2] = {
+    [] { int nb = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_csr_bucket<8>, 256, 0) == hipSuccess && nb > 0 ? nb : 4; }(),
+    [] { int nb = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_csr_bucket<9>, 256, 0) == hipSuccess && nb > 0 ? nb : 4; }() };
+  const dim3 cgrid((unsigned)std::min<uint64_t>(((uint64_t)j.buckets + 3) / 4, (uint64_t)ctx->num_cus * (uint64_t)csr_per_cu[r <= 8 ? 0 : 1]));
   if (r <= 8) { hipLaunchKernelGGL(k_csr_bucket<8>, cgrid, dim3(256), 0, ctx->stream, c); }
   else { hipLaunchKernelGGL(k_csr_bucket<9>, cgrid, dim3(256), 0, ctx->stream, c); }
   hipLaunchKernelGGL(k_csr_bucket_big, dim3((unsigned)ctx->num_cus * 4), dim3(256), 0, ctx->stream, c);
