@@ -6,6 +6,7 @@ TAG=${1:-closing}
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" | tee -a $O/status.txt
+cp $R/bench_detail.json $O/bench_detail.json 2>/dev/null     # (the side file of THIS run: the later --no-extras runs write their own)
 tail -c 600 $O/bench_default.json; echo
 KSTATS_LINES=40 timeout 600 bash tools/kstats.sh ${TAG}_step10M python $R/bench.py --steps 20 --warmup 3 --no-extras > $O/kstats.txt 2>&1; cp $R/gpurun_out/${TAG}_step10M_kernel_stats.csv $O/ 2>/dev/null
 head -14 $O/kstats.txt | cut -c1-150
