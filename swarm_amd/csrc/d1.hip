@@ -933,7 +933,8 @@ static ListRegions list_regions(const swa_ctx * ctx, uint64_t * total_items) {
     for (uint32_t k = 0; k < kListKinds; ++k) {
       r.at[c][k] = at;
       uint64_t room = 64;
-      if (ctx->class_pop[c] != 0) { room += k + 1 < kListKinds ? std::min<uint64_t>(ctx->class_pop[c], upto / least[k]) : upto / 64 + upto / least[k]; }
+      // (the tiled kernel's items: a row tile against kTiledCols column tiles — at most five an old row-tile item, group cap 4096)
+      if (ctx->class_pop[c] != 0) { room += k + 1 < kListKinds ? std::min<uint64_t>(ctx->class_pop[c], upto / least[k]) : 5u * (upto / 64 + upto / least[k]); }
       at += room;
     }
     r.at[c][kListKinds] = at;
