@@ -1495,7 +1495,11 @@ static int launch_csr_stream(swa_ctx * ctx, uint32_t first, uint32_t count, uint
 #define SWA_PAIR_CASE_DYN(KERNEL, P, WW, NN) \
   if (pass == P && width == WW && nwin == NN) { \
     const int bytes = (int)PairLayout<WW>::kDynamicBytes; \
-    if (bytes != 0) { SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<P, WW, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); } \
+    constexpr uint32_t bit_ = 1u << (P + (WW == 21 ? 2 : 0) + (NN == 2 ? 4 : (NN == 4 ? 8 : 0))); \
+    if (bytes != 0 && (ctx->pair_lds_opt_in & bit_) == 0u) {     /* (once per context: the call costs tens of microseconds now and then) */ \
+      SWA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<P, WW, NN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
+      ctx->pair_lds_opt_in |= bit_; \
+    } \
     hipLaunchKernelGGL((KERNEL<P, WW, NN>), dim3(grid), dim3(kThreads), (size_t)bytes, ctx->stream, a); return SWA_OK; }
 #define SWA_PAIR_WIDTH_DYN(KERNEL, WW) \
   SWA_PAIR_CASE_DYN(KERNEL, 0, WW, 1) SWA_PAIR_CASE_DYN(KERNEL, 1, WW, 1) SWA_PAIR_CASE_DYN(KERNEL, 0, WW, 2) SWA_PAIR_CASE_DYN(KERNEL, 1, WW, 2)

@@ -162,6 +162,7 @@ struct swa_ctx {
   int pair_blocks[4] = {};                      // workgroups of k_d1_group_pairs a CU holds, per width class (0: not asked yet)
   bool g1_lds_opt_in = false;                  // k_group1's dynamic-LDS attribute has been set on this context's device
   uint32_t part_lds_opt_in = 0;    // ... and the wide-tile forms of k_part_scatter (one bit each)
+  uint32_t pair_lds_opt_in = 0;    // ... and the W = 15 / 21 forms of k_d1_group_pairs (pass + 2 (W = 21) + 4 (NW = 2) + 8 (NW = 4))
   bool csr_has_diffs = false;                 // the resident network is a d >= 2 graph: one byte of differences per link behind the neighbours
   uint64_t csr_total = 0;
   swa_dbuf d_cluster, d_cluster_ctl;
