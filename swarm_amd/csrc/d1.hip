@@ -933,8 +933,9 @@ static ListRegions list_regions(const swa_ctx * ctx, uint64_t * total_items) {
     for (uint32_t k = 0; k < kListKinds; ++k) {
       r.at[c][k] = at;
       uint64_t room = 64;
-      // (the tiled kernel's items: a row tile against kTiledCols column tiles — at most five an old row-tile item, group cap 4096)
-      if (ctx->class_pop[c] != 0) { room += k + 1 < kListKinds ? std::min<uint64_t>(ctx->class_pop[c], upto / least[k]) : 5u * (upto / 64 + upto / least[k]); }
+      // (the tiled kernel's items: a row tile against kTiledCols column tiles — per row tile at most what the largest group has)
+      constexpr uint64_t per_row_tile = (tiled_item_count(kStreamGroupCap) + kStreamGroupCap / 64u - 1u) / (kStreamGroupCap / 64u);
+      if (ctx->class_pop[c] != 0) { room += k + 1 < kListKinds ? std::min<uint64_t>(ctx->class_pop[c], upto / least[k]) : per_row_tile * (upto / 64 + upto / least[k]); }
       at += room;
     }
     r.at[c][kListKinds] = at;
