@@ -484,6 +484,33 @@ __global__ __launch_bounds__(256) void k_dg_worklist(const unsigned long long * 
   }
 }
 
+// Round 6: the work list in the order of the alignments' expected length.  k_align_wfa runs a wave — four pairs — until its
+// LAST pair is done: a pair within d stops at its score, a pair beyond d takes every step; in the order the pair kernels
+// found them nearly every wave holds one of the latter.  Ordered by the q-gram distance of the two signatures (what the
+// filter measured: 0..30 differing bits x 10 for the pairs it let through), pairs that stop early share their waves.
+// key[i] for the work list's item i (both directions carry their pair's key).
+__global__ __launch_bounds__(256) void k_dg_work_keys(const uint32_t * __restrict__ wq, const uint32_t * __restrict__ wt, uint64_t nwork,
+                                                      const ulonglong2 * __restrict__ sigs, unsigned char * __restrict__ key,
+                                                      unsigned long long * __restrict__ packed) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t q = wq[i], t = wt[i];
+    const ulonglong2 * sq = sigs + (uint64_t)q * 8u;
+    const ulonglong2 * st = sigs + (uint64_t)t * 8u;
+    uint32_t pop = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { const ulonglong2 x = sq[w], y = st[w]; pop += (uint32_t)__popcll(x.x ^ y.x) + (uint32_t)__popcll(x.y ^ y.y); }
+    key[i] = (unsigned char)min(pop, 63u);
+    packed[i] = ((unsigned long long)q << 32) | t;
+  }
+}
+__global__ __launch_bounds__(256) void k_dg_work_unpack(const unsigned long long * __restrict__ packed, uint64_t nwork, uint32_t * __restrict__ wq,
+                                                        uint32_t * __restrict__ wt) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long v = packed[i];
+    wq[i] = (uint32_t)(v >> 32); wt[i] = (uint32_t)v;
+  }
+}
+
 // accepted alignments -> (query << 32 | target) keys + diffs, compacted.  A workgroup takes 2048 work items a turn — eight a
 // thread — and appends what it keeps with ONE atomic on the counter (a single address takes ~90 atomics a microsecond: one
 // per wave of 64 items was 50 000 of them, 0.55 of this kernel's 0.60 ms at 3.2 M items; round 6)
@@ -724,6 +751,22 @@ int swa_dn_graph_compute(swa_ctx * ctx, int no_cluster_breaking) {
       SWA_HIP(ctx, hipStreamSynchronize(ctx->stream));
       const uint64_t nwork = npairs + extra;
       ctx->dn_aligned = nwork;
+      // the wavefront kernel's work in the order of its expected length (k_dg_work_keys; SWA_DN_ALIGN_ORDER=0: as found)
+      static const bool ordered = [] { const char * e = getenv("SWA_DN_ALIGN_ORDER"); return !(e != nullptr && e[0] == '0'); }();
+      if (ordered && nwork > 1 && ctx->d_qgrams.ptr != nullptr) {
+        SWA_TRY(swa_reserve(ctx, ctx->d_dn_keys, 2 * nwork * sizeof(uint64_t)));          // packed items: in | out (the edges' keys later)
+        SWA_TRY(swa_reserve(ctx, ctx->d_dn_vals, 2 * nwork * sizeof(uint32_t)));          // keys: in | out (bytes; the edges' values later)
+        auto * packed = static_cast<unsigned long long *>(ctx->d_dn_keys.ptr);
+        auto * wkey = static_cast<unsigned char *>(ctx->d_dn_vals.ptr);
+        hipLaunchKernelGGL(k_dg_work_keys, dim3(grid_for(ctx, nwork)), dim3(256), 0, ctx->stream, wq, wt, nwork,
+                           static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr), wkey, packed);
+        size_t order_bytes = 0;
+        (void)rocprim::radix_sort_pairs(nullptr, order_bytes, wkey, wkey + nwork, packed, packed + nwork, nwork, 0, 6, ctx->stream);
+        SWA_TRY(swa_reserve(ctx, ctx->d_scan_hits, order_bytes + 16));
+        SWA_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_scan_hits.ptr, order_bytes, wkey, wkey + nwork, packed, packed + nwork, nwork, 0, 6, ctx->stream));
+        hipLaunchKernelGGL(k_dg_work_unpack, dim3(grid_for(ctx, nwork)), dim3(256), 0, ctx->stream, packed + nwork, nwork, wq, wt);
+        launches += 4;
+      }
       // (the launcher takes 32-bit counts: in slices)
       for (uint64_t at = 0; at < nwork; at += 0x40000000ull) {
         const uint32_t cnt = (uint32_t)std::min<uint64_t>(0x40000000ull, nwork - at);
