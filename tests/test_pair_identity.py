@@ -296,3 +296,39 @@ def test_shortened_chains_answer_as_the_full_chains(W, NW):
                 linked += int(short)
         checked += 1
     assert checked > 3000 and linked > 500
+
+
+# ---- round 6: the tiled kernel's items and the room the host gives them -----------------------------------------------------------
+def _tiled_item_count(members: int, cols: int = 4) -> int:
+    """tiled_item_count (d1_anchor.inc): a row tile of 64 members against its column tiles, `cols` (kTiledCols) at a time"""
+    tiles = (members + 63) // 64
+    return sum((tiles - r + cols - 1) // cols for r in range(tiles))
+
+
+def test_the_item_regions_hold_the_tiled_kernels_items_whatever_the_groups():
+    """list_regions (d1.hip) gives the tiled list per_row_tile * (pop / 64 + pop / 257) items, per_row_tile = what the largest
+    group (kStreamGroupCap = 4096 members) makes of one of its row tiles, rounded up.  Whatever mix of groups of 257..4096
+    members a population holds, their items fit: items(g) / row_tiles(g) grows with g, row_tiles(g) <= g / 64 + 1, and there
+    are at most pop / 257 groups."""
+    cap, least = 4096, 257
+    per_row_tile = -(-_tiled_item_count(cap) // (cap // 64))
+    ratios = [_tiled_item_count(g) / ((g + 63) // 64) for g in range(least, cap + 1)]
+    assert max(ratios) <= per_row_tile and ratios[-1] == max(ratios)
+    rng = np.random.default_rng(6)
+    for _ in range(300):
+        sizes = []
+        pop = int(rng.integers(least, 200_000))
+        left = pop
+        while left >= least:
+            kind = int(rng.integers(0, 4))
+            g = [least, cap, int(rng.integers(least, cap + 1)), 64 * int(rng.integers(5, 65)) + 1][kind]
+            g = min(g, left, cap)
+            if g < least:
+                break
+            sizes.append(g)
+            left -= g
+        items = sum(_tiled_item_count(g) for g in sizes)
+        room = 64 + per_row_tile * (pop // 64 + pop // least)
+        assert items <= room, (pop, len(sizes), items, room)
+    # the 16 bits an item's chunk has: row tile (6 bits) | part << 6
+    assert (cap // 64 - 1) | (((cap // 64 + 3) // 4 - 1) << 6) < 1 << 16
