@@ -487,11 +487,12 @@ __global__ __launch_bounds__(256) void k_dg_worklist(const unsigned long long * 
 // Round 6: the work list in the order of the alignments' expected length.  k_align_wfa runs a wave — four pairs — until its
 // LAST pair is done: a pair within d stops at its score, a pair beyond d takes every step; in the order the pair kernels
 // found them nearly every wave holds one of the latter.  Ordered by the q-gram distance of the two signatures (what the
-// filter measured: 0..30 differing bits x 10 for the pairs it let through), pairs that stop early share their waves.
+// filter measured: 0..30 differing bits for the pairs it let through) plus ten a nucleotide of length difference (a gap
+// costs more than a mismatch), pairs that stop early share their waves.
 // key[i] for the work list's item i (both directions carry their pair's key).
 __global__ __launch_bounds__(256) void k_dg_work_keys(const uint32_t * __restrict__ wq, const uint32_t * __restrict__ wt, uint64_t nwork,
-                                                      const ulonglong2 * __restrict__ sigs, unsigned char * __restrict__ key,
-                                                      unsigned long long * __restrict__ packed) {
+                                                      const ulonglong2 * __restrict__ sigs, const uint32_t * __restrict__ seqlen, uint32_t len_weight,
+                                                      unsigned char * __restrict__ key, unsigned long long * __restrict__ packed) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t q = wq[i], t = wt[i];
     const ulonglong2 * sq = sigs + (uint64_t)q * 8u;
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(256) void k_dg_work_keys(const uint32_t * __restric
     uint32_t pop = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { const ulonglong2 x = sq[w], y = st[w]; pop += (uint32_t)__popcll(x.x ^ y.x) + (uint32_t)__popcll(x.y ^ y.y); }
-    key[i] = (unsigned char)min(pop, 63u);
+    const uint32_t lq = seqlen[q], lt = seqlen[t];
+    key[i] = (unsigned char)min(pop + len_weight * (max(lq, lt) - min(lq, lt)), 63u);
     packed[i] = ((unsigned long long)q << 32) | t;
   }
 }
@@ -753,13 +755,14 @@ int swa_dn_graph_compute(swa_ctx * ctx, int no_cluster_breaking) {
       ctx->dn_aligned = nwork;
       // the wavefront kernel's work in the order of its expected length (k_dg_work_keys; SWA_DN_ALIGN_ORDER=0: as found)
       static const bool ordered = [] { const char * e = getenv("SWA_DN_ALIGN_ORDER"); return !(e != nullptr && e[0] == '0'); }();
+      static const uint32_t align_len_weight = [] { const char * e = getenv("SWA_DN_ALIGN_LEN_WEIGHT"); return e != nullptr ? (uint32_t)atoi(e) : 10u; }();   // (a nucleotide of length difference counts as ten signature bits: alignments + CSR 6.9-7.1 -> 6.5-6.6 ms against 0; 5 and 20: 7.0 / 6.8)
       if (ordered && nwork > 1 && ctx->d_qgrams.ptr != nullptr) {
         SWA_TRY(swa_reserve(ctx, ctx->d_dn_keys, 2 * nwork * sizeof(uint64_t)));          // packed items: in | out (the edges' keys later)
         SWA_TRY(swa_reserve(ctx, ctx->d_dn_vals, 2 * nwork * sizeof(uint32_t)));          // keys: in | out (bytes; the edges' values later)
         auto * packed = static_cast<unsigned long long *>(ctx->d_dn_keys.ptr);
         auto * wkey = static_cast<unsigned char *>(ctx->d_dn_vals.ptr);
         hipLaunchKernelGGL(k_dg_work_keys, dim3(grid_for(ctx, nwork)), dim3(256), 0, ctx->stream, wq, wt, nwork,
-                           static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr), wkey, packed);
+                           static_cast<const ulonglong2 *>(ctx->d_qgrams.ptr), ctx->db.seqlen, align_len_weight, wkey, packed);
         size_t order_bytes = 0;
         (void)rocprim::radix_sort_pairs(nullptr, order_bytes, wkey, wkey + nwork, packed, packed + nwork, nwork, 0, 6, ctx->stream);
         SWA_TRY(swa_reserve(ctx, ctx->d_scan_hits, order_bytes + 16));
